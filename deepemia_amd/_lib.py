@@ -1,0 +1,138 @@
+"""ctypes binding of ``libdeepemia_hip.so`` (the C ABI declared in ``include/deepemia_hip.h``).
+
+The product path has **no CPU fallback**: if the shared library is missing, or a kernel
+entry returns an error, this module raises.  PyTorch is used only for device memory and
+streams; every pointer handed to the library is a raw device pointer.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "csrc" / "libdeepemia_hip.so"
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
+RES_NONE, RES_SAME, RES_UP2 = 0, 1, 2
+
+
+class HipExtensionMissing(RuntimeError):
+    pass
+
+
+class HipKernelError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("in_", C.c_void_p), ("w", C.c_void_p), ("scale", C.c_void_p), ("bias", C.c_void_p),
+        ("residual", C.c_void_p), ("out", C.c_void_p),
+        ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32),
+        ("Ho", C.c_int32), ("Wo", C.c_int32), ("Cout", C.c_int32), ("CoutPad", C.c_int32),
+        ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+        ("dtype", C.c_int32), ("out_dtype", C.c_int32), ("act", C.c_int32), ("res_mode", C.c_int32),
+        ("out_ld", C.c_int32), ("tile_hint", C.c_int32),
+    ]
+
+
+class RpnDesc(C.Structure):
+    _fields_ = [
+        ("head", C.c_void_p * 5), ("H", C.c_int32 * 5), ("W", C.c_int32 * 5), ("stride", C.c_int32 * 5),
+        ("cell_anchors", C.c_void_p), ("head_ld", C.c_int32), ("N", C.c_int32),
+        ("img_h", C.c_int32), ("img_w", C.c_int32), ("pre_topk", C.c_int32), ("post_topk", C.c_int32),
+        ("nms_thresh", C.c_float), ("out_boxes", C.c_void_p), ("out_scores", C.c_void_p),
+        ("out_count", C.c_void_p), ("workspace", C.c_void_p),
+    ]
+
+
+class RoiAlignDesc(C.Structure):
+    _fields_ = [
+        ("feat", C.c_void_p * 4), ("H", C.c_int32 * 4), ("W", C.c_int32 * 4),
+        ("N", C.c_int32), ("R", C.c_int32), ("C", C.c_int32), ("P", C.c_int32), ("dtype", C.c_int32),
+        ("boxes", C.c_void_p), ("count", C.c_void_p), ("out", C.c_void_p),
+    ]
+
+
+class DetsDesc(C.Structure):
+    _fields_ = [
+        ("logits", C.c_void_p), ("ld", C.c_int32), ("props", C.c_void_p), ("prop_count", C.c_void_p),
+        ("N", C.c_int32), ("R", C.c_int32), ("K", C.c_int32), ("img_h", C.c_int32), ("img_w", C.c_int32),
+        ("score_thresh", C.c_float), ("nms_thresh", C.c_float), ("topk", C.c_int32),
+        ("det_boxes", C.c_void_p), ("det_scores", C.c_void_p), ("det_classes", C.c_void_p),
+        ("det_count", C.c_void_p),
+    ]
+
+
+class PasteDesc(C.Structure):
+    _fields_ = [
+        ("mask_prob", C.c_void_p), ("ld", C.c_int32), ("det_boxes", C.c_void_p), ("det_classes", C.c_void_p),
+        ("det_count", C.c_void_p), ("N", C.c_int32), ("D", C.c_int32), ("img_h", C.c_int32), ("img_w", C.c_int32),
+        ("out_h", C.c_int32), ("out_w", C.c_int32), ("out_boxes", C.c_void_p), ("valid", C.c_void_p),
+        ("packed", C.c_void_p),
+    ]
+
+
+# every symbol include/deepemia_hip.h declares (tests check the library exports all of them)
+EXPORTS = {
+    "demia_abi_version": (C.c_int, []),
+    "demia_last_error": (C.c_char_p, []),
+    "demia_build_arch": (C.c_char_p, []),
+    "demia_conv2d_nhwc": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "demia_resize_h_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "demia_resize_v_norm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_int,
+                                       C.c_void_p]),
+    "demia_stem_conv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                   C.c_int, C.c_int, C.c_void_p]),
+    "demia_maxpool3x3s2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "demia_subsample2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "demia_rpn_workspace_bytes": (C.c_int64, [C.c_int]),
+    "demia_rpn_proposals": (C.c_int, [C.POINTER(RpnDesc), C.c_void_p]),
+    "demia_roi_align": (C.c_int, [C.POINTER(RoiAlignDesc), C.c_void_p]),
+    "demia_box_detections": (C.c_int, [C.POINTER(DetsDesc), C.c_void_p]),
+    "demia_paste_masks": (C.c_int, [C.POINTER(PasteDesc), C.c_void_p]),
+    "demia_unpack_masks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+    "demia_mask_area_bbox": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the HIP library or raise :class:`HipExtensionMissing` -- never fall back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise HipExtensionMissing(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"(or `make -C {LIB_PATH.parent}`); there is no CPU fallback for the hot path."
+        )
+    try:
+        lib = C.CDLL(str(LIB_PATH), mode=getattr(os, "RTLD_NOW", 2))
+    except OSError as e:  # missing libamdhip64 etc.
+        raise HipExtensionMissing(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in EXPORTS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HipExtensionMissing(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = load().demia_last_error().decode(errors="replace")
+        raise HipKernelError(f"{what} failed with status {status}: {msg}")
+
+
+def ptr(t) -> int:
+    """Raw device pointer of a torch tensor (None -> NULL)."""
+    return 0 if t is None else int(t.data_ptr())

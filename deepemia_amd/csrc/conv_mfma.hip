@@ -1,0 +1,352 @@
+// Implicit-GEMM convolution on the CDNA4 matrix cores (gfx950).
+//
+//   out[m, co] = act( (sum_{kh,kw,ci} in[n, ho*s+kh-p, wo*s+kw-p, ci] * w[co, kh, kw, ci]) * scale[co]
+//                     + bias[co] + residual[m, co] )          m = (n, ho, wo)
+//
+// GEMM view: M = N*Ho*Wo output pixels (A rows, gathered on the fly from NHWC),
+// N = Cout (B rows = packed weights, K-contiguous), K = KH*KW*Cin walked in steps of
+// 128 bytes of one (kh, kw) tap, so a K-step of one A row is ONE contiguous 128-B run
+// of the input tensor (or zeros when the tap falls into the padding).
+//
+// Work decomposition for 64-wide wavefronts: 256 threads = 4 waves; each wave owns
+// TM x TN MFMA tiles of 32x32 (v_mfma_f32_32x32x16_bf16, or the exact-f32
+// v_mfma_f32_32x32x2_f32 in the parity build), accumulators stay in registers for
+// the whole K loop.  A/B tiles are register-staged into a double-buffered LDS image
+// with 144-byte rows (128 B + one 16-B pad => ds_read_b128 is bank-conflict free),
+// global loads for step s+1 are issued before the MFMAs of step s and written to LDS
+// after them (one barrier per K-step).  The epilogue goes through LDS so that
+// scale/bias/residual/activation run on, and global memory sees, 16-byte rows.
+//
+// Reference call sites replaced: every Conv2d/Linear/ConvTranspose2d executed by
+// Detectron2 0.6 `GeneralizedRCNN.inference` under `predictor(image)`
+// (reference src/functions/inference.py:1395,1398,1507,1669; src/data/models.py:107).
+#include "common.h"
+
+namespace {
+
+struct ConvP {
+    const void* in;
+    const void* w;
+    const float* scale;
+    const float* bias;
+    const void* residual;
+    void* out;
+    int N, H, W, Cin, Ho, Wo, Cout, CoutPad, KH, KW, stride, pad;
+    int act, res_mode, out_ld;
+    int M, HoWo, ntn, nwg, ksteps, csteps, vec_ok;
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    // one 16-byte fragment = 8 bf16 = one 32x32x16 MFMA
+    static __device__ __forceinline__ f32x16 run(const uint4& a, const uint4& b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&a),
+                                                       *reinterpret_cast<const bf16x8*>(&b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    // one 16-byte fragment = 4 f32 = four 32x32x2 MFMAs.  Lane half h owns k = 4h..4h+3 of
+    // each 8-wide chunk (a permutation of the k order; the sum is over all of them).
+    static __device__ __forceinline__ f32x16 run(const uint4& a, const uint4& b, f32x16 c) {
+        const float* af = reinterpret_cast<const float*>(&a);
+        const float* bf = reinterpret_cast<const float*>(&b);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0], bf[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1], bf[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[2], bf[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[3], bf[3], c, 0, 0, 0);
+        return c;
+    }
+};
+
+template <typename TO> __device__ __forceinline__ void store4(TO* p, const float v[4]);
+template <> __device__ __forceinline__ void store4<float>(float* p, const float v[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const float v[4]) {
+    bf16x4 o;
+    o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
+    *reinterpret_cast<bf16x4*>(p) = o;
+}
+template <typename TO> __device__ __forceinline__ void load4(const TO* p, float v[4]);
+template <> __device__ __forceinline__ void load4<float>(const float* p, float v[4]) {
+    float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float v[4]) {
+    bf16x4 t = *reinterpret_cast<const bf16x4*>(p);
+    v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == DEMIA_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == DEMIA_ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+    return v;
+}
+
+constexpr int ROWB = 144;  // bytes per LDS tile row: 128 B of K + 16 B pad
+
+template <typename T, typename TO, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
+    constexpr int BM = WM * TM * 32;
+    constexpr int BN = WN * TN * 32;
+    constexpr int EPV = 16 / (int)sizeof(T);   // elements per 16-B vector
+    constexpr int BK = 128 / (int)sizeof(T);   // elements per K-step
+    constexpr int AV = BM / 32;                // A vectors per thread per K-step
+    constexpr int BV = BN / 32;                // B vectors per thread per K-step
+    constexpr int STAGE = (BM + BN) * ROWB;
+    constexpr int EROW = BN * 4 + 16;          // epilogue LDS row (f32) + pad
+    static_assert(BM * EROW <= 2 * STAGE, "epilogue staging must fit in the tile buffers");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int swz = xcd_remap(blockIdx.x, p.nwg);
+    const int tile_n = swz % p.ntn;
+    const int tile_m = swz / p.ntn;
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+
+    const T* __restrict__ in = reinterpret_cast<const T*>(p.in);
+    const T* __restrict__ wt = reinterpret_cast<const T*>(p.w);
+
+    // ---- per-thread gather bookkeeping --------------------------------------------------
+    const int chunk = tid & 7;
+    const int lrow = tid >> 3;  // 0..31
+    long a_base[AV];
+    int a_hi0[AV], a_wi0[AV];
+    bool a_vm[AV];
+#pragma unroll
+    for (int i = 0; i < AV; ++i) {
+        const int m = m0 + lrow + 32 * i;
+        a_vm[i] = m < p.M;
+        const int mm = a_vm[i] ? m : 0;
+        const int n = mm / p.HoWo;
+        const int rem = mm - n * p.HoWo;
+        const int ho = rem / p.Wo;
+        const int wo = rem - ho * p.Wo;
+        a_hi0[i] = ho * p.stride - p.pad;
+        a_wi0[i] = wo * p.stride - p.pad;
+        a_base[i] = (((long)n * p.H + a_hi0[i]) * p.W + a_wi0[i]) * p.Cin + chunk * EPV;
+    }
+    const long Ktot = (long)p.KH * p.KW * p.Cin;
+    long b_off[BV];
+    bool b_vm[BV];
+#pragma unroll
+    for (int i = 0; i < BV; ++i) {
+        const int co = n0 + lrow + 32 * i;
+        b_vm[i] = co < p.CoutPad;
+        b_off[i] = (long)(b_vm[i] ? co : 0) * Ktot + chunk * EPV;
+    }
+
+    uint4 ra[AV], rb[BV];
+    int kh = 0, kw = 0, c0 = 0;  // tap / channel offset of the step being LOADED
+
+    auto load_step = [&]() {
+        const long tap = ((long)kh * p.W + kw) * p.Cin + c0;
+#pragma unroll
+        for (int i = 0; i < AV; ++i) {
+            const int hi = a_hi0[i] + kh, wi = a_wi0[i] + kw;
+            const bool ok = a_vm[i] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            ra[i] = ok ? *reinterpret_cast<const uint4*>(in + a_base[i] + tap) : make_uint4(0, 0, 0, 0);
+        }
+        const long kof = ((long)kh * p.KW + kw) * p.Cin + c0;
+#pragma unroll
+        for (int i = 0; i < BV; ++i)
+            rb[i] = b_vm[i] ? *reinterpret_cast<const uint4*>(wt + b_off[i] + kof) : make_uint4(0, 0, 0, 0);
+        c0 += BK;
+        if (c0 >= p.Cin) { c0 = 0; if (++kw == p.KW) { kw = 0; ++kh; } }
+    };
+    auto store_step = [&](int buf) {
+        char* sA = smem + buf * STAGE;
+        char* sB = sA + BM * ROWB;
+#pragma unroll
+        for (int i = 0; i < AV; ++i)
+            *reinterpret_cast<uint4*>(sA + (lrow + 32 * i) * ROWB + chunk * 16) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BV; ++i)
+            *reinterpret_cast<uint4*>(sB + (lrow + 32 * i) * ROWB + chunk * 16) = rb[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int frag_off = (lane & 31) * ROWB + (lane >> 5) * 16;
+    const int a_row0 = wm * TM * 32;
+    const int b_row0 = wn * TN * 32;
+
+    load_step();
+    store_step(0);
+    __syncthreads();
+
+    for (int s = 0; s < p.ksteps; ++s) {
+        const int buf = s & 1;
+        const bool more = (s + 1) < p.ksteps;
+        if (more) load_step();
+        const char* sA = smem + buf * STAGE + a_row0 * ROWB + frag_off;
+        const char* sB = smem + buf * STAGE + BM * ROWB + b_row0 * ROWB + frag_off;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            uint4 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const uint4*>(sA + i * 32 * ROWB + kk * 32);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const uint4*>(sB + j * 32 * ROWB + kk * 32);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::run(fa[i], fb[j], acc[i][j]);
+        }
+        if (more) store_step(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: accumulators -> LDS (f32) -> 16-byte rows --------------------------
+    // C layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    {
+        float* e = reinterpret_cast<float*>(smem);
+        constexpr int EF = EROW / 4;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = a_row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const int col = b_row0 + j * 32 + (lane & 31);
+                    e[row * EF + col] = acc[i][j][r];
+                }
+    }
+    __syncthreads();
+    {
+        constexpr int G = BN / 4;          // 4-channel groups per row
+        constexpr int RPP = 256 / G;       // rows per pass
+        const int g = tid % G;
+        const int r0 = tid / G;
+        const int co = n0 + g * 4;
+        TO* __restrict__ out = reinterpret_cast<TO*>(p.out);
+        const TO* __restrict__ res = reinterpret_cast<const TO*>(p.residual);
+        if (co < p.Cout) {
+            float sc[4], bs[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool ok = (co + q) < p.Cout;
+                sc[q] = (p.scale && ok) ? p.scale[co + q] : 1.0f;
+                bs[q] = (p.bias && ok) ? p.bias[co + q] : 0.0f;
+            }
+            const char* e = smem;
+            for (int r = r0; r < BM; r += RPP) {
+                const int m = m0 + r;
+                if (m >= p.M) break;
+                const float4 a4 = *reinterpret_cast<const float4*>(e + r * EROW + g * 16);
+                float v[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = v[q] * sc[q] + bs[q];
+                if (p.res_mode != DEMIA_RES_NONE) {
+                    long ridx;
+                    if (p.res_mode == DEMIA_RES_SAME) {
+                        ridx = (long)m * p.Cout + co;
+                    } else {
+                        const int n = m / p.HoWo;
+                        const int rem = m - n * p.HoWo;
+                        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+                        const int Hr = (p.Ho + 1) >> 1, Wr = (p.Wo + 1) >> 1;
+                        ridx = (((long)n * Hr + (ho >> 1)) * Wr + (wo >> 1)) * p.Cout + co;
+                    }
+                    if (p.vec_ok) {
+                        float rv[4];
+                        load4<TO>(res + ridx, rv);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] += rv[q];
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (co + q < p.Cout) v[q] += to_f32<TO>(res[ridx + q]);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = apply_act(v[q], p.act);
+                TO* o = out + (long)m * p.out_ld + co;
+                if (p.vec_ok) {
+                    store4<TO>(o, v);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (co + q < p.Cout) o[q] = from_f32<TO>(v[q]);
+                }
+            }
+        }
+    }
+}
+
+template <typename T, typename TO, int WM, int WN, int TM, int TN>
+int launch_cfg(ConvP p, hipStream_t st) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int smem = 2 * (BM + BN) * ROWB;
+    p.ntn = cdiv(p.CoutPad, BN);
+    const int ntm = cdiv(p.M, BM);
+    p.nwg = p.ntn * ntm;
+    auto k = conv_igemm_kernel<T, TO, WM, WN, TM, TN>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k, dim3(p.nwg), dim3(256), smem, st, p);
+    DEMIA_CHECK_LAUNCH("conv_igemm_kernel");
+    return DEMIA_OK;
+}
+
+template <typename T, typename TO>
+int launch_typed(ConvP p, int bn, hipStream_t st) {
+    if (bn == 128) return launch_cfg<T, TO, 2, 2, 2, 2>(p, st);
+    if (bn == 64) return launch_cfg<T, TO, 4, 1, 1, 2>(p, st);
+    return launch_cfg<T, TO, 4, 1, 1, 1>(p, st);
+}
+
+}  // namespace
+
+extern "C" int demia_conv2d_nhwc(const demia_conv_desc* d, void* stream) {
+    DEMIA_REQUIRE(d && d->in && d->w && d->out, "null pointer");
+    DEMIA_REQUIRE(d->dtype == DEMIA_F32 || d->dtype == DEMIA_BF16, "dtype");
+    DEMIA_REQUIRE(d->out_dtype == DEMIA_F32 || d->out_dtype == DEMIA_BF16, "out_dtype");
+    const int bk = d->dtype == DEMIA_BF16 ? 64 : 32;
+    DEMIA_REQUIRE(d->Cin > 0 && d->Cin % bk == 0, "Cin must be a multiple of 64 (bf16) / 32 (f32)");
+    DEMIA_REQUIRE(d->CoutPad >= d->Cout && d->CoutPad % 32 == 0, "CoutPad");
+    DEMIA_REQUIRE(d->KH > 0 && d->KW > 0 && d->stride > 0 && d->pad >= 0, "kernel geometry");
+    DEMIA_REQUIRE(d->Ho == (d->H + 2 * d->pad - d->KH) / d->stride + 1, "Ho");
+    DEMIA_REQUIRE(d->Wo == (d->W + 2 * d->pad - d->KW) / d->stride + 1, "Wo");
+    DEMIA_REQUIRE(d->res_mode == DEMIA_RES_NONE || d->residual, "residual pointer");
+    DEMIA_REQUIRE((long)d->N * d->Ho * d->Wo < (1L << 31), "M overflow");
+    ConvP p;
+    p.in = d->in; p.w = d->w; p.scale = d->scale; p.bias = d->bias; p.residual = d->residual; p.out = d->out;
+    p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo;
+    p.Cout = d->Cout; p.CoutPad = d->CoutPad; p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad;
+    p.act = d->act; p.res_mode = d->res_mode;
+    p.out_ld = d->out_ld > 0 ? d->out_ld : d->Cout;
+    DEMIA_REQUIRE(p.out_ld >= d->Cout, "out_ld");
+    p.M = d->N * d->Ho * d->Wo;
+    p.HoWo = d->Ho * d->Wo;
+    p.csteps = d->Cin / bk;
+    p.ksteps = d->KH * d->KW * p.csteps;
+    p.vec_ok = (d->Cout % 4 == 0 && p.out_ld % 4 == 0) ? 1 : 0;
+    p.ntn = p.nwg = 0;
+    if (p.M == 0) return DEMIA_OK;
+    int bn = d->tile_hint;
+    if (bn != 128 && bn != 64 && bn != 32) bn = d->CoutPad >= 128 ? 128 : (d->CoutPad >= 64 ? 64 : 32);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (d->dtype == DEMIA_BF16) {
+        if (d->out_dtype == DEMIA_BF16) return launch_typed<bf16_t, bf16_t>(p, bn, st);
+        return launch_typed<bf16_t, float>(p, bn, st);
+    }
+    DEMIA_REQUIRE(d->out_dtype == DEMIA_F32, "f32 input requires f32 output");
+    return launch_typed<float, float>(p, bn, st);
+}

@@ -1,0 +1,205 @@
+// Full-resolution mask paste -> bit-packed masks, plus the packed-mask utilities that keep
+// N x H x W masks off PCIe (the reference copies them to the host three times per call,
+// src/functions/inference.py:1401-1403).
+//
+// Replaces detectron2.layers.mask_ops.paste_masks_in_image / _do_paste_mask (v0.6) and
+// detector_postprocess's box rescale + clip + nonempty filter.  -ffp-contract=off: the
+// sampling-grid arithmetic follows torch's separate fp32 ops, then the grid_sample
+// (bilinear, zeros padding, align_corners=False) formula.
+//
+// Output layout: one bit per pixel, 32 pixels per u32 word, bit (x & 31) of word (x >> 5);
+// a 2048 x 2048 mask is 512 KiB instead of the reference's 4 MiB bool array.
+#include "common.h"
+
+namespace {
+
+struct PasteP {
+    const float* mask_prob;
+    int ld;
+    const float* det_boxes;
+    const int* det_classes;
+    const int* det_count;
+    int N, D, img_h, img_w, out_h, out_w;
+    float* out_boxes;
+    uint8_t* valid;
+    uint32_t* packed;
+};
+
+constexpr int PASTE_ROWS = 8;
+
+__global__ __launch_bounds__(256) void paste_kernel(const PasteP p) {
+    __shared__ float sm[28 * 28];
+    __shared__ float sbox[4];
+    __shared__ int sflag;
+    const int inst = blockIdx.y;  // n * D + i
+    const int n = inst / p.D, i = inst - n * p.D;
+    const int tid = threadIdx.x;
+    const int wpr = p.out_w >> 5;  // words per row
+    const int row0 = blockIdx.x * PASTE_ROWS;
+    uint32_t* dst = p.packed + ((long)inst * p.out_h + row0) * wpr;
+    const int nrows = min(PASTE_ROWS, p.out_h - row0);
+    if (tid == 0) {
+        int ok = i < p.det_count[n];
+        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) {
+            const float4 nb = reinterpret_cast<const float4*>(p.det_boxes)[inst];
+            const float sx = (float)((double)p.out_w / (double)p.img_w);
+            const float sy = (float)((double)p.out_h / (double)p.img_h);
+            b.x = fminf(fmaxf(nb.x * sx, 0.f), (float)p.out_w);
+            b.z = fminf(fmaxf(nb.z * sx, 0.f), (float)p.out_w);
+            b.y = fminf(fmaxf(nb.y * sy, 0.f), (float)p.out_h);
+            b.w = fminf(fmaxf(nb.w * sy, 0.f), (float)p.out_h);
+            ok = ((b.z - b.x) > 0.f) && ((b.w - b.y) > 0.f);
+        }
+        sbox[0] = b.x; sbox[1] = b.y; sbox[2] = b.z; sbox[3] = b.w;
+        sflag = ok;
+        if (blockIdx.x == 0) {
+            reinterpret_cast<float4*>(p.out_boxes)[inst] = b;
+            p.valid[inst] = (uint8_t)ok;
+        }
+    }
+    __syncthreads();
+    const float x0 = sbox[0], y0 = sbox[1], x1 = sbox[2], y1 = sbox[3];
+    const int x0i = max((int)floorf(x0) - 1, 0), y0i = max((int)floorf(y0) - 1, 0);
+    const int x1i = min((int)ceilf(x1) + 1, p.out_w), y1i = min((int)ceilf(y1) + 1, p.out_h);
+    const bool live = sflag && (row0 < y1i) && (row0 + nrows > y0i);
+    if (!live) {
+        for (int w = tid; w < nrows * wpr; w += 256) dst[w] = 0u;
+        return;
+    }
+    {
+        const int cls = p.det_classes[inst];
+        const float* mp = p.mask_prob + (long)inst * 196 * 4 * p.ld + cls;
+        for (int e = tid; e < 784; e += 256) {
+            const int yy = e / 28, xx = e - yy * 28;
+            const int cell = (yy >> 1) * 14 + (xx >> 1), sub = (yy & 1) * 2 + (xx & 1);
+            sm[e] = mp[(long)(cell * 4 + sub) * p.ld];
+        }
+    }
+    __syncthreads();
+    const float invw = x1 - x0, invh = y1 - y0;
+    for (int w = tid; w < nrows * wpr; w += 256) {
+        const int ry = w / wpr, wx = w - ry * wpr;
+        const int Y = row0 + ry;
+        uint32_t bits = 0u;
+        const int xa = wx << 5;
+        if (Y >= y0i && Y < y1i && xa < x1i && xa + 32 > x0i) {
+            float gy = ((float)Y + 0.5f - y0) / invh * 2.0f - 1.0f;
+            const float iy = ((gy + 1.0f) * 28.0f - 1.0f) / 2.0f;
+            const float yn = floorf(iy);
+            const float ns = iy - yn, ss = 1.0f - ns;  // weights: n (south part), s
+            const int yi0 = (int)yn, yi1 = yi0 + 1;
+            const bool vy0 = (unsigned)yi0 < 28u, vy1 = (unsigned)yi1 < 28u;
+            const float* r0 = sm + (vy0 ? yi0 : 0) * 28;
+            const float* r1 = sm + (vy1 ? yi1 : 0) * 28;
+            for (int bx = 0; bx < 32; ++bx) {
+                const int X = xa + bx;
+                if (X < x0i || X >= x1i) continue;
+                float gx = ((float)X + 0.5f - x0) / invw * 2.0f - 1.0f;
+                const float ix = ((gx + 1.0f) * 28.0f - 1.0f) / 2.0f;
+                const float xw = floorf(ix);
+                const float we = ix - xw, ww = 1.0f - we;
+                const int xi0 = (int)xw, xi1 = xi0 + 1;
+                const bool vx0 = (unsigned)xi0 < 28u, vx1 = (unsigned)xi1 < 28u;
+                const float nw = (vy0 && vx0) ? r0[xi0] : 0.f;
+                const float ne = (vy0 && vx1) ? r0[xi1] : 0.f;
+                const float sw = (vy1 && vx0) ? r1[xi0] : 0.f;
+                const float se = (vy1 && vx1) ? r1[xi1] : 0.f;
+                const float v = nw * (ss * ww) + ne * (ss * we) + sw * (ns * ww) + se * (ns * we);
+                if (v >= 0.5f) bits |= 1u << bx;
+            }
+        }
+        dst[w] = bits;
+    }
+}
+
+__global__ void unpack_kernel(const uint32_t* __restrict__ packed, uint8_t* __restrict__ out, long nwords) {
+    for (long w = blockIdx.x * (long)blockDim.x + threadIdx.x; w < nwords; w += (long)gridDim.x * blockDim.x) {
+        const uint32_t b = packed[w];
+        uint32_t o[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const uint32_t nib = (b >> (4 * q)) & 15u;
+            o[q] = (nib & 1u) | ((nib & 2u) << 7) | ((nib & 4u) << 14) | ((nib & 8u) << 21);
+        }
+        uint4* d = reinterpret_cast<uint4*>(out + w * 32);
+        d[0] = make_uint4(o[0], o[1], o[2], o[3]);
+        d[1] = make_uint4(o[4], o[5], o[6], o[7]);
+    }
+}
+
+// one block per mask: popcount + tight bbox (y0, x0, y1, x1 inclusive; -1 when empty)
+__global__ __launch_bounds__(1024) void area_bbox_kernel(const uint32_t* __restrict__ packed, int* __restrict__ area,
+                                                         int* __restrict__ bbox, int H, int W) {
+    __shared__ int s_area, s_y0, s_y1, s_x0, s_x1;
+    const long m = blockIdx.x;
+    const int wpr = W >> 5;
+    const uint32_t* src = packed + m * (long)H * wpr;
+    if (threadIdx.x == 0) { s_area = 0; s_y0 = 1 << 30; s_x0 = 1 << 30; s_y1 = -1; s_x1 = -1; }
+    __syncthreads();
+    int a = 0, y0 = 1 << 30, y1 = -1, x0 = 1 << 30, x1 = -1;
+    for (int w = threadIdx.x; w < H * wpr; w += blockDim.x) {
+        const uint32_t b = src[w];
+        if (b) {
+            const int y = w / wpr, xb = (w - y * wpr) << 5;
+            a += __popc(b);
+            y0 = min(y0, y); y1 = max(y1, y);
+            x0 = min(x0, xb + __ffs((int)b) - 1);
+            x1 = max(x1, xb + 31 - __clz((int)b));
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_down(a, o, 64);
+        y0 = min(y0, __shfl_down(y0, o, 64)); x0 = min(x0, __shfl_down(x0, o, 64));
+        y1 = max(y1, __shfl_down(y1, o, 64)); x1 = max(x1, __shfl_down(x1, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&s_area, a);
+        atomicMin(&s_y0, y0); atomicMin(&s_x0, x0);
+        atomicMax(&s_y1, y1); atomicMax(&s_x1, x1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        area[m] = s_area;
+        const bool e = s_area == 0;
+        bbox[m * 4 + 0] = e ? -1 : s_y0; bbox[m * 4 + 1] = e ? -1 : s_x0;
+        bbox[m * 4 + 2] = e ? -1 : s_y1; bbox[m * 4 + 3] = e ? -1 : s_x1;
+    }
+}
+
+}  // namespace
+
+extern "C" int demia_paste_masks(const demia_paste_desc* d, void* stream) {
+    DEMIA_REQUIRE(d && d->mask_prob && d->det_boxes && d->det_classes && d->det_count && d->out_boxes && d->valid &&
+                      d->packed, "null pointer");
+    DEMIA_REQUIRE(d->out_w % 32 == 0 && d->out_w > 0 && d->out_h > 0, "out_w must be a multiple of 32");
+    DEMIA_REQUIRE(d->N * d->D <= 65535, "N*D <= 65535");
+    PasteP p;
+    p.mask_prob = d->mask_prob; p.ld = d->ld; p.det_boxes = d->det_boxes; p.det_classes = d->det_classes;
+    p.det_count = d->det_count; p.N = d->N; p.D = d->D; p.img_h = d->img_h; p.img_w = d->img_w;
+    p.out_h = d->out_h; p.out_w = d->out_w; p.out_boxes = d->out_boxes; p.valid = d->valid; p.packed = d->packed;
+    if (d->N * d->D == 0) return DEMIA_OK;
+    hipLaunchKernelGGL(paste_kernel, dim3(cdiv(d->out_h, PASTE_ROWS), d->N * d->D), dim3(256), 0, (hipStream_t)stream, p);
+    DEMIA_CHECK_LAUNCH("paste_kernel");
+    return DEMIA_OK;
+}
+
+extern "C" int demia_unpack_masks(const uint32_t* packed, uint8_t* out_bool, int64_t M, int H, int W, void* stream) {
+    DEMIA_REQUIRE(packed && out_bool && W % 32 == 0, "args");
+    const long nwords = (long)M * H * (W / 32);
+    if (nwords == 0) return DEMIA_OK;
+    long g = (nwords + 255) / 256;
+    if (g > 32768) g = 32768;
+    hipLaunchKernelGGL(unpack_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, packed, out_bool, nwords);
+    DEMIA_CHECK_LAUNCH("unpack_kernel");
+    return DEMIA_OK;
+}
+
+extern "C" int demia_mask_area_bbox(const uint32_t* packed, int32_t* area, int32_t* bbox, int64_t M, int H, int W,
+                                    void* stream) {
+    DEMIA_REQUIRE(packed && area && bbox && W % 32 == 0, "args");
+    if (M == 0) return DEMIA_OK;
+    hipLaunchKernelGGL(area_bbox_kernel, dim3((int)M), dim3(1024), 0, (hipStream_t)stream, packed, area, bbox, H, W);
+    DEMIA_CHECK_LAUNCH("area_bbox_kernel");
+    return DEMIA_OK;
+}

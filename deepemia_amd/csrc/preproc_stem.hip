@@ -1,0 +1,293 @@
+// Input side of the network: Pillow-exact resize, normalise+pad, 7x7 stem conv, max pools.
+// All HBM-bound or tiny; written for coalesced NHWC access, no MFMA reshaping.
+//
+// Replaces (Detectron2 0.6, reached from reference src/functions/inference.py:1395):
+//   DefaultPredictor.__call__: ResizeShortestEdge -> PIL Image.resize(BILINEAR)
+//   GeneralizedRCNN.preprocess_image: (x - pixel_mean) / 1, ImageList pad to /32
+//   BasicStem: conv7x7 s2 p3 + FrozenBN + ReLU + max_pool2d(3, 2, 1)
+//   LastLevelMaxPool: max_pool2d(kernel 1, stride 2)
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ int clip8(int v) {
+    v >>= 22;  // PRECISION_BITS = 32 - 8 - 2
+    return v < 0 ? 0 : (v > 255 ? 255 : v);
+}
+
+// horizontal pass: one thread per output pixel (3 channels)
+__global__ void resize_h_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ tmp, long total, int W, int newW,
+                                const int* __restrict__ xmin, const int* __restrict__ xsize,
+                                const int* __restrict__ xk, int ks) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int xx = (int)(i % newW);
+        const long row = i / newW;  // n*H + y
+        const uint8_t* s = src + (row * W + xmin[xx]) * 3;
+        const int n = xsize[xx];
+        const int* k = xk + (long)xx * ks;
+        int a0 = 1 << 21, a1 = 1 << 21, a2 = 1 << 21;
+        for (int x = 0; x < n; ++x) {
+            const int kv = k[x];
+            a0 += (int)s[x * 3 + 0] * kv;
+            a1 += (int)s[x * 3 + 1] * kv;
+            a2 += (int)s[x * 3 + 2] * kv;
+        }
+        uint8_t* d = tmp + i * 3;
+        d[0] = (uint8_t)clip8(a0);
+        d[1] = (uint8_t)clip8(a1);
+        d[2] = (uint8_t)clip8(a2);
+    }
+}
+
+// vertical pass + (x - mean) + write into the zero-bordered, 4-channel f32 stem input
+__global__ void resize_v_norm_kernel(const uint8_t* __restrict__ tmp, float* __restrict__ dst, long total, int H, int newW,
+                                     int newH, int PH, int PW, const int* __restrict__ ymin,
+                                     const int* __restrict__ ysize, const int* __restrict__ yk, int ks,
+                                     float m0, float m1, float m2) {
+    const int DW = PW + 8, DH = PH + 6;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int xx = (int)(i % newW);
+        const long t = i / newW;
+        const int yy = (int)(t % newH);
+        const long n = t / newH;
+        const uint8_t* s = tmp + ((n * H + ymin[yy]) * (long)newW + xx) * 3;
+        const int cnt = ysize[yy];
+        const int* k = yk + (long)yy * ks;
+        int a0 = 1 << 21, a1 = 1 << 21, a2 = 1 << 21;
+        const long rs = (long)newW * 3;
+        for (int y = 0; y < cnt; ++y) {
+            const int kv = k[y];
+            a0 += (int)s[y * rs + 0] * kv;
+            a1 += (int)s[y * rs + 1] * kv;
+            a2 += (int)s[y * rs + 2] * kv;
+        }
+        float4 o;
+        o.x = (float)clip8(a0) - m0;
+        o.y = (float)clip8(a1) - m1;
+        o.z = (float)clip8(a2) - m2;
+        o.w = 0.f;
+        *reinterpret_cast<float4*>(dst + ((n * DH + yy + 3) * (long)DW + xx + 3) * 4) = o;
+    }
+}
+
+// ---- stem: 7x7 s2 p3, 3(4) -> 64, + FrozenBN + ReLU ----------------------------------
+// block = 256 threads = 16x16 output pixels; thread = 4 adjacent pixels x 16 channels.
+// LDS: input patch 37 x 40 x 4 f32 and the whole 7x7x4x64 f32 filter bank.
+constexpr int ST_TW = 16, ST_TH = 16;
+constexpr int ST_IH = ST_TH * 2 + 5, ST_IW = 40;  // 37 rows, 37 cols padded to 40
+template <typename TO>
+__global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                       const float* __restrict__ scale, const float* __restrict__ bias,
+                                                       TO* __restrict__ out, int PH, int PW) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* sIn = reinterpret_cast<float4*>(smem);                           // [37][40] float4
+    float4* sW = reinterpret_cast<float4*>(smem + ST_IH * ST_IW * 16);       // [7*7*4][16] float4 (64 co)
+    const int Ho = PH / 2, Wo = PW / 2;
+    const int DW = PW + 8, DH = PH + 6;
+    const int n = blockIdx.z;
+    const int ho0 = blockIdx.y * ST_TH, wo0 = blockIdx.x * ST_TW;
+    const int tid = threadIdx.x;
+    // weights: [kh][kw(8)][c(4)][64] in global -> we only stage kw < 7
+    for (int i = tid; i < 7 * 7 * 4 * 16; i += 256) {
+        const int co4 = i & 15;
+        const int c = (i >> 4) & 3;
+        const int kw = (i >> 6) % 7;
+        const int kh = (i >> 6) / 7;
+        sW[i] = *reinterpret_cast<const float4*>(w + (((kh * 8 + kw) * 4 + c) * 64) + co4 * 4);
+    }
+    // input patch: rows 2*ho0 .. 2*ho0+36 (buffer coords: +3 border already included), cols 2*wo0 .. +36
+    const float4* in4 = reinterpret_cast<const float4*>(in) + (long)n * DH * DW;
+    for (int i = tid; i < ST_IH * ST_IW; i += 256) {
+        const int r = i / ST_IW, c = i - r * ST_IW;
+        const int gy = 2 * ho0 + r, gx = 2 * wo0 + c;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gy < DH && gx < DW) v = in4[(long)gy * DW + gx];
+        sIn[i] = v;
+    }
+    __syncthreads();
+    const int cg = tid & 3;
+    const int q = tid >> 2;
+    const int row = q >> 2;
+    const int col0 = (q & 3) * 4;
+    float acc[4][16];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int c = 0; c < 16; ++c) acc[p][c] = 0.f;
+    for (int kh = 0; kh < 7; ++kh) {
+        const float4* irow = sIn + (2 * row + kh) * ST_IW + 2 * col0;
+#pragma unroll
+        for (int kw = 0; kw < 7; ++kw) {
+            float4 x[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) x[p] = irow[2 * p + kw];
+            const float4* wp = sW + ((kh * 7 + kw) * 4) * 16 + cg * 4;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float wv[16];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 t = wp[c * 16 + j];
+                    wv[4 * j + 0] = t.x; wv[4 * j + 1] = t.y; wv[4 * j + 2] = t.z; wv[4 * j + 3] = t.w;
+                }
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const float xv = c == 0 ? x[p].x : (c == 1 ? x[p].y : x[p].z);
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) acc[p][j] = fmaf(xv, wv[j], acc[p][j]);
+                }
+            }
+        }
+    }
+    const int ho = ho0 + row;
+    if (ho >= Ho) return;
+    float sc[16], bs[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        sc[j] = scale[cg * 16 + j];
+        bs[j] = bias[cg * 16 + j];
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int wo = wo0 + col0 + p;
+        if (wo >= Wo) continue;
+        TO* o = out + (((long)n * Ho + ho) * Wo + wo) * 64 + cg * 16;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            float v = acc[p][j] * sc[j] + bs[j];
+            o[j] = from_f32<TO>(v > 0.f ? v : 0.f);
+        }
+    }
+}
+
+// maxpool 3x3 s2 p1 (padding never wins: implicit -inf), NHWC, 4 channels per thread
+template <typename T>
+__global__ void maxpool3x3s2_kernel(const T* __restrict__ in, T* __restrict__ out, long total, int H, int W, int C,
+                                    int Ho, int Wo) {
+    const int C4 = C / 4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        long t = i / C4;
+        const int wo = (int)(t % Wo);
+        t /= Wo;
+        const int ho = (int)(t % Ho);
+        const long n = t / Ho;
+        float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int y = 2 * ho - 1 + dy;
+            if ((unsigned)y >= (unsigned)H) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int x = 2 * wo - 1 + dx;
+                if ((unsigned)x >= (unsigned)W) continue;
+                const T* p = in + ((n * H + y) * (long)W + x) * C + c4 * 4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) m[q] = fmaxf(m[q], to_f32<T>(p[q]));
+            }
+        }
+        T* o = out + ((n * Ho + ho) * (long)Wo + wo) * C + c4 * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = from_f32<T>(m[q]);
+    }
+}
+
+template <typename T>
+__global__ void subsample2_kernel(const T* __restrict__ in, T* __restrict__ out, long total, int H, int W, int C, int Ho,
+                                  int Wo) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long t = i / C;
+        const int wo = (int)(t % Wo);
+        t /= Wo;
+        const int ho = (int)(t % Ho);
+        const long n = t / Ho;
+        out[i] = in[((n * H + 2 * ho) * (long)W + 2 * wo) * C + c];
+    }
+}
+
+inline int grid_for(long total, int block) {
+    long g = (total + block - 1) / block;
+    return (int)(g > 16384 ? 16384 : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+extern "C" int demia_resize_h_u8(const uint8_t* src, uint8_t* tmp, int N, int H, int W, int newW, const int32_t* xmin,
+                                 const int32_t* xsize, const int32_t* xk, int ksx, void* stream) {
+    DEMIA_REQUIRE(src && tmp && xmin && xsize && xk && ksx > 0, "args");
+    const long total = (long)N * H * newW;
+    if (total == 0) return DEMIA_OK;
+    hipLaunchKernelGGL(resize_h_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, src, tmp, total, W,
+                       newW, xmin, xsize, xk, ksx);
+    DEMIA_CHECK_LAUNCH("resize_h_kernel");
+    return DEMIA_OK;
+}
+
+extern "C" int demia_resize_v_norm(const uint8_t* tmp, void* dst, int N, int H, int newW, int newH, int PH, int PW,
+                                   const int32_t* ymin, const int32_t* ysize, const int32_t* yk, int ksy,
+                                   const float* mean3, int dtype, void* stream) {
+    DEMIA_REQUIRE(tmp && dst && ymin && ysize && yk && mean3 && ksy > 0, "args");
+    DEMIA_REQUIRE(dtype == DEMIA_F32, "stem input is always f32");
+    DEMIA_REQUIRE(PH >= newH && PW >= newW && PH % 32 == 0 && PW % 32 == 0, "padded size");
+    const long total = (long)N * newH * newW;
+    if (total == 0) return DEMIA_OK;
+    hipLaunchKernelGGL(resize_v_norm_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, tmp,
+                       (float*)dst, total, H, newW, newH, PH, PW, ymin, ysize, yk, ksy, mean3[0], mean3[1], mean3[2]);
+    DEMIA_CHECK_LAUNCH("resize_v_norm_kernel");
+    return DEMIA_OK;
+}
+
+extern "C" int demia_stem_conv(const void* in, const void* w, const float* scale, const float* bias, void* mid, int N,
+                               int PH, int PW, int dtype, void* stream) {
+    DEMIA_REQUIRE(in && w && scale && bias && mid, "args");
+    DEMIA_REQUIRE(PH % 32 == 0 && PW % 32 == 0, "padded size");
+    const int Ho = PH / 2, Wo = PW / 2;
+    const int smem = ST_IH * ST_IW * 16 + 7 * 7 * 4 * 64 * 4;
+    dim3 grid(cdiv(Wo, ST_TW), cdiv(Ho, ST_TH), N);
+    if (dtype == DEMIA_BF16) {
+        auto k = stem_conv_kernel<bf16_t>;
+        static bool done = false;
+        if (!done) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem); done = true; }
+        hipLaunchKernelGGL(k, grid, dim3(256), smem, (hipStream_t)stream, (const float*)in, (const float*)w, scale, bias,
+                           (bf16_t*)mid, PH, PW);
+    } else {
+        auto k = stem_conv_kernel<float>;
+        static bool done = false;
+        if (!done) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem); done = true; }
+        hipLaunchKernelGGL(k, grid, dim3(256), smem, (hipStream_t)stream, (const float*)in, (const float*)w, scale, bias,
+                           (float*)mid, PH, PW);
+    }
+    DEMIA_CHECK_LAUNCH("stem_conv_kernel");
+    return DEMIA_OK;
+}
+
+extern "C" int demia_maxpool3x3s2(const void* in, void* out, int N, int H, int W, int C, int dtype, void* stream) {
+    DEMIA_REQUIRE(in && out && C % 4 == 0, "args");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const long total = (long)N * Ho * Wo * (C / 4);
+    if (total == 0) return DEMIA_OK;
+    if (dtype == DEMIA_BF16)
+        hipLaunchKernelGGL(maxpool3x3s2_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)in, (bf16_t*)out, total, H, W, C, Ho, Wo);
+    else
+        hipLaunchKernelGGL(maxpool3x3s2_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)in, (float*)out, total, H, W, C, Ho, Wo);
+    DEMIA_CHECK_LAUNCH("maxpool3x3s2_kernel");
+    return DEMIA_OK;
+}
+
+extern "C" int demia_subsample2(const void* in, void* out, int N, int H, int W, int C, int dtype, void* stream) {
+    DEMIA_REQUIRE(in && out, "args");
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long total = (long)N * Ho * Wo * C;
+    if (total == 0) return DEMIA_OK;
+    if (dtype == DEMIA_BF16)
+        hipLaunchKernelGGL(subsample2_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)in, (bf16_t*)out, total, H, W, C, Ho, Wo);
+    else
+        hipLaunchKernelGGL(subsample2_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)in, (float*)out, total, H, W, C, Ho, Wo);
+    DEMIA_CHECK_LAUNCH("subsample2_kernel");
+    return DEMIA_OK;
+}

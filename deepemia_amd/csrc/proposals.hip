@@ -1,0 +1,470 @@
+// RPN proposal selection and Fast R-CNN detection selection: order/compare work
+// (radix select, bitonic sort, bit-matrix hard NMS) kept entirely on the GPU so that no
+// score table ever crosses PCIe.  Compiled with -ffp-contract=off: box arithmetic follows
+// the reference's separate fp32 mul / add ops.
+//
+// Replaces (Detectron2 0.6 under reference src/functions/inference.py:1395 predictor(image)):
+//   RPN.predict_proposals + find_top_rpn_proposals (+ torchvision batched_nms / nms)
+//   FastRCNNOutputLayers.inference + fast_rcnn_inference_single_image
+// Tie order (unspecified upstream) is fixed to "stable, lower index first" -- the same
+// choice the CPU oracle makes.
+#include "common.h"
+
+namespace {
+
+constexpr int RPN_MAXK = 1024;   // >= pre_topk / post_topk
+constexpr int NW = RPN_MAXK / 64;  // 64-bit words per suppression row
+constexpr float SCALE_CLAMP = 4.135166556742356f;  // log(1000 / 16)
+
+__device__ __forceinline__ unsigned f2key(float f) {  // monotone: bigger float -> bigger key
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(unsigned k) {
+    unsigned u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+    return __uint_as_float(u);
+}
+
+// in-LDS bitonic sort, DESCENDING, of n (power of two) 64-bit keys by all threads of the block
+__device__ void bitonic_desc(unsigned long long* a, int n) {
+    for (int k = 2; k <= n; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < n; i += blockDim.x) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long x = a[i], y = a[ixj];
+                    const bool up = (i & k) == 0;  // descending block
+                    if (up ? (x < y) : (x > y)) { a[i] = y; a[ixj] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__device__ __forceinline__ bool iou_gt(const float4 a, const float4 b, float thr) {
+    // torchvision nms_kernel: area = (x2-x1)*(y2-y1); suppress when inter / (a + b - inter) > thr
+    const float aa = (a.z - a.x) * (a.w - a.y);
+    const float ab = (b.z - b.x) * (b.w - b.y);
+    const float xx1 = fmaxf(a.x, b.x), yy1 = fmaxf(a.y, b.y);
+    const float xx2 = fminf(a.z, b.z), yy2 = fminf(a.w, b.w);
+    const float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
+    const float inter = w * h;
+    const float ovr = inter / (aa + ab - inter);
+    return ovr > thr;
+}
+
+// Greedy resolution of a sorted candidate list given a strictly-upper-triangular suppression
+// bit matrix `mat` (row i: candidates j > i that i would suppress) held in LDS.  Executed by
+// wave 0 only.  `removed` enters holding the pre-removed (invalid) candidates; on exit bit i is
+// set iff candidate i is NOT kept.  Works 64 candidates at a time: the diagonal 64x64 block is
+// resolved with scalar-ish readlane steps, then the rows of the survivors are OR-ed into the
+// later words (independent LDS reads, no serial dependency).
+__device__ void greedy_resolve(const unsigned long long* mat, unsigned long long* removed_words, int n) {
+    const int lane = threadIdx.x & 63;
+    const int nwords = (n + 63) >> 6;
+    for (int wb = 0; wb < nwords; ++wb) {
+        unsigned long long rem = removed_words[wb];  // uniform
+        const int i = wb * 64 + lane;
+        const unsigned long long diag = (i < n) ? mat[(long)i * NW + wb] : 0ull;
+        for (int b = 0; b < 64; ++b) {
+            const unsigned long long row = __shfl(diag, b, 64);
+            if (!((rem >> b) & 1ull)) rem |= row;
+        }
+        if (lane == 0) removed_words[wb] = rem;
+        // OR the kept rows into the later words: lane w owns word w (w < NW)
+        unsigned long long acc = 0ull;
+        unsigned long long kept = ~rem;
+        if (wb == nwords - 1 && (n & 63)) kept &= (1ull << (n & 63)) - 1ull;
+        while (kept) {
+            const int b = __ffsll((long long)kept) - 1;
+            kept &= kept - 1ull;
+            if (lane < NW && lane > wb) acc |= mat[(long)(wb * 64 + b) * NW + lane];
+        }
+        if (lane < NW && lane > wb) removed_words[lane] |= acc;
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+struct RpnP {
+    const float* head[5];
+    int H[5], W[5], stride[5];
+    float cell[5][3][4];
+    int head_ld, N, img_h, img_w, pre_topk, post_topk;
+    float nms_thresh;
+    float* out_boxes;
+    float* out_scores;
+    int* out_count;
+    // workspace
+    float* lvl_boxes;   // [N][5][1024][4]
+    float* lvl_scores;  // [N][5][1024]
+    int* lvl_kept;      // [N][5][1024]  1 = survived per-level NMS
+};
+
+// grid (5, N), block 1024.  LDS: suppression matrix 128 KiB + sort keys 8 KiB + boxes 16 KiB + misc
+__global__ __launch_bounds__(1024) void rpn_level_kernel(const RpnP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long* mat = reinterpret_cast<unsigned long long*>(smem);            // [1024][16]
+    unsigned long long* keys = mat + RPN_MAXK * NW;                                   // [1024]
+    float4* boxes = reinterpret_cast<float4*>(keys + RPN_MAXK);                       // [1024]
+    unsigned long long* removed = reinterpret_cast<unsigned long long*>(boxes + RPN_MAXK);  // [16]
+    unsigned* hist = reinterpret_cast<unsigned*>(removed + NW);                      // [256]
+    int* sh = reinterpret_cast<int*>(hist + 256);                                     // scratch [40]
+
+    const int lvl = blockIdx.x, n = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int H = p.H[lvl], W = p.W[lvl];
+    const int total = H * W * 3;
+    const int k = total < p.pre_topk ? total : p.pre_topk;
+    const float* head = p.head[lvl] + (long)n * H * W * p.head_ld;
+    auto logit = [&](int i) -> float { return head[(long)(i / 3) * p.head_ld + (i % 3)]; };
+
+    // ---- radix select: threshold key T = k-th largest -------------------------------------
+    unsigned prefix = 0, pmask = 0;
+    int need = k;  // how many still to take among keys matching the prefix
+    for (int pass = 3; pass >= 0; --pass) {
+        for (int i = tid; i < 256; i += blockDim.x) hist[i] = 0;
+        __syncthreads();
+        const int shift = pass * 8;
+        for (int i = tid; i < total; i += blockDim.x) {
+            const unsigned key = f2key(logit(i));
+            if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int acc = 0, d = 255;
+            for (; d > 0; --d) {
+                if (acc + (int)hist[d] >= need) break;
+                acc += hist[d];
+            }
+            sh[0] = d;
+            sh[1] = need - acc;
+        }
+        __syncthreads();
+        prefix |= ((unsigned)sh[0]) << shift;
+        pmask |= 255u << shift;
+        need = sh[1];
+        __syncthreads();
+    }
+    const unsigned T = prefix;  // exactly `need` elements equal to T are taken, lowest index first
+
+    // ---- ordered compaction ------------------------------------------------------------------
+    if (tid == 0) { sh[2] = 0; sh[3] = 0; }  // running counts: selected, equal-taken
+    for (int i = tid; i < RPN_MAXK; i += blockDim.x) keys[i] = 0ull;
+    __syncthreads();
+    for (int base = 0; base < total; base += blockDim.x) {
+        const int i = base + tid;
+        unsigned key = 0;
+        bool gt = false, eq = false;
+        if (i < total) {
+            key = f2key(logit(i));
+            gt = key > T;
+            eq = key == T;
+        }
+        const unsigned long long bg = __ballot(gt), be = __ballot(eq);
+        if (lane == 0) { sh[8 + wave] = __popcll(bg); sh[24 + wave] = __popcll(be); }
+        __syncthreads();
+        int off_g = 0, off_e = 0;
+        for (int w = 0; w < wave; ++w) { off_g += sh[8 + w]; off_e += sh[24 + w]; }
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        const int my_g = off_g + __popcll(bg & lt);
+        const int my_e = off_e + __popcll(be & lt);
+        const int base_sel = sh[2], base_eq = sh[3];
+        int tot_g = 0, tot_e = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { tot_g += sh[8 + w]; tot_e += sh[24 + w]; }
+        const int eq_room = need - base_eq;               // equal keys still allowed
+        const int eq_take = tot_e < eq_room ? tot_e : (eq_room > 0 ? eq_room : 0);
+        // slot layout inside this chunk: all gt first (index order), then the taken eq (index order)
+        if (gt) keys[base_sel + my_g] = ((unsigned long long)key << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
+        if (eq && my_e < eq_take)
+            keys[base_sel + tot_g + my_e] = ((unsigned long long)key << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
+        __syncthreads();
+        if (tid == 0) { sh[2] = base_sel + tot_g + eq_take; sh[3] = base_eq + eq_take; }
+        __syncthreads();
+    }
+    bitonic_desc(keys, RPN_MAXK);
+
+    // ---- decode + clip + validity ----------------------------------------------------------------
+    for (int i = tid; i < NW; i += blockDim.x) removed[i] = 0ull;
+    __syncthreads();
+    float my_score = 0.f;
+    bool valid = false;
+    float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < k) {
+        const unsigned long long kk = keys[tid];
+        const int idx = (int)(0xFFFFFFFFu - (unsigned)(kk & 0xFFFFFFFFull));
+        my_score = key2f((unsigned)(kk >> 32));
+        const int a = idx % 3, loc = idx / 3;
+        const int hh = loc / W, ww = loc - hh * W;
+        const float sx = (float)(ww * p.stride[lvl]), sy = (float)(hh * p.stride[lvl]);
+        const float ax1 = sx + p.cell[lvl][a][0], ay1 = sy + p.cell[lvl][a][1];
+        const float ax2 = sx + p.cell[lvl][a][2], ay2 = sy + p.cell[lvl][a][3];
+        const float* d = head + (long)loc * p.head_ld + 3 + a * 4;
+        const float widths = ax2 - ax1, heights = ay2 - ay1;
+        const float cx = ax1 + 0.5f * widths, cy = ay1 + 0.5f * heights;
+        const float dx = d[0], dy = d[1];
+        const float dw = fminf(d[2], SCALE_CLAMP), dh = fminf(d[3], SCALE_CLAMP);
+        const float pcx = dx * widths + cx, pcy = dy * heights + cy;
+        const float pw = expf(dw) * widths, ph = expf(dh) * heights;
+        float x1 = pcx - 0.5f * pw, y1 = pcy - 0.5f * ph, x2 = pcx + 0.5f * pw, y2 = pcy + 0.5f * ph;
+        const bool fin = isfinite(x1) && isfinite(y1) && isfinite(x2) && isfinite(y2) && isfinite(my_score);
+        const float iw = (float)p.img_w, ih = (float)p.img_h;
+        x1 = fminf(fmaxf(x1, 0.f), iw); x2 = fminf(fmaxf(x2, 0.f), iw);
+        y1 = fminf(fmaxf(y1, 0.f), ih); y2 = fminf(fmaxf(y2, 0.f), ih);
+        valid = fin && (x2 - x1) > 0.f && (y2 - y1) > 0.f;
+        bx = make_float4(x1, y1, x2, y2);
+    }
+    boxes[tid] = bx;
+    {
+        const unsigned long long inv = __ballot(!valid);
+        if (lane == 0) removed[wave] = inv;
+    }
+    __syncthreads();
+    // ---- suppression matrix: thread = row -------------------------------------------------------
+    {
+        const int i = tid;
+        for (int w = 0; w < NW; ++w) {
+            unsigned long long bits = 0ull;
+            if (i < k && valid && (w * 64 + 63) > i) {
+                const int j0 = w * 64;
+                for (int b = 0; b < 64; ++b) {
+                    const int j = j0 + b;
+                    if (j > i && j < k && iou_gt(bx, boxes[j], p.nms_thresh)) bits |= 1ull << b;
+                }
+            }
+            mat[(long)i * NW + w] = bits;
+        }
+    }
+    __syncthreads();
+    if (wave == 0) greedy_resolve(mat, removed, k);
+    __syncthreads();
+    // ---- publish level results ----------------------------------------------------------------------
+    {
+        const long o = ((long)n * 5 + lvl) * RPN_MAXK + tid;
+        const bool kept = tid < k && !((removed[tid >> 6] >> (tid & 63)) & 1ull);
+        reinterpret_cast<float4*>(p.lvl_boxes)[o] = bx;
+        p.lvl_scores[o] = my_score;
+        p.lvl_kept[o] = kept ? 1 : 0;
+    }
+}
+
+// grid N, block 1024: stable descending merge of the per-level survivors, keep post_topk
+__global__ __launch_bounds__(1024) void rpn_merge_kernel(const RpnP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);  // [8192]
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const long base = (long)n * 5 * RPN_MAXK;
+    for (int i = tid; i < 8192; i += blockDim.x) {
+        unsigned long long key = 0ull;
+        if (i < 5 * RPN_MAXK && p.lvl_kept[base + i])
+            key = ((unsigned long long)f2key(p.lvl_scores[base + i]) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
+        keys[i] = key;
+    }
+    __syncthreads();
+    bitonic_desc(keys, 8192);
+    __shared__ int cnt;
+    if (tid == 0) cnt = 0;
+    __syncthreads();
+    for (int i = tid; i < p.post_topk; i += blockDim.x) {
+        const unsigned long long kk = keys[i];
+        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+        float s = 0.f;
+        if (kk != 0ull) {
+            const int src = (int)(0xFFFFFFFFu - (unsigned)(kk & 0xFFFFFFFFull));
+            b = reinterpret_cast<const float4*>(p.lvl_boxes)[base + src];
+            s = p.lvl_scores[base + src];
+            atomicAdd(&cnt, 1);
+        }
+        reinterpret_cast<float4*>(p.out_boxes)[(long)n * p.post_topk + i] = b;
+        p.out_scores[(long)n * p.post_topk + i] = s;
+    }
+    __syncthreads();
+    if (tid == 0) p.out_count[n] = cnt;
+}
+
+// -------------------------------------------------------------------------------------------------
+// Fast R-CNN detections
+// -------------------------------------------------------------------------------------------------
+struct DetP {
+    const float* logits;
+    int ld;
+    const float* props;
+    const int* prop_count;
+    int N, R, K, img_h, img_w;
+    float score_thresh, nms_thresh;
+    int topk;
+    float* det_boxes;
+    float* det_scores;
+    int* det_classes;
+    int* det_count;
+};
+constexpr int DET_MAXC = 4096;
+constexpr int DET_MAXK = 128;
+
+// grid N, block 1024.  LDS: keys 32 KiB + cand boxes 64 KiB + kept list
+__global__ __launch_bounds__(1024) void box_detections_kernel(const DetP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);   // [4096]
+    float4* cbox = reinterpret_cast<float4*>(keys + DET_MAXC);                // [4096] by candidate id
+    float4* kbox = cbox + DET_MAXC;                                           // [128] kept boxes
+    int* kcls = reinterpret_cast<int*>(kbox + DET_MAXK);                      // [128]
+    float* kscore = reinterpret_cast<float*>(kcls + DET_MAXK);                // [128]
+    __shared__ int nkept;
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int K = p.K;
+    const int R = p.prop_count[n] < p.R ? p.prop_count[n] : p.R;
+    const float iw = (float)p.img_w, ih = (float)p.img_h;
+    for (int i = tid; i < DET_MAXC; i += blockDim.x) keys[i] = 0ull;
+    if (tid == 0) nkept = 0;
+    __syncthreads();
+    for (int r = tid; r < R; r += blockDim.x) {
+        const float* lg = p.logits + ((long)n * p.R + r) * p.ld;
+        float mx = lg[0];
+        for (int c = 1; c <= K; ++c) mx = fmaxf(mx, lg[c]);
+        float sum = 0.f;
+        for (int c = 0; c <= K; ++c) sum += expf(lg[c] - mx);
+        const float4 pb = reinterpret_cast<const float4*>(p.props)[(long)n * p.R + r];
+        const float widths = pb.z - pb.x, heights = pb.w - pb.y;
+        const float cx = pb.x + 0.5f * widths, cy = pb.y + 0.5f * heights;
+        bool row_fin = true;
+        for (int c = 0; c <= K; ++c) row_fin = row_fin && isfinite(expf(lg[c] - mx) / sum);
+        float4 bb[8];
+        for (int c = 0; c < K && c < 8; ++c) {
+            const float* d = lg + K + 1 + 4 * c;
+            const float dx = d[0] / 10.0f, dy = d[1] / 10.0f;
+            const float dw = fminf(d[2] / 5.0f, SCALE_CLAMP), dh = fminf(d[3] / 5.0f, SCALE_CLAMP);
+            const float pcx = dx * widths + cx, pcy = dy * heights + cy;
+            const float pw = expf(dw) * widths, ph = expf(dh) * heights;
+            const float x1 = pcx - 0.5f * pw, y1 = pcy - 0.5f * ph, x2 = pcx + 0.5f * pw, y2 = pcy + 0.5f * ph;
+            row_fin = row_fin && isfinite(x1) && isfinite(y1) && isfinite(x2) && isfinite(y2);
+            bb[c] = make_float4(fminf(fmaxf(x1, 0.f), iw), fminf(fmaxf(y1, 0.f), ih), fminf(fmaxf(x2, 0.f), iw),
+                                fminf(fmaxf(y2, 0.f), ih));
+        }
+        for (int c = 0; c < K && c < 8; ++c) {
+            const float sc = expf(lg[c] - mx) / sum;
+            const int cand = r * K + c;
+            cbox[cand] = bb[c];
+            if (row_fin && sc > p.score_thresh)
+                keys[cand] = ((unsigned long long)f2key(sc) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)cand);
+        }
+    }
+    __syncthreads();
+    bitonic_desc(keys, DET_MAXC);
+    // ---- greedy per-class NMS with early stop at topk, wave 0 ---------------------------------------
+    if (tid < 64) {
+        int kept_n = 0;
+        for (int base = 0; base < DET_MAXC && kept_n < p.topk; base += 64) {
+            const unsigned long long kk = keys[base + lane];
+            const bool live = kk != 0ull;
+            if (!__any(live)) break;
+            const int cand = live ? (int)(0xFFFFFFFFu - (unsigned)(kk & 0xFFFFFFFFull)) : 0;
+            const int cls = cand % K;
+            const float4 b = cbox[cand];
+            bool sup = !live;
+            for (int j = 0; j < kept_n && !sup; ++j)
+                if (kcls[j] == cls && iou_gt(kbox[j], b, p.nms_thresh)) sup = true;
+            // intra-chunk rows
+            unsigned long long row = 0ull;
+            for (int j = 0; j < 64; ++j) {
+                const float4 bj = make_float4(__shfl(b.x, j, 64), __shfl(b.y, j, 64), __shfl(b.z, j, 64), __shfl(b.w, j, 64));
+                const int cj = __shfl(cls, j, 64);
+                const bool lj = __shfl((int)live, j, 64) != 0;
+                if (j > lane && live && lj && cj == cls && iou_gt(b, bj, p.nms_thresh)) row |= 1ull << j;
+            }
+            unsigned long long rem = __ballot(sup);
+            for (int bbit = 0; bbit < 64; ++bbit) {
+                const unsigned long long rr = __shfl(row, bbit, 64);
+                if (!((rem >> bbit) & 1ull)) rem |= rr;
+            }
+            const unsigned long long keptm = ~rem;
+            const bool me = (keptm >> lane) & 1ull;
+            const int pos = kept_n + __popcll(keptm & ((1ull << lane) - 1ull));
+            if (me && pos < p.topk) {
+                kbox[pos] = b;
+                kcls[pos] = cls;
+                kscore[pos] = key2f((unsigned)(kk >> 32));
+            }
+            kept_n += __popcll(keptm);
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (lane == 0) nkept = kept_n < p.topk ? kept_n : p.topk;
+    }
+    __syncthreads();
+    for (int i = tid; i < p.topk; i += blockDim.x) {
+        const bool ok = i < nkept;
+        reinterpret_cast<float4*>(p.det_boxes)[(long)n * p.topk + i] = ok ? kbox[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        p.det_scores[(long)n * p.topk + i] = ok ? kscore[i] : 0.f;
+        p.det_classes[(long)n * p.topk + i] = ok ? kcls[i] : 0;
+    }
+    if (tid == 0) p.det_count[n] = nkept;
+}
+
+}  // namespace
+
+extern "C" int64_t demia_rpn_workspace_bytes(int N) {
+    return (int64_t)N * 5 * RPN_MAXK * (16 + 4 + 4);
+}
+
+extern "C" int demia_rpn_proposals(const demia_rpn_desc* d, void* stream) {
+    DEMIA_REQUIRE(d && d->out_boxes && d->out_scores && d->out_count && d->workspace, "null pointer");
+    DEMIA_REQUIRE(d->pre_topk > 0 && d->pre_topk <= 1000 && d->post_topk > 0 && d->post_topk <= RPN_MAXK, "topk");
+    DEMIA_REQUIRE(d->head_ld >= 15, "head_ld");
+    RpnP p;
+    for (int l = 0; l < 5; ++l) {
+        DEMIA_REQUIRE(d->head[l], "head level pointer");
+        p.head[l] = d->head[l];
+        p.H[l] = d->H[l];
+        p.W[l] = d->W[l];
+        p.stride[l] = d->stride[l];
+        for (int a = 0; a < 3; ++a)
+            for (int c = 0; c < 4; ++c) p.cell[l][a][c] = d->cell_anchors[(l * 3 + a) * 4 + c];
+    }
+    p.head_ld = d->head_ld; p.N = d->N; p.img_h = d->img_h; p.img_w = d->img_w;
+    p.pre_topk = d->pre_topk; p.post_topk = d->post_topk; p.nms_thresh = d->nms_thresh;
+    p.out_boxes = d->out_boxes; p.out_scores = d->out_scores; p.out_count = d->out_count;
+    char* ws = reinterpret_cast<char*>(d->workspace);
+    const long slots = (long)d->N * 5 * RPN_MAXK;
+    p.lvl_boxes = reinterpret_cast<float*>(ws);
+    p.lvl_scores = reinterpret_cast<float*>(ws + slots * 16);
+    p.lvl_kept = reinterpret_cast<int*>(ws + slots * 20);
+    if (d->N == 0) return DEMIA_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int smem1 = RPN_MAXK * NW * 8 + RPN_MAXK * 8 + RPN_MAXK * 16 + NW * 8 + 256 * 4 + 64 * 4;
+    static bool done = false;
+    if (!done) {
+        (void)hipFuncSetAttribute((const void*)rpn_level_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem1);
+        (void)hipFuncSetAttribute((const void*)rpn_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8);
+        done = true;
+    }
+    hipLaunchKernelGGL(rpn_level_kernel, dim3(5, d->N), dim3(1024), smem1, st, p);
+    DEMIA_CHECK_LAUNCH("rpn_level_kernel");
+    hipLaunchKernelGGL(rpn_merge_kernel, dim3(d->N), dim3(1024), 8192 * 8, st, p);
+    DEMIA_CHECK_LAUNCH("rpn_merge_kernel");
+    return DEMIA_OK;
+}
+
+extern "C" int demia_box_detections(const demia_dets_desc* d, void* stream) {
+    DEMIA_REQUIRE(d && d->logits && d->props && d->prop_count && d->det_boxes && d->det_scores && d->det_classes &&
+                      d->det_count, "null pointer");
+    DEMIA_REQUIRE(d->K >= 1 && d->K <= 8, "1 <= K <= 8");
+    DEMIA_REQUIRE((long)d->R * d->K <= DET_MAXC, "R*K <= 4096");
+    DEMIA_REQUIRE(d->topk > 0 && d->topk <= DET_MAXK, "topk <= 128");
+    DEMIA_REQUIRE(d->ld >= 5 * d->K + 1, "ld");
+    DetP p;
+    p.logits = d->logits; p.ld = d->ld; p.props = d->props; p.prop_count = d->prop_count;
+    p.N = d->N; p.R = d->R; p.K = d->K; p.img_h = d->img_h; p.img_w = d->img_w;
+    p.score_thresh = d->score_thresh; p.nms_thresh = d->nms_thresh; p.topk = d->topk;
+    p.det_boxes = d->det_boxes; p.det_scores = d->det_scores; p.det_classes = d->det_classes; p.det_count = d->det_count;
+    if (d->N == 0) return DEMIA_OK;
+    const int smem = DET_MAXC * 8 + DET_MAXC * 16 + DET_MAXK * (16 + 4 + 4);
+    static bool done = false;
+    if (!done) {
+        (void)hipFuncSetAttribute((const void*)box_detections_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        done = true;
+    }
+    hipLaunchKernelGGL(box_detections_kernel, dim3(d->N), dim3(1024), smem, (hipStream_t)stream, p);
+    DEMIA_CHECK_LAUNCH("box_detections_kernel");
+    return DEMIA_OK;
+}

@@ -1,0 +1,430 @@
+"""Host driver of the MI355X Mask R-CNN forward: packs Detectron2 weights into the NHWC /
+K-contiguous layouts the HIP kernels want and sequences the C-ABI calls on one HIP stream.
+
+This is what replaces ``DefaultPredictor.__call__`` -> ``GeneralizedRCNN.inference``
+(Detectron2 0.6) behind the reference's ``predictor(image)`` call
+(``src/functions/inference.py:1395,1398,1507,1669``; built at ``src/data/models.py:107``).
+Semantics follow SURVEY.md Appendix A; every compute step is a HIP kernel from
+``libdeepemia_hip.so`` -- torch is used for device buffers and the stream only.
+
+Layout in HBM (per batch of B equally sized images):
+  activations  NHWC, bf16 (default) or f32 (parity mode), B outermost so B tiles form ONE
+               implicit-GEMM M dimension (B*Ho*Wo pixels) -- this is what fills 256 CUs on
+               the 25^2..200^2 feature maps;
+  weights      [CoutPad, KH, KW, Cin] (K contiguous per output channel), FrozenBN kept as
+               per-channel f32 scale/bias applied in the conv epilogue;
+  masks        bit-packed, 1 bit per pixel ([B, D, H, W/32] u32): 512 KiB per 2048^2 mask.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, BF16, F32, RES_NONE, RES_SAME, RES_UP2
+
+RES_BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}
+PIXEL_MEAN = (103.530, 116.280, 123.675)
+ANCHOR_SIZES = (32, 64, 128, 256, 512)
+ANCHOR_RATIOS = (0.5, 1.0, 2.0)
+STRIDES = (4, 8, 16, 32, 64)
+BN_EPS = 1e-5
+PRE_NMS_TOPK = 1000
+POST_NMS_TOPK = 1000
+RPN_NMS_THRESH = 0.7
+DET_NMS_THRESH = 0.5
+DETS_PER_IMAGE = 100
+
+EXPECTED_IGNORED_PREFIXES = ("proposal_generator.anchor_generator.", "pixel_mean", "pixel_std")
+
+
+def resize_shape(h: int, w: int, short: int = 800, max_size: int = 1333) -> Tuple[int, int]:
+    """``ResizeShortestEdge.get_output_shape`` (Detectron2 0.6)."""
+    scale = short * 1.0 / min(h, w)
+    if h < w:
+        newh, neww = short, scale * w
+    else:
+        newh, neww = scale * h, short
+    if max(newh, neww) > max_size:
+        s = max_size * 1.0 / max(newh, neww)
+        newh, neww = newh * s, neww * s
+    return int(newh + 0.5), int(neww + 0.5)
+
+
+def pil_bilinear_tables(in_size: int, out_size: int):
+    """Pillow ``precompute_coeffs`` + ``normalize_coeffs_8bpc`` for the triangle filter
+    (PRECISION_BITS = 22).  Host-side table; the separable integer passes run on the GPU."""
+    if in_size == out_size:
+        return (np.arange(out_size, dtype=np.int32), np.ones(out_size, dtype=np.int32),
+                np.full((out_size, 1), 1 << 22, dtype=np.int32))
+    scale = filterscale = in_size / out_size
+    if filterscale < 1.0:
+        filterscale = 1.0
+    support = 1.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    xx = np.arange(out_size, dtype=np.float64)
+    center = (xx + 0.5) * scale
+    xmin = np.maximum((center - support + 0.5).astype(np.int64), 0)
+    xmax = np.minimum((center + support + 0.5).astype(np.int64), in_size)
+    xsize = xmax - xmin
+    j = np.arange(ksize, dtype=np.float64)[None, :]
+    arg = (j + xmin[:, None] - center[:, None] + 0.5) * (1.0 / filterscale)
+    wgt = np.where(np.abs(arg) < 1.0, 1.0 - np.abs(arg), 0.0)
+    wgt = np.where(j < xsize[:, None], wgt, 0.0)
+    # Pillow accumulates ww sequentially in double; cumulative sum reproduces that order
+    ww = np.zeros(out_size, dtype=np.float64)
+    for c in range(ksize):
+        ww = ww + wgt[:, c]
+    kk = np.where(ww[:, None] != 0.0, wgt / np.where(ww == 0.0, 1.0, ww)[:, None], wgt)
+    ik = np.where(kk < 0, np.trunc(-0.5 + kk * (1 << 22)), np.trunc(0.5 + kk * (1 << 22))).astype(np.int32)
+    return xmin.astype(np.int32), xsize.astype(np.int32), np.ascontiguousarray(ik)
+
+
+def cell_anchor_table() -> np.ndarray:
+    out = np.zeros((5, 3, 4), dtype=np.float32)
+    for l, size in enumerate(ANCHOR_SIZES):
+        area = size ** 2.0
+        for a, r in enumerate(ANCHOR_RATIOS):
+            w = math.sqrt(area / r)
+            h = r * w
+            out[l, a] = (-w / 2.0, -h / 2.0, w / 2.0, h / 2.0)
+    return out
+
+
+@dataclass
+class ConvLayer:
+    w: torch.Tensor
+    scale: Optional[torch.Tensor]
+    bias: Optional[torch.Tensor]
+    cin: int
+    cout: int
+    cout_pad: int
+    kh: int
+    kw: int
+    stride: int
+    pad: int
+
+
+@dataclass
+class RawDetections:
+    """Device-resident result of one batched forward (nothing has crossed PCIe yet)."""
+    boxes: torch.Tensor      # [B, D, 4] f32 output-image coords
+    scores: torch.Tensor     # [B, D] f32
+    classes: torch.Tensor    # [B, D] i32
+    valid: torch.Tensor      # [B, D] u8   (i < count and box non-empty)
+    count: torch.Tensor      # [B] i32
+    packed: torch.Tensor     # [B, D, H, W/32] i32 (bit-packed masks)
+    height: int
+    width: int
+
+
+class MaskRCNNEngine:
+    def __init__(self, state_dict: Dict[str, torch.Tensor], depth: int, num_classes: int, score_thresh: float,
+                 device: str = "cuda:0", precision: str = "bf16"):
+        if depth not in RES_BLOCKS:
+            raise ValueError(f"unsupported ResNet depth {depth}")
+        if not torch.cuda.is_available():
+            raise _lib.HipExtensionMissing("no HIP device visible: the deepEMIA hot path has no CPU fallback")
+        self.lib = _lib.load()
+        self.depth = depth
+        self.K = int(num_classes)
+        self.score_thresh = float(score_thresh)
+        self.device = torch.device(device)
+        self.precision = precision
+        self.dt = BF16 if precision == "bf16" else F32
+        self.tdt = torch.bfloat16 if precision == "bf16" else torch.float32
+        self._tables: Dict[Tuple[int, int], dict] = {}
+        self._cell = cell_anchor_table()
+        self.unmatched_keys: List[str] = []
+        self._used = set()
+        self._pack(state_dict)
+
+    # ------------------------------------------------------------------ weight packing
+    def _get(self, sd, key):
+        if key not in sd:
+            raise KeyError(f"checkpoint is missing '{key}' (expected Detectron2 0.6 Mask R-CNN R{self.depth}-FPN layout)")
+        self._used.add(key)
+        return sd[key].detach().to(torch.float32).cpu()
+
+    def _conv(self, sd, prefix, stride=1, pad=0, norm=False, bias=False, weight=None, bias_t=None) -> ConvLayer:
+        w = self._get(sd, prefix + ".weight") if weight is None else weight
+        cout, cin, kh, kw = w.shape
+        cout_pad = (cout + 31) // 32 * 32
+        wp = torch.zeros((cout_pad, kh, kw, cin), dtype=torch.float32)
+        wp[:cout] = w.permute(0, 2, 3, 1)
+        scale = b = None
+        if norm:
+            g = self._get(sd, prefix + ".norm.weight")
+            beta = self._get(sd, prefix + ".norm.bias")
+            rm = self._get(sd, prefix + ".norm.running_mean")
+            rv = self._get(sd, prefix + ".norm.running_var")
+            scale = g * (rv + BN_EPS).rsqrt()
+            b = beta - rm * scale
+        elif bias:
+            b = self._get(sd, prefix + ".bias") if bias_t is None else bias_t
+        dev = self.device
+        return ConvLayer(wp.to(dev, self.tdt).contiguous(),
+                         None if scale is None else scale.to(dev).contiguous(),
+                         None if b is None else b.to(dev).contiguous(), cin, cout, cout_pad, kh, kw, stride, pad)
+
+    def _pack(self, sd):
+        bu = "backbone.bottom_up."
+        w = self._get(sd, bu + "stem.conv1.weight")  # [64, 3, 7, 7]
+        ws = torch.zeros((7, 8, 4, 64), dtype=torch.float32)
+        ws[:, :7, :3, :] = w.permute(2, 3, 1, 0)
+        g = self._get(sd, bu + "stem.conv1.norm.weight")
+        beta = self._get(sd, bu + "stem.conv1.norm.bias")
+        rm = self._get(sd, bu + "stem.conv1.norm.running_mean")
+        rv = self._get(sd, bu + "stem.conv1.norm.running_var")
+        sc = g * (rv + BN_EPS).rsqrt()
+        self.stem_w = ws.to(self.device).contiguous()
+        self.stem_scale = sc.to(self.device).contiguous()
+        self.stem_bias = (beta - rm * sc).to(self.device).contiguous()
+        self.blocks = []
+        for stage, nblk in zip((2, 3, 4, 5), RES_BLOCKS[self.depth]):
+            stage_blocks = []
+            for i in range(nblk):
+                p = f"{bu}res{stage}.{i}."
+                stride = 2 if (i == 0 and stage > 2) else 1
+                blk = {}
+                if (p + "shortcut.weight") in sd:
+                    blk["shortcut"] = self._conv(sd, p + "shortcut", stride=stride, norm=True)
+                blk["conv1"] = self._conv(sd, p + "conv1", stride=stride, norm=True)
+                blk["conv2"] = self._conv(sd, p + "conv2", pad=1, norm=True)
+                blk["conv3"] = self._conv(sd, p + "conv3", norm=True)
+                stage_blocks.append(blk)
+            self.blocks.append(stage_blocks)
+        self.fpn_lateral = {l: self._conv(sd, f"backbone.fpn_lateral{l}", bias=True) for l in (2, 3, 4, 5)}
+        self.fpn_output = {l: self._conv(sd, f"backbone.fpn_output{l}", pad=1, bias=True) for l in (2, 3, 4, 5)}
+        rp = "proposal_generator.rpn_head."
+        self.rpn_conv = self._conv(sd, rp + "conv", pad=1, bias=True)
+        wobj, wdel = self._get(sd, rp + "objectness_logits.weight"), self._get(sd, rp + "anchor_deltas.weight")
+        bobj, bdel = self._get(sd, rp + "objectness_logits.bias"), self._get(sd, rp + "anchor_deltas.bias")
+        self.rpn_pred = self._conv(sd, "", bias=True, weight=torch.cat([wobj, wdel], 0), bias_t=torch.cat([bobj, bdel], 0))
+        bh = "roi_heads.box_head."
+        w1 = self._get(sd, bh + "fc1.weight")
+        w1 = w1.view(w1.shape[0], 256, 7, 7).permute(0, 2, 3, 1).reshape(w1.shape[0], 12544, 1, 1)
+        self.fc1 = self._conv(sd, "", bias=True, weight=w1, bias_t=self._get(sd, bh + "fc1.bias"))
+        w2 = self._get(sd, bh + "fc2.weight")
+        self.fc2 = self._conv(sd, "", bias=True, weight=w2[:, :, None, None], bias_t=self._get(sd, bh + "fc2.bias"))
+        bp = "roi_heads.box_predictor."
+        wc, wb = self._get(sd, bp + "cls_score.weight"), self._get(sd, bp + "bbox_pred.weight")
+        bc, bb = self._get(sd, bp + "cls_score.bias"), self._get(sd, bp + "bbox_pred.bias")
+        if wc.shape[0] != self.K + 1 or wb.shape[0] != 4 * self.K:
+            raise ValueError(f"checkpoint has {wc.shape[0] - 1} classes, dataset metadata says {self.K}")
+        self.box_pred = self._conv(sd, "", bias=True, weight=torch.cat([wc, wb], 0)[:, :, None, None],
+                                   bias_t=torch.cat([bc, bb], 0))
+        mh = "roi_heads.mask_head."
+        self.mask_fcn = [self._conv(sd, f"{mh}mask_fcn{i}", pad=1, bias=True) for i in range(1, 5)]
+        wd = self._get(sd, mh + "deconv.weight")  # [Cin, Cout, 2, 2]
+        wd = wd.permute(2, 3, 1, 0).reshape(4 * wd.shape[1], wd.shape[0], 1, 1)
+        self.deconv = self._conv(sd, "", bias=True, weight=wd, bias_t=self._get(sd, mh + "deconv.bias").repeat(4))
+        self.mask_pred = self._conv(sd, mh + "predictor", bias=True)
+        self.unmatched_keys = sorted(k for k in sd if k not in self._used
+                                     and not k.startswith(EXPECTED_IGNORED_PREFIXES))
+
+    # ------------------------------------------------------------------ kernel helpers
+    def _stream(self) -> int:
+        return int(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def conv(self, x: torch.Tensor, L: ConvLayer, act=ACT_NONE, residual=None, res_mode=RES_NONE,
+             out_dtype=None, out: Optional[torch.Tensor] = None, out_ld: int = 0, tile_hint: int = 0) -> torch.Tensor:
+        n, h, w, cin = x.shape
+        assert cin == L.cin, (cin, L.cin)
+        ho = (h + 2 * L.pad - L.kh) // L.stride + 1
+        wo = (w + 2 * L.pad - L.kw) // L.stride + 1
+        odt = self.tdt if out_dtype is None else out_dtype
+        ld = out_ld if out_ld > 0 else L.cout
+        if out is None:
+            out = torch.empty((n, ho, wo, ld), dtype=odt, device=self.device)
+        d = _lib.ConvDesc(_lib.ptr(x), _lib.ptr(L.w), _lib.ptr(L.scale), _lib.ptr(L.bias), _lib.ptr(residual),
+                          _lib.ptr(out), n, h, w, cin, ho, wo, L.cout, L.cout_pad, L.kh, L.kw, L.stride, L.pad,
+                          self.dt, BF16 if odt == torch.bfloat16 else F32, act, res_mode, ld, tile_hint)
+        _lib.check(self.lib.demia_conv2d_nhwc(C.byref(d), self._stream()), "demia_conv2d_nhwc")
+        return out
+
+    def _resize_tables(self, h: int, w: int):
+        key = (h, w)
+        if key not in self._tables:
+            newh, neww = resize_shape(h, w)
+            xm, xs, xk = pil_bilinear_tables(w, neww)
+            ym, ys, yk = pil_bilinear_tables(h, newh)
+            t = lambda a: torch.from_numpy(a).to(self.device)
+            self._tables[key] = dict(newh=newh, neww=neww, xm=t(xm), xs=t(xs), xk=t(xk), ksx=xk.shape[1],
+                                     ym=t(ym), ys=t(ys), yk=t(yk), ksy=yk.shape[1], need_h=(w != neww))
+        return self._tables[key]
+
+    # ------------------------------------------------------------------ stages
+    def preprocess(self, images: torch.Tensor):
+        """[B, H, W, 3] u8 BGR (device) -> zero-bordered f32 stem input, (newh, neww, PH, PW)."""
+        b, h, w, _ = images.shape
+        t = self._resize_tables(h, w)
+        newh, neww = t["newh"], t["neww"]
+        ph, pw = (newh + 31) // 32 * 32, (neww + 31) // 32 * 32
+        st = self._stream()
+        if t["need_h"]:
+            tmp = torch.empty((b, h, neww, 3), dtype=torch.uint8, device=self.device)
+            _lib.check(self.lib.demia_resize_h_u8(_lib.ptr(images), _lib.ptr(tmp), b, h, w, neww, _lib.ptr(t["xm"]),
+                                                  _lib.ptr(t["xs"]), _lib.ptr(t["xk"]), t["ksx"], st), "demia_resize_h_u8")
+        else:
+            tmp = images
+        dst = torch.zeros((b, ph + 6, pw + 8, 4), dtype=torch.float32, device=self.device)
+        mean = (C.c_float * 3)(*PIXEL_MEAN)
+        _lib.check(self.lib.demia_resize_v_norm(_lib.ptr(tmp), _lib.ptr(dst), b, h, neww, newh, ph, pw, _lib.ptr(t["ym"]),
+                                                _lib.ptr(t["ys"]), _lib.ptr(t["yk"]), t["ksy"], mean, F32, st),
+                   "demia_resize_v_norm")
+        return dst, newh, neww, ph, pw
+
+    def backbone(self, xin: torch.Tensor, ph: int, pw: int) -> Dict[str, torch.Tensor]:
+        b = xin.shape[0]
+        st = self._stream()
+        mid = torch.empty((b, ph // 2, pw // 2, 64), dtype=self.tdt, device=self.device)
+        _lib.check(self.lib.demia_stem_conv(_lib.ptr(xin), _lib.ptr(self.stem_w), _lib.ptr(self.stem_scale),
+                                            _lib.ptr(self.stem_bias), _lib.ptr(mid), b, ph, pw, self.dt, st), "demia_stem_conv")
+        x = torch.empty((b, ph // 4, pw // 4, 64), dtype=self.tdt, device=self.device)
+        _lib.check(self.lib.demia_maxpool3x3s2(_lib.ptr(mid), _lib.ptr(x), b, ph // 2, pw // 2, 64, self.dt, st),
+                   "demia_maxpool3x3s2")
+        feats = {"stem": x}
+        for si, stage_blocks in enumerate(self.blocks):
+            for blk in stage_blocks:
+                sc = self.conv(x, blk["shortcut"]) if "shortcut" in blk else x
+                o = self.conv(x, blk["conv1"], act=ACT_RELU)
+                o = self.conv(o, blk["conv2"], act=ACT_RELU)
+                x = self.conv(o, blk["conv3"], act=ACT_RELU, residual=sc, res_mode=RES_SAME)
+            feats[f"res{si + 2}"] = x
+        prev = None
+        for lvl in (5, 4, 3, 2):
+            if prev is None:
+                lat = self.conv(feats[f"res{lvl}"], self.fpn_lateral[lvl])
+            else:
+                lat = self.conv(feats[f"res{lvl}"], self.fpn_lateral[lvl], residual=prev, res_mode=RES_UP2)
+            prev = lat
+            feats[f"p{lvl}"] = self.conv(lat, self.fpn_output[lvl])
+        p5 = feats["p5"]
+        h5, w5 = p5.shape[1], p5.shape[2]
+        p6 = torch.empty((b, (h5 - 1) // 2 + 1, (w5 - 1) // 2 + 1, 256), dtype=self.tdt, device=self.device)
+        _lib.check(self.lib.demia_subsample2(_lib.ptr(p5), _lib.ptr(p6), b, h5, w5, 256, self.dt, st), "demia_subsample2")
+        feats["p6"] = p6
+        return feats
+
+    def rpn(self, feats, newh: int, neww: int):
+        b = feats["p2"].shape[0]
+        heads = []
+        for name in ("p2", "p3", "p4", "p5", "p6"):
+            t = self.conv(feats[name], self.rpn_conv, act=ACT_RELU)
+            heads.append(self.conv(t, self.rpn_pred, out_dtype=torch.float32, out_ld=16))
+        boxes = torch.empty((b, POST_NMS_TOPK, 4), dtype=torch.float32, device=self.device)
+        scores = torch.empty((b, POST_NMS_TOPK), dtype=torch.float32, device=self.device)
+        count = torch.empty((b,), dtype=torch.int32, device=self.device)
+        ws = torch.empty((int(self.lib.demia_rpn_workspace_bytes(b)),), dtype=torch.uint8, device=self.device)
+        d = _lib.RpnDesc()
+        for i, hd in enumerate(heads):
+            d.head[i] = _lib.ptr(hd)
+            d.H[i], d.W[i], d.stride[i] = hd.shape[1], hd.shape[2], STRIDES[i]
+        d.cell_anchors = self._cell.ctypes.data
+        d.head_ld, d.N, d.img_h, d.img_w = 16, b, newh, neww
+        d.pre_topk, d.post_topk, d.nms_thresh = PRE_NMS_TOPK, POST_NMS_TOPK, RPN_NMS_THRESH
+        d.out_boxes, d.out_scores, d.out_count, d.workspace = _lib.ptr(boxes), _lib.ptr(scores), _lib.ptr(count), _lib.ptr(ws)
+        _lib.check(self.lib.demia_rpn_proposals(C.byref(d), self._stream()), "demia_rpn_proposals")
+        self._dbg_heads = heads
+        return boxes, scores, count
+
+    def roi_align(self, feats, boxes: torch.Tensor, count: torch.Tensor, P: int) -> torch.Tensor:
+        b, r, _ = boxes.shape
+        out = torch.empty((b, r, P, P, 256), dtype=self.tdt, device=self.device)
+        d = _lib.RoiAlignDesc()
+        for i, name in enumerate(("p2", "p3", "p4", "p5")):
+            f = feats[name]
+            d.feat[i] = _lib.ptr(f)
+            d.H[i], d.W[i] = f.shape[1], f.shape[2]
+        d.N, d.R, d.C, d.P, d.dtype = b, r, 256, P, self.dt
+        d.boxes, d.count, d.out = _lib.ptr(boxes), _lib.ptr(count), _lib.ptr(out)
+        _lib.check(self.lib.demia_roi_align(C.byref(d), self._stream()), "demia_roi_align")
+        return out
+
+    def box_head(self, pooled: torch.Tensor) -> torch.Tensor:
+        b, r = pooled.shape[:2]
+        x = pooled.view(b * r, 1, 1, 12544)
+        x = self.conv(x, self.fc1, act=ACT_RELU)
+        x = self.conv(x, self.fc2, act=ACT_RELU)
+        ld = (5 * self.K + 1 + 3) // 4 * 4
+        return self.conv(x, self.box_pred, out_dtype=torch.float32, out_ld=ld).view(b, r, ld)
+
+    def detections(self, logits, props, prop_count, newh, neww):
+        b, r, ld = logits.shape
+        D = DETS_PER_IMAGE
+        det_boxes = torch.empty((b, D, 4), dtype=torch.float32, device=self.device)
+        det_scores = torch.empty((b, D), dtype=torch.float32, device=self.device)
+        det_classes = torch.empty((b, D), dtype=torch.int32, device=self.device)
+        det_count = torch.empty((b,), dtype=torch.int32, device=self.device)
+        d = _lib.DetsDesc(_lib.ptr(logits), ld, _lib.ptr(props), _lib.ptr(prop_count), b, r, self.K, newh, neww,
+                          self.score_thresh, DET_NMS_THRESH, D, _lib.ptr(det_boxes), _lib.ptr(det_scores),
+                          _lib.ptr(det_classes), _lib.ptr(det_count))
+        _lib.check(self.lib.demia_box_detections(C.byref(d), self._stream()), "demia_box_detections")
+        return det_boxes, det_scores, det_classes, det_count
+
+    def mask_head(self, mpooled: torch.Tensor) -> torch.Tensor:
+        b, dd = mpooled.shape[:2]
+        x = mpooled.view(b * dd, 14, 14, 256)
+        for L in self.mask_fcn:
+            x = self.conv(x, L, act=ACT_RELU)
+        x = self.conv(x.view(b * dd * 196, 1, 1, 256), self.deconv, act=ACT_RELU)        # [.., 1024] = (dy,dx,co)
+        x = self.conv(x.view(b * dd * 196 * 4, 1, 1, 256), self.mask_pred, act=ACT_SIGMOID,
+                      out_dtype=torch.float32, out_ld=(self.K + 3) // 4 * 4)
+        return x  # [(i*196 + cell)*4 + sub, 1, 1, ld] f32 probabilities
+
+    def paste(self, mask_prob, det_boxes, det_classes, det_count, newh, neww, out_h, out_w):
+        b, D = det_boxes.shape[:2]
+        if out_w % 32 != 0:
+            raise ValueError("image width must be a multiple of 32 for bit-packed masks")
+        out_boxes = torch.empty((b, D, 4), dtype=torch.float32, device=self.device)
+        valid = torch.empty((b, D), dtype=torch.uint8, device=self.device)
+        packed = torch.empty((b, D, out_h, out_w // 32), dtype=torch.int32, device=self.device)
+        d = _lib.PasteDesc(_lib.ptr(mask_prob), mask_prob.shape[-1], _lib.ptr(det_boxes), _lib.ptr(det_classes),
+                           _lib.ptr(det_count), b, D, newh, neww, out_h, out_w, _lib.ptr(out_boxes), _lib.ptr(valid),
+                           _lib.ptr(packed))
+        _lib.check(self.lib.demia_paste_masks(C.byref(d), self._stream()), "demia_paste_masks")
+        return out_boxes, valid, packed
+
+    # ------------------------------------------------------------------ whole forward
+    @torch.no_grad()
+    def forward(self, images: torch.Tensor, keep_intermediates: bool = False) -> RawDetections:
+        """images: [B, H, W, 3] uint8 BGR on the device."""
+        assert images.dtype == torch.uint8 and images.dim() == 4 and images.shape[3] == 3
+        images = images.contiguous()
+        b, h, w, _ = images.shape
+        xin, newh, neww, ph, pw = self.preprocess(images)
+        feats = self.backbone(xin, ph, pw)
+        props, pscores, pcount = self.rpn(feats, newh, neww)
+        pooled = self.roi_align(feats, props, pcount, 7)
+        logits = self.box_head(pooled)
+        det_boxes, det_scores, det_classes, det_count = self.detections(logits, props, pcount, newh, neww)
+        mpooled = self.roi_align(feats, det_boxes, det_count, 14)
+        mask_prob = self.mask_head(mpooled)
+        out_boxes, valid, packed = self.paste(mask_prob, det_boxes, det_classes, det_count, newh, neww, h, w)
+        res = RawDetections(out_boxes, det_scores, det_classes, valid, det_count, packed, h, w)
+        if keep_intermediates:
+            res.dbg = dict(xin=xin, feats=feats, props=props, pscores=pscores, pcount=pcount, pooled=pooled,
+                           logits=logits, det_boxes=det_boxes, mpooled=mpooled, mask_prob=mask_prob,
+                           heads=self._dbg_heads, newh=newh, neww=neww)
+        return res
+
+    def unpack(self, packed: torch.Tensor, h: int, w: int) -> torch.Tensor:
+        """bit-packed [M, H, W/32] -> Detectron2's (M, H, W) bool."""
+        m = packed.shape[0]
+        out = torch.empty((m, h, w), dtype=torch.bool, device=self.device)
+        _lib.check(self.lib.demia_unpack_masks(_lib.ptr(packed), _lib.ptr(out), m, h, w, self._stream()), "demia_unpack_masks")
+        return out
+
+    def area_bbox(self, packed: torch.Tensor, h: int, w: int):
+        m = packed.shape[0]
+        area = torch.empty((m,), dtype=torch.int32, device=self.device)
+        bbox = torch.empty((m, 4), dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.demia_mask_area_bbox(_lib.ptr(packed), _lib.ptr(area), _lib.ptr(bbox), m, h, w, self._stream()),
+                   "demia_mask_area_bbox")
+        return area, bbox

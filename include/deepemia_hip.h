@@ -1,0 +1,202 @@
+/*
+ * deepemia_hip.h -- C ABI of libdeepemia_hip.so (gfx950 / MI355X only).
+ *
+ * This is the drop-in boundary for ONE path of Deam0on/deepEMIA: the
+ * Detectron2 `DefaultPredictor.__call__` that the reference invokes at
+ *   src/functions/inference.py:1395, 1398, 1507, 1669   (predictor(image))
+ * built by src/data/models.py:103-107 (load_model -> DefaultPredictor(cfg)),
+ * plus the per-mask post-processing / dedup / measurement reductions that the
+ * reference runs on the host afterwards.
+ *
+ * Conventions
+ *   - every entry point is `extern "C"`, takes raw DEVICE pointers + sizes +
+ *     a `hipStream_t` (passed as void*), and returns 0 on success or a negative
+ *     DEMIA_E* code; no exceptions cross the ABI, nothing is allocated or freed
+ *     behind the caller's back, no ownership is transferred;
+ *   - all launches are asynchronous on the given stream and graph-capturable
+ *     (no hipMalloc / hipFree / sync inside);
+ *   - tensors are NHWC ("pixel-major, channel-minor"); `dtype` is 0 = f32,
+ *     1 = bf16;
+ *   - re-entrant per stream; one host thread per GPU.
+ */
+#ifndef DEEPEMIA_HIP_H
+#define DEEPEMIA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DEMIA_OK 0
+#define DEMIA_EINVAL (-1)   /* bad shape / unsupported combination            */
+#define DEMIA_ELAUNCH (-2)  /* hipLaunch / runtime error (see demia_last_error) */
+
+#define DEMIA_F32 0
+#define DEMIA_BF16 1
+
+#define DEMIA_ACT_NONE 0
+#define DEMIA_ACT_RELU 1
+#define DEMIA_ACT_SIGMOID 2
+
+#define DEMIA_RES_NONE 0
+#define DEMIA_RES_SAME 1      /* residual has the output's shape                      */
+#define DEMIA_RES_UP2 2       /* residual is (Ho/2 rounded up, Wo/2 rounded up): nearest x2  */
+
+/* library / device info ------------------------------------------------------------*/
+int demia_abi_version(void);
+const char* demia_last_error(void);
+const char* demia_build_arch(void);   /* "gfx950" */
+
+/* a3: convolution as implicit GEMM on MFMA -------------------------------------------
+ * Replaces every Conv2d(+FrozenBatchNorm)(+ReLU)(+residual add) / Linear /
+ * ConvTranspose2d(k2,s2) that Detectron2's GeneralizedRCNN runs inside
+ * predictor(image) (inference.py:1395).
+ *   in        [N, H, W, Cin]        dtype `dtype`
+ *   w         [CoutPad, KH, KW, Cin] dtype `dtype`, CoutPad = multiple of 32 >= Cout
+ *   scale/bias [Cout] f32 or NULL    y = acc * scale + bias   (FrozenBN folded / conv bias)
+ *   residual  NULL or out-shaped (RES_SAME) / half-res (RES_UP2), dtype `out_dtype`
+ *   out       [N, Ho, Wo, Cout]      dtype `out_dtype`
+ * Cin must be a multiple of 64 (bf16) / 32 (f32).  */
+typedef struct demia_conv_desc {
+    const void* in;
+    const void* w;
+    const float* scale;
+    const float* bias;
+    const void* residual;
+    void* out;
+    int32_t N, H, W, Cin;
+    int32_t Ho, Wo, Cout, CoutPad;
+    int32_t KH, KW, stride, pad;
+    int32_t dtype, out_dtype;
+    int32_t act, res_mode;
+    int32_t out_ld;          /* elements between consecutive output pixels (>= Cout); 0 -> Cout */
+    int32_t tile_hint;       /* 0 = auto; else BN in {128, 64, 32} */
+} demia_conv_desc;
+int demia_conv2d_nhwc(const demia_conv_desc* d, void* stream);
+
+/* a3: Pillow-exact ResizeShortestEdge + (x - mean) + zero pad -------------------------
+ * Replaces T.ResizeShortestEdge.get_transform(img).apply_image(img) +
+ * normalisation + ImageList.from_tensors inside DefaultPredictor.__call__ /
+ * GeneralizedRCNN.preprocess_image (Detectron2 0.6), called from inference.py:1395.
+ * Two separable 8-bit fixed-point passes (22-bit coefficients) identical to
+ * Pillow's ImagingResample.  Coefficient tables are computed by the host.
+ *   src     [N, H, W, 3] u8 (BGR)         tmp [N, H, newW, 3] u8
+ *   xmin/xsize [newW] i32, xk [newW, ksx] i32; same for y
+ *   dst     [N, PH + 6, PW + 8, 4] `dtype`: interior at (+3, +3) holds the
+ *           normalised image, channel 3 and every border / pad element = 0.   */
+int demia_resize_h_u8(const uint8_t* src, uint8_t* tmp, int N, int H, int W, int newW,
+                      const int32_t* xmin, const int32_t* xsize, const int32_t* xk, int ksx, void* stream);
+int demia_resize_v_norm(const uint8_t* tmp, void* dst, int N, int H, int newW, int newH, int PH, int PW,
+                        const int32_t* ymin, const int32_t* ysize, const int32_t* yk, int ksy,
+                        const float* mean3, int dtype, void* stream);
+
+/* a3: ResNet stem: conv 7x7 s2 p3 (3->64) + FrozenBN + ReLU, then maxpool 3x3 s2 p1 ----
+ *   in   [N, PH + 6, PW + 8, 4] f32 (see above)    w [7, 8, 4, 64] f32 (kh, kw, c, co; kw 7 and c 3 zero)
+ *   mid  [N, PH/2, PW/2, 64]   out [N, PH/4, PW/4, 64]                              */
+int demia_stem_conv(const void* in, const void* w, const float* scale, const float* bias, void* mid,
+                    int N, int PH, int PW, int dtype, void* stream);
+int demia_maxpool3x3s2(const void* in, void* out, int N, int H, int W, int C, int dtype, void* stream);
+/* LastLevelMaxPool (kernel 1, stride 2): p6 = p5[:, ::2, ::2, :] */
+int demia_subsample2(const void* in, void* out, int N, int H, int W, int C, int dtype, void* stream);
+
+/* a3: RPN proposal selection --------------------------------------------------------
+ * Replaces RPN.predict_proposals / find_top_rpn_proposals (Detectron2 0.6):
+ * per image and level the top `pre_topk` objectness logits in STABLE descending
+ * order (ties: lower flattened (h, w, a) index first), anchor generation + delta
+ * decode (weights 1,1,1,1, clamp log(1000/16)), clip to the image, drop non-finite /
+ * empty boxes, per-level hard NMS (IoU > thresh suppresses), then the `post_topk`
+ * best survivors over all levels in stable descending score order.
+ *   head[l]   [N, H_l, W_l, head_ld] f32: channels 0..2 = logits (a), 3..14 = deltas (a*4 + c)
+ *   out_boxes [N, post_topk, 4] f32, out_scores [N, post_topk] f32, out_count [N] i32
+ *   workspace: demia_rpn_workspace_bytes(N) bytes                                      */
+typedef struct demia_rpn_desc {
+    const float* head[5];
+    int32_t H[5], W[5], stride[5];
+    const float* cell_anchors;   /* HOST pointer, [5][3][4] f32: (x1,y1,x2,y2) of anchor a at the origin */
+    int32_t head_ld;
+    int32_t N;
+    int32_t img_h, img_w;        /* unpadded network-input size boxes are clipped to */
+    int32_t pre_topk, post_topk; /* <= 1024 each */
+    float nms_thresh;
+    float* out_boxes;
+    float* out_scores;
+    int32_t* out_count;
+    void* workspace;
+} demia_rpn_desc;
+int64_t demia_rpn_workspace_bytes(int N);
+int demia_rpn_proposals(const demia_rpn_desc* d, void* stream);
+
+/* a3: ROIAlignV2 (aligned, sampling_ratio 0 = adaptive) over p2..p5 -------------------
+ * Replaces ROIPooler.forward -> torchvision.ops.roi_align(aligned=True) incl. the
+ * FPN level assignment floor(4 + log2(sqrt(area)/224 + 1e-8)) clamped to [2, 5].
+ *   feat[l] [N, H_l, W_l, C] `dtype`; boxes [N, R, 4] f32 (network-input coords);
+ *   count [N] i32 (rows >= count[n] are written as zeros); out [N, R, P, P, C] `dtype` */
+typedef struct demia_roialign_desc {
+    const void* feat[4];
+    int32_t H[4], W[4];
+    int32_t N, R, C, P, dtype;
+    const float* boxes;
+    const int32_t* count;
+    void* out;
+} demia_roialign_desc;
+int demia_roi_align(const demia_roialign_desc* d, void* stream);
+
+/* a3: Fast R-CNN inference ---------------------------------------------------------
+ * Replaces FastRCNNOutputLayers.inference / fast_rcnn_inference_single_image:
+ * softmax over K+1 logits, class-specific delta decode (weights 10,10,5,5), clip,
+ * score > thresh (strict), candidates in row-major (proposal, class) order, stable
+ * descending sort, per-class hard NMS (IoU > 0.5), first `topk` survivors.
+ *   logits [N, R, ld] f32: channels 0..K = class logits, K+1 .. K+4K = deltas
+ *   props  [N, R, 4] f32, prop_count [N] i32
+ *   det_boxes [N, topk, 4] f32 (network-input coords), det_scores [N, topk] f32,
+ *   det_classes [N, topk] i32, det_count [N] i32;  R*K <= 4096, topk <= 128           */
+typedef struct demia_dets_desc {
+    const float* logits;
+    int32_t ld;
+    const float* props;
+    const int32_t* prop_count;
+    int32_t N, R, K;
+    int32_t img_h, img_w;
+    float score_thresh, nms_thresh;
+    int32_t topk;
+    float* det_boxes;
+    float* det_scores;
+    int32_t* det_classes;
+    int32_t* det_count;
+} demia_dets_desc;
+int demia_box_detections(const demia_dets_desc* d, void* stream);
+
+/* a3: mask paste (paste_masks_in_image / _do_paste_mask, Detectron2 0.6) --------------
+ * Boxes are rescaled to the original image (scale_x = out_w / img_w ...), clipped,
+ * empty boxes flagged; each 28x28 probability map is resampled with bilinear
+ * grid_sample(align_corners=False, zero padding) and thresholded (>= 0.5).
+ *   mask_logit_or_prob [N*D, 196, 4, ld] f32 -- deconv-blocked layout: pixel (2y+dy, 2x+dx)
+ *        of instance i lives at [(i*196 + y*14 + x), dy*2+dx, class]; already sigmoid-ed
+ *   det_boxes [N, D, 4] f32 network-input coords, det_classes, det_count as above
+ *   out_boxes [N, D, 4] f32 output-image coords (clipped); valid [N, D] u8 (nonempty)
+ *   packed    [N, D, out_h, out_w/32] u32 : bit (x & 31) of word x>>5 = mask[y][x]
+ * out_w must be a multiple of 32.                                                     */
+typedef struct demia_paste_desc {
+    const float* mask_prob;
+    int32_t ld;
+    const float* det_boxes;
+    const int32_t* det_classes;
+    const int32_t* det_count;
+    int32_t N, D;
+    int32_t img_h, img_w;     /* network-input size */
+    int32_t out_h, out_w;     /* original image size */
+    float* out_boxes;
+    uint8_t* valid;
+    uint32_t* packed;
+} demia_paste_desc;
+int demia_paste_masks(const demia_paste_desc* d, void* stream);
+/* packed bits -> Detectron2's (M, H, W) bool bytes (pred_masks drop-in layout) */
+int demia_unpack_masks(const uint32_t* packed, uint8_t* out_bool, int64_t M, int H, int W, void* stream);
+/* per-mask popcount ("np.sum(mask)", inference.py:1688, 2599) and tight bbox [M,4] = y0,x0,y1,x1 (inclusive; -1 if empty) */
+int demia_mask_area_bbox(const uint32_t* packed, int32_t* area, int32_t* bbox, int64_t M, int H, int W, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEEPEMIA_HIP_H */
