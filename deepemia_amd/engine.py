@@ -140,6 +140,7 @@ class MaskRCNNEngine:
         self.tdt = torch.bfloat16 if precision == "bf16" else torch.float32
         self._tables: Dict[Tuple[int, int], dict] = {}
         self._cell = cell_anchor_table()
+        self.conv_events = None   # bench hook: list of (start_event, end_event, algorithmic_flops)
         self.unmatched_keys: List[str] = []
         self._used = set()
         self._pack(state_dict)
@@ -245,7 +246,14 @@ class MaskRCNNEngine:
         d = _lib.ConvDesc(_lib.ptr(x), _lib.ptr(L.w), _lib.ptr(L.scale), _lib.ptr(L.bias), _lib.ptr(residual),
                           _lib.ptr(out), n, h, w, cin, ho, wo, L.cout, L.cout_pad, L.kh, L.kw, L.stride, L.pad,
                           self.dt, BF16 if odt == torch.bfloat16 else F32, act, res_mode, ld, tile_hint)
+        ev = self.conv_events
+        if ev is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(self.device))
         _lib.check(self.lib.demia_conv2d_nhwc(C.byref(d), self._stream()), "demia_conv2d_nhwc")
+        if ev is not None:
+            e1.record(torch.cuda.current_stream(self.device))
+            ev.append((e0, e1, 2.0 * n * ho * wo * L.cout * L.kh * L.kw * cin))
         return out
 
     def _resize_tables(self, h: int, w: int):

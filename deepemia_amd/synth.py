@@ -108,6 +108,8 @@ def random_d2_state_dict(
     * ``head_gain``: multiplies the N(0, .01)/N(0, .001) std of RPN logits /
       deltas, ``cls_score`` and ``bbox_pred`` so that logits are not all ~0.
     * ``mask_bias``: ``mask_head.predictor.bias`` (+2 -> solid masks).
+    * the 1x1 / FC prediction layers (RPN logits and deltas, ``cls_score``, ``bbox_pred``)
+      get zero-mean rows, so class scores are balanced and detections saturate at 100.
     """
     assert depth in RES_BLOCKS
     g = torch.Generator().manual_seed(int(seed) * 1000 + depth)
@@ -143,12 +145,16 @@ def random_d2_state_dict(
         sd[f"backbone.fpn_lateral{lvl}.bias"] = torch.zeros(256)
         sd[f"backbone.fpn_output{lvl}.weight"] = _kaiming_uniform_a1((256, 256, 3, 3), g)
         sd[f"backbone.fpn_output{lvl}.bias"] = torch.zeros(256)
+    def zero_mean_rows(w):
+        # post-ReLU features are all positive: rows that sum to zero keep each logit centred on 0
+        return w - w.flatten(1).mean(dim=1).view(-1, *([1] * (w.dim() - 1)))
+
     rp = "proposal_generator.rpn_head."
     sd[rp + "conv.weight"] = torch.randn((256, 256, 3, 3), generator=g) * 0.01
     sd[rp + "conv.bias"] = torch.zeros(256)
-    sd[rp + "objectness_logits.weight"] = torch.randn((3, 256, 1, 1), generator=g) * 0.01 * head_gain
+    sd[rp + "objectness_logits.weight"] = zero_mean_rows(torch.randn((3, 256, 1, 1), generator=g)) * 0.01 * head_gain
     sd[rp + "objectness_logits.bias"] = torch.zeros(3)
-    sd[rp + "anchor_deltas.weight"] = torch.randn((12, 256, 1, 1), generator=g) * 0.01 * head_gain
+    sd[rp + "anchor_deltas.weight"] = zero_mean_rows(torch.randn((12, 256, 1, 1), generator=g)) * 0.01 * head_gain
     sd[rp + "anchor_deltas.bias"] = torch.zeros(12)
     bh = "roi_heads.box_head."
     sd[bh + "fc1.weight"] = _kaiming_uniform_a1((1024, 256 * 7 * 7), g)
@@ -157,9 +163,9 @@ def random_d2_state_dict(
     sd[bh + "fc2.bias"] = torch.zeros(1024)
     bp = "roi_heads.box_predictor."
     k = int(num_classes)
-    sd[bp + "cls_score.weight"] = torch.randn((k + 1, 1024), generator=g) * 0.01 * head_gain
+    sd[bp + "cls_score.weight"] = zero_mean_rows(torch.randn((k + 1, 1024), generator=g)) * 0.01 * head_gain
     sd[bp + "cls_score.bias"] = torch.zeros(k + 1)
-    sd[bp + "bbox_pred.weight"] = torch.randn((4 * k, 1024), generator=g) * 0.001 * head_gain
+    sd[bp + "bbox_pred.weight"] = zero_mean_rows(torch.randn((4 * k, 1024), generator=g)) * 0.001 * head_gain
     sd[bp + "bbox_pred.bias"] = torch.zeros(4 * k)
     mh = "roi_heads.mask_head."
     for i in range(1, 5):

@@ -1,0 +1,332 @@
+"""GPU parity tests proper: every stage of the HIP predictor against the CPU oracle, called
+through the C ABI of libdeepemia_hip.so (ctypes), on the same seeded inputs.
+
+Tolerances (floating point; integer / order / byte work is bit-exact):
+  * resize + normalise: bit-exact vs Pillow;
+  * f32 convolutions (exact-f32 MFMA): <= 2e-5 of the tensor's max |value|;
+  * bf16 convolutions: <= 3e-2 of max |value| (bf16 has 8 significand bits);
+  * proposal / detection selection on identical inputs: identical order and classes,
+    boxes within 2e-3 px (expf differs by <= 2 ulp between libm and the GPU);
+  * pasted masks: IoU >= 0.999 (north_star), here observed 1.0;
+  * end to end in f32: same instances in the same order, mask IoU >= 0.999.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+from PIL import Image
+
+pytestmark = pytest.mark.gpu
+
+K = 2
+THR = 0.3
+
+
+@pytest.fixture(scope="module")
+def env(gpu_device):
+    from deepemia_amd import synth
+    from deepemia_amd.engine import MaskRCNNEngine
+    from oracle import maskrcnn_ref as R
+
+    sd = synth.random_d2_state_dict(50, K, seed=0)
+    img = synth.em_tile(0, 1024)
+    ref = R.predict(img, sd, 50, THR, return_intermediates=True)
+    eng = MaskRCNNEngine(sd, 50, K, THR, gpu_device, "f32")
+    return dict(sd=sd, img=img, ref=ref, eng=eng, R=R, synth=synth, dev=gpu_device)
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def test_library_is_the_hip_one(env):
+    lib = env["eng"].lib
+    assert lib.demia_build_arch().decode() == "gfx950"
+    assert lib.demia_abi_version() == 1
+
+
+@pytest.mark.parametrize("hw", [(1024, 1024), (2048, 2048), (600, 600), (700, 1100), (1000, 2000)])
+def test_resize_normalise_bit_exact_vs_pillow(env, hw):
+    eng, R = env["eng"], env["R"]
+    h, w = hw
+    rng = np.random.default_rng(h * 7 + w)
+    img = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+    x = torch.from_numpy(img)[None].to(env["dev"])
+    xin, newh, neww, ph, pw = eng.preprocess(x)
+    ref = np.asarray(Image.fromarray(img).resize((neww, newh), Image.BILINEAR)).astype(np.float32)
+    ref = ref - np.array(R.PIXEL_MEAN, dtype=np.float32)
+    got = xin[0].cpu().numpy()
+    assert got.shape == (ph + 6, pw + 8, 4)
+    assert (newh, neww) == R.resize_shape(h, w)
+    np.testing.assert_array_equal(got[3:3 + newh, 3:3 + neww, :3], ref)
+    # border, padding and the 4th channel are zero
+    mask = np.ones_like(got, dtype=bool)
+    mask[3:3 + newh, 3:3 + neww, :3] = False
+    assert not got[mask].any()
+
+
+CONV_CASES = [
+    # cin, cout, k, stride, pad, h, w, n, relu, res
+    (64, 64, 1, 1, 0, 50, 50, 2, True, 0),
+    (64, 256, 1, 1, 0, 37, 41, 1, False, 1),
+    (256, 128, 1, 2, 0, 50, 50, 2, True, 0),
+    (64, 64, 3, 1, 1, 33, 29, 2, True, 0),
+    (128, 128, 3, 1, 1, 25, 25, 3, True, 0),
+    (256, 15, 1, 1, 0, 13, 13, 2, False, 0),
+    (256, 256, 3, 1, 1, 14, 14, 5, True, 0),
+    (512, 256, 1, 1, 0, 50, 50, 1, False, 2),
+]
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_igemm_vs_torch(env, case, prec):
+    from deepemia_amd import engine as E
+    from deepemia_amd._lib import ACT_NONE, ACT_RELU, RES_NONE, RES_SAME, RES_UP2
+
+    cin, cout, k, stride, pad, h, w, n, relu, res = case
+    g = torch.Generator().manual_seed(cin * 131 + cout * 7 + k)
+    eng = env["eng"] if prec == "f32" else E.MaskRCNNEngine.__new__(E.MaskRCNNEngine)
+    if prec == "bf16":
+        eng.__dict__.update(env["eng"].__dict__)
+        eng.dt, eng.tdt, eng.precision = E.BF16, torch.bfloat16, "bf16"
+    x = torch.randn((n, cin, h, w), generator=g)
+    wt = torch.randn((cout, cin, k, k), generator=g) / (cin * k * k) ** 0.5
+    scale = torch.rand((cout,), generator=g) + 0.5
+    bias = torch.randn((cout,), generator=g) * 0.1
+    if prec == "bf16":  # compare like with like: reference sees the same rounded operands
+        x, wt = x.bfloat16().float(), wt.bfloat16().float()
+    y = F.conv2d(x, wt, None, stride=stride, padding=pad) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)
+    ho, wo = y.shape[2], y.shape[3]
+    residual = None
+    if res == 1:
+        residual = torch.randn((n, cout, ho, wo), generator=g)
+        y = y + residual
+    elif res == 2:
+        residual = torch.randn((n, cout, (ho + 1) // 2, (wo + 1) // 2), generator=g)
+        y = y + F.interpolate(residual, scale_factor=2.0, mode="nearest")[:, :, :ho, :wo]
+    if relu:
+        y = F.relu(y)
+    cout_pad = (cout + 31) // 32 * 32
+    wp = torch.zeros((cout_pad, k, k, cin))
+    wp[:cout] = wt.permute(0, 2, 3, 1)
+    dev = env["dev"]
+    L = E.ConvLayer(wp.to(dev, eng.tdt), scale.to(dev), bias.to(dev), cin, cout, cout_pad, k, k, stride, pad)
+    rdev = None if residual is None else nhwc(residual).to(dev, eng.tdt)
+    if prec == "bf16" and residual is not None:
+        # the reference must see the rounded residual as well
+        rr = rdev.float().cpu().permute(0, 3, 1, 2)
+        y = F.conv2d(x, wt, None, stride=stride, padding=pad) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)
+        y = y + (rr if res == 1 else F.interpolate(rr, scale_factor=2.0, mode="nearest")[:, :, :ho, :wo])
+        y = F.relu(y) if relu else y
+    out = eng.conv(nhwc(x).to(dev, eng.tdt), L, act=ACT_RELU if relu else ACT_NONE, residual=rdev,
+                   res_mode=(RES_NONE, RES_SAME, RES_UP2)[res], out_dtype=torch.float32)
+    got = out.cpu().permute(0, 3, 1, 2)
+    tol = 2e-5 if prec == "f32" else 3e-2
+    err = float((got - y).abs().max() / y.abs().max())
+    assert err <= tol, err
+
+
+def test_backbone_fpn_features_f32(env):
+    eng, d = env["eng"], env["ref"]["dbg"]
+    x = torch.from_numpy(env["img"])[None].to(env["dev"])
+    xin, newh, neww, ph, pw = eng.preprocess(x)
+    feats = eng.backbone(xin, ph, pw)
+    for k in ("res2", "res3", "res4", "res5", "p2", "p3", "p4", "p5", "p6"):
+        a = feats[k][0].permute(2, 0, 1).cpu()
+        b = d["feats"][k][0]
+        assert a.shape == b.shape
+        assert float((a - b).abs().max() / b.abs().max()) < 2e-5, k
+
+
+def _oracle_heads(env):
+    """RPN head tensors of the oracle in the [N, H, W, 16] layout of the C ABI."""
+    d = env["ref"]["dbg"]
+    heads = []
+    for li, name in enumerate(("p2", "p3", "p4", "p5", "p6")):
+        f = d["feats"][name]
+        h, w = f.shape[2], f.shape[3]
+        lv = d["rpn"]["per_level"][li]
+        hd = torch.zeros((1, h, w, 16))
+        hd[0, :, :, :3] = lv["logits"].view(h, w, 3)
+        hd[0, :, :, 3:15] = lv["deltas"].view(h, w, 12)
+        heads.append(hd.to(env["dev"]))
+    return heads
+
+
+def test_rpn_selection_on_oracle_heads(env):
+    from deepemia_amd import _lib, engine as E
+
+    eng, d = env["eng"], env["ref"]["dbg"]
+    heads = _oracle_heads(env)
+    newh, neww = d["resized"].shape[:2]
+    dev = env["dev"]
+    boxes = torch.empty((1, 1000, 4), device=dev)
+    scores = torch.empty((1, 1000), device=dev)
+    count = torch.empty((1,), dtype=torch.int32, device=dev)
+    ws = torch.empty((int(eng.lib.demia_rpn_workspace_bytes(1)),), dtype=torch.uint8, device=dev)
+    desc = _lib.RpnDesc()
+    for i, hd in enumerate(heads):
+        desc.head[i] = _lib.ptr(hd)
+        desc.H[i], desc.W[i], desc.stride[i] = hd.shape[1], hd.shape[2], E.STRIDES[i]
+    cell = E.cell_anchor_table()
+    desc.cell_anchors = cell.ctypes.data
+    desc.head_ld, desc.N, desc.img_h, desc.img_w = 16, 1, newh, neww
+    desc.pre_topk, desc.post_topk, desc.nms_thresh = 1000, 1000, 0.7
+    desc.out_boxes, desc.out_scores, desc.out_count, desc.workspace = map(_lib.ptr, (boxes, scores, count, ws))
+    _lib.check(eng.lib.demia_rpn_proposals(C.byref(desc), eng._stream()), "rpn")
+    torch.cuda.synchronize()
+    n = int(count[0])
+    assert n == d["prop_boxes"].shape[0]
+    # identical inputs -> identical order: scores are the logits themselves, bit-exact
+    np.testing.assert_array_equal(scores[0, :n].cpu().numpy(), d["prop_scores"].numpy())
+    assert float((boxes[0, :n].cpu() - d["prop_boxes"]).abs().max()) < 2e-3
+
+
+def test_roi_align_on_oracle_inputs(env):
+    eng, d = env["eng"], env["ref"]["dbg"]
+    dev = env["dev"]
+    feats = {k: nhwc(d["feats"][k]).to(dev) for k in ("p2", "p3", "p4", "p5")}
+    for boxes, P, ref in ((d["prop_boxes"], 7, d["pooled"]), (d["det_boxes"], 14, d["mpooled"])):
+        n = boxes.shape[0]
+        b = boxes[None].contiguous().to(dev)
+        cnt = torch.tensor([n], dtype=torch.int32, device=dev)
+        out = eng.roi_align(feats, b, cnt, P)[0].permute(0, 3, 1, 2).cpu()
+        err = float((out - ref).abs().max() / ref.abs().max())
+        assert err < 1e-5, (P, err)
+    # rows beyond count are zero
+    cnt = torch.tensor([3], dtype=torch.int32, device=dev)
+    out = eng.roi_align(feats, d["det_boxes"][None].contiguous().to(dev), cnt, 14)
+    assert not out[0, 3:].any()
+
+
+def test_box_detections_on_oracle_inputs(env):
+    eng, d, ref = env["eng"], env["ref"]["dbg"], env["ref"]
+    dev = env["dev"]
+    r = d["prop_boxes"].shape[0]
+    ld = 12
+    logits = torch.zeros((1, r, ld))
+    logits[0, :, :K + 1] = d["cls_logits"]
+    logits[0, :, K + 1:K + 1 + 4 * K] = d["deltas"]
+    newh, neww = d["resized"].shape[:2]
+    db, ds, dc, dn = eng.detections(logits.to(dev), d["prop_boxes"][None].contiguous().to(dev),
+                                    torch.tensor([r], dtype=torch.int32, device=dev), newh, neww)
+    n = int(dn[0])
+    assert n == d["det_boxes"].shape[0]
+    np.testing.assert_array_equal(dc[0, :n].cpu().numpy(), d["det_classes"].numpy())
+    assert float((ds[0, :n].cpu() - d["det_scores"]).abs().max()) < 1e-6
+    assert float((db[0, :n].cpu() - d["det_boxes"]).abs().max()) < 2e-3
+
+
+def test_paste_on_oracle_inputs(env):
+    eng, d, ref = env["eng"], env["ref"]["dbg"], env["ref"]
+    dev = env["dev"]
+    n = d["det_boxes"].shape[0]
+    D = 100
+    mp = d["mask_probs"][:, 0]  # [n, 28, 28]
+    blocked = torch.zeros((D, 196, 4, 4))
+    for dy in range(2):
+        for dx in range(2):
+            sub = mp[:, dy::2, dx::2].reshape(n, 196)
+            for c in range(K):
+                blocked[:n, :, dy * 2 + dx, c] = torch.where(d["det_classes"][:, None] == c, sub, torch.full_like(sub, -1.0))
+    det_boxes = torch.zeros((1, D, 4))
+    det_boxes[0, :n] = d["det_boxes"]
+    det_classes = torch.zeros((1, D), dtype=torch.int32)
+    det_classes[0, :n] = d["det_classes"].int()
+    newh, neww = d["resized"].shape[:2]
+    h, w = env["img"].shape[:2]
+    ob, valid, packed = eng.paste(blocked.view(D * 196 * 4, 1, 1, 4).to(dev), det_boxes.to(dev), det_classes.to(dev),
+                                  torch.tensor([n], dtype=torch.int32, device=dev), newh, neww, h, w)
+    masks = eng.unpack(packed[0, :n].contiguous(), h, w).cpu()
+    assert bool(valid[0, :n].all()) and not bool(valid[0, n:].any())
+    assert float((ob[0, :n].cpu() - ref["pred_boxes"]).abs().max()) < 1e-3
+    r = ref["pred_masks"]
+    diff = int((masks != r).sum())
+    inter = (masks & r).sum((1, 2)).float()
+    union = (masks | r).sum((1, 2)).float().clamp(min=1)
+    assert float((inter / union).min()) >= 0.999
+    assert diff <= n  # at most a threshold-tie pixel per instance
+    assert not packed[0, n:].any()
+
+
+def test_unpack_and_area_bbox_bit_exact(env):
+    eng, dev = env["eng"], env["dev"]
+    rng = np.random.default_rng(5)
+    m, h, w = 7, 96, 128
+    masks = np.zeros((m, h, w), dtype=bool)
+    for i in range(m - 1):
+        y0, x0 = rng.integers(0, h - 10), rng.integers(0, w - 10)
+        y1, x1 = rng.integers(y0 + 1, h + 1), rng.integers(x0 + 1, w + 1)
+        masks[i, y0:y1, x0:x1] = rng.random((y1 - y0, x1 - x0)) > 0.3
+    packed = np.packbits(masks.reshape(m, h, w // 32, 32), axis=-1, bitorder="little").view(np.uint32).reshape(m, h, w // 32)
+    p = torch.from_numpy(packed.view(np.int32)).to(dev)
+    got = eng.unpack(p, h, w).cpu().numpy()
+    np.testing.assert_array_equal(got, masks)
+    area, bbox = eng.area_bbox(p, h, w)
+    np.testing.assert_array_equal(area.cpu().numpy(), masks.sum((1, 2)))
+    for i in range(m):
+        ys, xs = np.nonzero(masks[i])
+        exp = [-1, -1, -1, -1] if len(ys) == 0 else [ys.min(), xs.min(), ys.max(), xs.max()]
+        assert bbox[i].cpu().tolist() == exp
+
+
+def test_end_to_end_f32_matches_oracle(env):
+    from deepemia_amd.predictor import Predictor
+
+    ref = env["ref"]
+    inst = Predictor(env["eng"])(env["img"])["instances"]
+    n = len(inst)
+    assert n == ref["scores"].shape[0] == 100
+    got = inst.to("cpu")
+    np.testing.assert_array_equal(got._fields["pred_classes"].numpy(), ref["pred_classes"].numpy())
+    assert got._fields["pred_classes"].dtype == torch.int64
+    assert float((got.scores - ref["scores"]).abs().max()) < 1e-4
+    assert bool((got.scores[:-1] >= got.scores[1:]).all())
+    assert float((got.pred_boxes - ref["pred_boxes"]).abs().max()) < 5e-2
+    m, r = got.pred_masks, ref["pred_masks"]
+    assert m.dtype == torch.bool and tuple(m.shape) == (n, 1024, 1024)
+    iou = (m & r).sum((1, 2)).float() / (m | r).sum((1, 2)).float().clamp(min=1)
+    assert float(iou.min()) >= 0.999
+
+
+def test_full_size_batch_properties(env):
+    """BASELINE configs[1] size (2048^2, R101 weights are only needed for speed, not here):
+    determinism and batch invariance of the whole path at the full tile size."""
+    eng, synth, dev = env["eng"], env["synth"], env["dev"]
+    tiles = np.stack([synth.em_tile(i, 2048) for i in range(3)])
+    x = torch.from_numpy(tiles).to(dev)
+    a = eng.forward(x)
+    b = eng.forward(x)
+    torch.cuda.synchronize()
+    assert torch.equal(a.packed, b.packed) and torch.equal(a.scores, b.scores) and torch.equal(a.boxes, b.boxes)
+    single = eng.forward(x[1:2].contiguous())
+    assert torch.equal(single.count[0], a.count[1])
+    n = int(single.count[0])
+    assert torch.equal(single.classes[0, :n], a.classes[1, :n])
+    assert torch.equal(single.packed[0, :n], a.packed[1, :n])
+    # mask area from the packed popcount equals the unpacked bool sum; masks lie inside their boxes' hull
+    area, bbox = eng.area_bbox(a.packed[1, :n].contiguous(), 2048, 2048)
+    um = eng.unpack(a.packed[1, :n].contiguous(), 2048, 2048)
+    assert torch.equal(area.long(), um.sum((1, 2)))
+    bx = a.boxes[1, :n]
+    ok = (bbox[:, 1] >= torch.floor(bx[:, 0]).int() - 1) & (bbox[:, 3] <= torch.ceil(bx[:, 2]).int() + 1)
+    assert bool(ok[area > 0].all())
+
+
+def test_bf16_features_within_tolerance(env):
+    from deepemia_amd.engine import MaskRCNNEngine
+
+    eng = MaskRCNNEngine(env["sd"], 50, K, THR, env["dev"], "bf16")
+    d = env["ref"]["dbg"]
+    x = torch.from_numpy(env["img"])[None].to(env["dev"])
+    xin, newh, neww, ph, pw = eng.preprocess(x)
+    feats = eng.backbone(xin, ph, pw)
+    for k in ("res5", "p2", "p5"):
+        a = feats[k][0].permute(2, 0, 1).float().cpu()
+        b = d["feats"][k][0]
+        assert float((a - b).abs().max() / b.abs().max()) < 5e-2, k
+    out = eng.forward(x)
+    assert int(out.count[0]) == 100
