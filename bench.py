@@ -34,7 +34,11 @@ def cpu_baseline(depth: int, size: int, thr: float, sd) -> dict:
     from oracle import maskrcnn_ref
 
     img = synth.em_tile(0, size)
-    torch.set_num_threads(max(1, (os.cpu_count() or 2)))
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(16, ncpu)))  # the GPU box gives one GPU a 16-core share
     t0 = time.perf_counter()
     out = maskrcnn_ref.predict(img, sd, depth, thr)
     dt = time.perf_counter() - t0

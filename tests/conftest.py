@@ -8,7 +8,21 @@ if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
 
+def _bounded_threads():
+    # the GPU box exposes every host core but gives one GPU a 16-core share: oversubscribing
+    # torch-CPU (the oracle) makes it many times slower
+    import os
+
+    import torch
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(16, n)))
+
+
 def pytest_configure(config):
+    _bounded_threads()
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 

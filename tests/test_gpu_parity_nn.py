@@ -121,9 +121,11 @@ def test_conv_igemm_vs_torch(env, case, prec):
         y = F.conv2d(x, wt, None, stride=stride, padding=pad) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)
         y = y + (rr if res == 1 else F.interpolate(rr, scale_factor=2.0, mode="nearest")[:, :, :ho, :wo])
         y = F.relu(y) if relu else y
+    # the residual is read in the OUTPUT dtype (ABI contract), so a bf16 residual means bf16 output
+    odt = torch.float32 if (prec == "f32" or residual is None) else torch.bfloat16
     out = eng.conv(nhwc(x).to(dev, eng.tdt), L, act=ACT_RELU if relu else ACT_NONE, residual=rdev,
-                   res_mode=(RES_NONE, RES_SAME, RES_UP2)[res], out_dtype=torch.float32)
-    got = out.cpu().permute(0, 3, 1, 2)
+                   res_mode=(RES_NONE, RES_SAME, RES_UP2)[res], out_dtype=odt)
+    got = out.float().cpu().permute(0, 3, 1, 2)
     tol = 2e-5 if prec == "f32" else 3e-2
     err = float((got - y).abs().max() / y.abs().max())
     assert err <= tol, err
