@@ -1,0 +1,595 @@
+// Per-instance contour extraction and morphometrics on bit-packed masks.
+//
+//   trace    cv2.findContours(mask, RETR_EXTERNAL, CHAIN_APPROX_SIMPLE)   inference.py:1164, 2605
+//            + cv2.contourArea (shoelace, exact integer) + cv2.arcLength (per-segment f32 sqrt,
+//            accumulated in double)                                        inference.py:1175, 2607; measurements.py:134-135
+//   measure  measurements.py:114-233: minAreaRect (convex hull + f32 rotating calipers) -> boxPoints
+//            -> int truncation -> imutils order_points -> mid-point distances; fitEllipse
+//            (algebraic least squares); the 12 derived values of the CSV row.
+//
+// Parallel decomposition (order/compare work, latency-bound): a border can only start at a pixel
+// whose west, north-west, north and north-east neighbours are background; every such pixel that also
+// has TRUE outside background to its west (not a hole of the filled mask) is traced by one lane with
+// Suzuki-Abe's 8-neighbour rule, and the trace is kept iff it never meets a pixel that precedes its
+// start in raster order -- i.e. iff the start is the component's first pixel, which is where OpenCV's
+// sequential raster scan starts the same border.  Pass A validates and reduces (area, perimeter,
+// point count), pass B writes the SIMPLE points at an atomically reserved offset.
+// Compiled with -ffp-contract=off: the f32 calipers follow OpenCV's operation order.
+#include "common.h"
+
+namespace {
+
+__constant__ int c_dx[8] = {1, 1, 0, -1, -1, -1, 0, 1};
+__constant__ int c_dy[8] = {0, -1, -1, -1, 0, 1, 1, 1};
+
+struct BitImg {
+    const uint32_t* p;
+    int H, W, wpr;
+    __device__ __forceinline__ int get(int x, int y) const {
+        if ((unsigned)x >= (unsigned)W || (unsigned)y >= (unsigned)H) return 0;
+        return (p[(long)y * wpr + (x >> 5)] >> (x & 31)) & 1u;
+    }
+};
+
+struct TraceResult {
+    int valid;
+    int npts;
+    long area2;      // signed shoelace sum
+    double perimeter;
+};
+
+template <bool EMIT>
+__device__ TraceResult trace_border(const BitImg& im, int sx, int sy, int* __restrict__ pts /* EMIT only */) {
+    TraceResult r;
+    r.valid = 1; r.npts = 0; r.area2 = 0; r.perimeter = 0.0;
+    int s = 4, s_end = 4;
+    int nx, ny;
+    do {
+        s = (s - 1) & 7;
+        nx = sx + c_dx[s]; ny = sy + c_dy[s];
+    } while (im.get(nx, ny) == 0 && s != s_end);
+    if (s == s_end) {  // single pixel
+        if (EMIT) { pts[0] = sx; pts[1] = sy; }
+        r.npts = 1;
+        return r;
+    }
+    const int i1x = nx, i1y = ny;
+    int x = sx, y = sy;
+    int prev_s = s ^ 4;
+    int fx = 0, fy = 0, lx = 0, ly = 0;  // first / last emitted point
+    const long max_steps = 4L * ((long)im.H * im.W + 4);
+    for (long step = 0; step < max_steps; ++step) {
+        s_end = s;
+        int qx, qy;
+        for (;;) {
+            ++s;
+            qx = x + c_dx[s & 7]; qy = y + c_dy[s & 7];
+            if (im.get(qx, qy)) break;
+        }
+        s &= 7;
+        if (s != prev_s) {
+            if (EMIT) { pts[2 * r.npts] = x; pts[2 * r.npts + 1] = y; }
+            if (r.npts == 0) { fx = x; fy = y; }
+            else {
+                const float ddx = (float)(x - lx), ddy = (float)(y - ly);
+                r.perimeter += (double)sqrtf(ddx * ddx + ddy * ddy);
+            }
+            lx = x; ly = y;
+            ++r.npts;
+            prev_s = s;
+        }
+        r.area2 += (long)x * qy - (long)y * qx;
+        if (qy < sy || (qy == sy && qx < sx)) { r.valid = 0; return r; }
+        const bool done = (qx == sx && qy == sy && x == i1x && y == i1y);
+        x = qx; y = qy;
+        if (done) break;
+        s = (s + 4) & 7;
+    }
+    if (r.npts > 1) {
+        const float ddx = (float)(fx - lx), ddy = (float)(fy - ly);
+        r.perimeter += (double)sqrtf(ddx * ddx + ddy * ddy);
+    }
+    return r;
+}
+
+constexpr int CAND_MAX = 4096;
+
+struct ContourP {
+    const uint32_t* masks;
+    const uint32_t* filled;
+    const int* bbox;
+    int M, H, W, C;          // C = max contours per mask
+    int max_points;
+    int* count;              // [M]
+    int* info;               // [M, C, 4] sx, sy, npts, offset
+    double* red;             // [M, C, 2] area, perimeter
+    int* points;             // [max_points, 2]
+    int* counters;           // [0] = points used, [1] = error flags
+};
+
+__global__ __launch_bounds__(256) void contour_trace_kernel(const ContourP p) {
+    __shared__ int cand[CAND_MAX];
+    __shared__ int ncand, ncont;
+    const int m = blockIdx.x, tid = threadIdx.x;
+    const int wpr = p.W >> 5;
+    BitImg im{p.masks + (long)m * p.H * wpr, p.H, p.W, wpr};
+    const uint32_t* fl = p.filled + (long)m * p.H * wpr;
+    const int y0 = p.bbox[m * 4 + 0], x0 = p.bbox[m * 4 + 1], y1 = p.bbox[m * 4 + 2], x1 = p.bbox[m * 4 + 3];
+    if (tid == 0) { ncand = 0; ncont = 0; }
+    __syncthreads();
+    if (y0 >= 0) {
+        const int wx0 = x0 >> 5, rw = (x1 >> 5) - wx0 + 1, rh = y1 - y0 + 1;
+        for (int i = tid; i < rh * rw; i += blockDim.x) {
+            const int y = y0 + i / rw, wx = wx0 + i % rw;
+            const long o = (long)y * wpr + wx;
+            const uint32_t mm = im.p[o];
+            if (!mm) continue;
+            const uint32_t ml = (mm << 1) | (wx > 0 ? im.p[o - 1] >> 31 : 0u);
+            const uint32_t f = fl[o];
+            const uint32_t fleft = (f << 1) | (wx > 0 ? fl[o - 1] >> 31 : 0u);
+            uint32_t u = 0u, ul = 0u, ur = 0u;
+            if (y > 0) {
+                u = im.p[o - wpr];
+                ul = (u << 1) | (wx > 0 ? im.p[o - wpr - 1] >> 31 : 0u);
+                ur = (u >> 1) | (wx < wpr - 1 ? im.p[o - wpr + 1] << 31 : 0u);
+            }
+            uint32_t c = mm & ~ml & ~fleft & ~u & ~ul & ~ur;
+            while (c) {
+                const int b = __ffs((int)c) - 1;
+                c &= c - 1u;
+                const int slot = atomicAdd(&ncand, 1);
+                if (slot < CAND_MAX) cand[slot] = y * p.W + wx * 32 + b;
+            }
+        }
+    }
+    __syncthreads();
+    if (ncand > CAND_MAX) {
+        if (tid == 0) { atomicOr(&p.counters[1], 1); p.count[m] = 0; }
+        return;
+    }
+    for (int c = tid; c < ncand; c += blockDim.x) {
+        const int sy = cand[c] / p.W, sx = cand[c] - sy * p.W;
+        const TraceResult r = trace_border<false>(im, sx, sy, nullptr);
+        if (!r.valid) continue;
+        const int slot = atomicAdd(&ncont, 1);
+        if (slot >= p.C) { atomicOr(&p.counters[1], 2); continue; }
+        const int off = atomicAdd(&p.counters[0], r.npts);
+        int* inf = p.info + ((long)m * p.C + slot) * 4;
+        inf[0] = sx; inf[1] = sy; inf[2] = r.npts; inf[3] = off;
+        double* rd = p.red + ((long)m * p.C + slot) * 2;
+        rd[0] = (double)(r.area2 < 0 ? -r.area2 : r.area2) * 0.5;
+        rd[1] = r.perimeter;
+        if (off + r.npts > p.max_points) { atomicOr(&p.counters[1], 4); inf[2] = 0; continue; }
+        trace_border<true>(im, sx, sy, p.points + 2L * off);
+    }
+    __syncthreads();
+    if (tid == 0) p.count[m] = ncont < p.C ? ncont : p.C;
+}
+
+// =============================================================================================
+// measurements: one thread per contour
+// =============================================================================================
+struct Pt { int x, y; };
+
+__device__ __forceinline__ bool pt_less(const int* pts, int a, int b) {
+    const int ax = pts[2 * a], ay = pts[2 * a + 1], bx = pts[2 * b], by = pts[2 * b + 1];
+    if (ax != bx) return ax < bx;
+    if (ay != by) return ay < by;
+    return a < b;
+}
+
+__device__ void heapsort_idx(const int* pts, int* idx, int n) {
+    for (int i = 0; i < n; ++i) idx[i] = i;
+    auto sift = [&](int start, int end) {
+        int root = start;
+        for (;;) {
+            int child = 2 * root + 1;
+            if (child > end) break;
+            if (child + 1 <= end && pt_less(pts, idx[child], idx[child + 1])) ++child;
+            if (pt_less(pts, idx[root], idx[child])) { const int t = idx[root]; idx[root] = idx[child]; idx[child] = t; root = child; }
+            else break;
+        }
+    };
+    for (int s = (n - 2) / 2; s >= 0; --s) sift(s, n - 1);
+    for (int e = n - 1; e > 0; --e) {
+        const int t = idx[e]; idx[e] = idx[0]; idx[0] = t;
+        sift(0, e - 1);
+    }
+}
+
+__device__ __forceinline__ int sgn(long v) { return (v > 0) - (v < 0); }
+
+// cv::Sklansky_ on the sorted order; writes the stack, returns its size
+__device__ int sklansky(const int* pts, const int* order, int start, int end, int* stack, int nsign, int sign2) {
+    const int incr = end > start ? 1 : -1;
+    int pprev = start, pcur = pprev + incr, pnext = pcur + incr;
+    int size = 3;
+#define PX(i) pts[2 * order[i]]
+#define PY(i) pts[2 * order[i] + 1]
+    if (start == end || (PX(start) == PX(end) && PY(start) == PY(end))) { stack[0] = start; return 1; }
+    stack[0] = pprev; stack[1] = pcur; stack[2] = pnext;
+    end += incr;
+    while (pnext != end) {
+        const int cury = PY(pcur), nexty = PY(pnext);
+        const int by = nexty - cury;
+        if (sgn(by) != nsign) {
+            const int ax = PX(pcur) - PX(pprev), bx = PX(pnext) - PX(pcur), ay = cury - PY(pprev);
+            const long conv = (long)ay * bx - (long)ax * by;
+            if (sgn(conv) == sign2 && (ax != 0 || ay != 0)) {
+                pprev = pcur; pcur = pnext; pnext += incr;
+                stack[size++] = pnext;
+            } else if (pprev == start) {
+                pcur = pnext; stack[1] = pcur; pnext += incr; stack[2] = pnext;
+            } else {
+                stack[size - 2] = pnext; pcur = pprev; pprev = stack[size - 4]; --size;
+            }
+        } else {
+            pnext += incr;
+            stack[size - 1] = pnext;
+        }
+    }
+#undef PX
+#undef PY
+    return --size;
+}
+
+// cv::convexHull(points, clockwise=false) -> indices into pts; returns count.  work: 3*n+4 ints
+__device__ int convex_hull_idx(const int* pts, int n, int* order, int* stack, int* hull) {
+    heapsort_idx(pts, order, n);
+    int miny = 0, maxy = 0;
+    for (int i = 1; i < n; ++i) {
+        const int y = pts[2 * order[i] + 1];
+        if (pts[2 * order[miny] + 1] > y) miny = i;
+        if (pts[2 * order[maxy] + 1] < y) maxy = i;
+    }
+    int nout = 0;
+    if (pts[2 * order[0]] == pts[2 * order[n - 1]] && pts[2 * order[0] + 1] == pts[2 * order[n - 1] + 1]) {
+        hull[nout++] = order[0];
+        return nout;
+    }
+    int* tl = stack;
+    int tlc = sklansky(pts, order, 0, maxy, tl, -1, 1);
+    int* tr = stack + tlc;
+    int trc = sklansky(pts, order, n - 1, maxy, tr, -1, -1);
+    { int* t = tl; tl = tr; tr = t; const int c = tlc; tlc = trc; trc = c; }  // !clockwise
+    for (int i = 0; i < tlc - 1; ++i) hull[nout++] = order[tl[i]];
+    for (int i = trc - 1; i > 0; --i) hull[nout++] = order[tr[i]];
+    const int stop_idx = trc > 2 ? tr[1] : (tlc > 2 ? tl[tlc - 2] : -1);
+    // the stacks are reused below, but stop_idx is a position in `order`, still valid
+    int* bl = stack;
+    int blc = sklansky(pts, order, 0, miny, bl, 1, -1);
+    int* br = stack + blc;
+    int brc = sklansky(pts, order, n - 1, miny, br, 1, 1);
+    if (stop_idx >= 0) {
+        const int check_idx = blc > 2 ? bl[1] : (blc + brc > 2 ? br[2 - blc] : -1);
+        if (check_idx == stop_idx || (check_idx >= 0 && pts[2 * order[check_idx]] == pts[2 * order[stop_idx]] &&
+                                      pts[2 * order[check_idx] + 1] == pts[2 * order[stop_idx] + 1])) {
+            blc = blc < 2 ? blc : 2;
+            brc = brc < 2 ? brc : 2;
+        }
+    }
+    for (int i = 0; i < blc - 1; ++i) hull[nout++] = order[bl[i]];
+    for (int i = brc - 1; i > 0; --i) hull[nout++] = order[br[i]];
+    if (nout >= 3) {
+        int min_i = 0, max_i = 0, lt = 0;
+        for (int i = 1; i < nout; ++i) {
+            const int v = hull[i];
+            lt += hull[i - 1] < v;
+            if (lt > 1 && lt <= i - 2) break;
+            if (v < hull[min_i]) min_i = i;
+            if (v > hull[max_i]) max_i = i;
+        }
+        const int mm = max_i > min_i ? max_i - min_i : min_i - max_i;
+        if ((mm == 1 || mm == nout - 1) && (lt <= 1 || lt >= nout - 2)) {
+            const int ascending = (max_i + 1) % nout == min_i;
+            const int i0 = ascending ? min_i : max_i;
+            if (i0 > 0) {
+                int j = i0, i = 0;
+                for (; i < nout; ++i) {
+                    const int cur = stack[i] = hull[j];
+                    const int nj = j + 1 < nout ? j + 1 : 0;
+                    if (i < nout - 1 && (ascending != (cur < hull[nj]))) break;
+                    j = nj;
+                }
+                if (i == nout) for (int q = 0; q < nout; ++q) hull[q] = stack[q];
+            }
+        }
+    }
+    return nout;
+}
+
+// cv::rotatingCalipers(..., CALIPERS_MINAREARECT), float32; hp = hull points (float x, y), work floats: 3*n
+__device__ void rotating_calipers(const float* hp, int n, float* vect, float* inv_len, float out[6]) {
+    int left = 0, bottom = 0, right = 0, top = 0;
+    float p0x = hp[0], p0y = hp[1];
+    float left_x = p0x, right_x = p0x, top_y = p0y, bottom_y = p0y;
+    for (int i = 0; i < n; ++i) {
+        if (p0x < left_x) { left_x = p0x; left = i; }
+        if (p0x > right_x) { right_x = p0x; right = i; }
+        if (p0y > top_y) { top_y = p0y; top = i; }
+        if (p0y < bottom_y) { bottom_y = p0y; bottom = i; }
+        const int nx = (i + 1 < n) ? i + 1 : 0;
+        const float qx = hp[2 * nx], qy = hp[2 * nx + 1];
+        const double dx = (double)qx - (double)p0x, dy = (double)qy - (double)p0y;
+        vect[2 * i] = (float)dx; vect[2 * i + 1] = (float)dy;
+        inv_len[i] = (float)(1.0 / sqrt(dx * dx + dy * dy));
+        p0x = qx; p0y = qy;
+    }
+    float orientation = 0.f;
+    {
+        double ax = vect[2 * (n - 1)], ay = vect[2 * (n - 1) + 1];
+        for (int i = 0; i < n; ++i) {
+            const double bx = vect[2 * i], by = vect[2 * i + 1];
+            const double conv = ax * by - ay * bx;
+            if (conv != 0) { orientation = conv > 0 ? 1.f : -1.f; break; }
+            ax = bx; ay = by;
+        }
+    }
+    float base_a = orientation, base_b = 0.f;
+    int seq[4] = {bottom, right, top, left};
+    float minarea = 3.402823466e+38f;
+    int b_left = 0, b_bottom = 0;
+    float b_a = 0.f, b_w = 0.f, b_b = 0.f, b_h = 0.f;
+    for (int k = 0; k < n; ++k) {
+        float dp[4];
+        dp[0] = +base_a * vect[2 * seq[0]] + base_b * vect[2 * seq[0] + 1];
+        dp[1] = -base_b * vect[2 * seq[1]] + base_a * vect[2 * seq[1] + 1];
+        dp[2] = -base_a * vect[2 * seq[2]] - base_b * vect[2 * seq[2] + 1];
+        dp[3] = +base_b * vect[2 * seq[3]] - base_a * vect[2 * seq[3] + 1];
+        float maxcos = dp[0] * inv_len[seq[0]];
+        int main_e = 0;
+        for (int i = 1; i < 4; ++i) {
+            const float c = dp[i] * inv_len[seq[i]];
+            if (c > maxcos) { main_e = i; maxcos = c; }
+        }
+        {
+            const int pi = seq[main_e];
+            const float lead_x = vect[2 * pi] * inv_len[pi], lead_y = vect[2 * pi + 1] * inv_len[pi];
+            if (main_e == 0) { base_a = lead_x; base_b = lead_y; }
+            else if (main_e == 1) { base_a = lead_y; base_b = -lead_x; }
+            else if (main_e == 2) { base_a = -lead_x; base_b = -lead_y; }
+            else { base_a = -lead_y; base_b = lead_x; }
+        }
+        seq[main_e] = (seq[main_e] + 1 == n) ? 0 : seq[main_e] + 1;
+        float dx = hp[2 * seq[1]] - hp[2 * seq[3]], dy = hp[2 * seq[1] + 1] - hp[2 * seq[3] + 1];
+        const float width = dx * base_a + dy * base_b;
+        dx = hp[2 * seq[2]] - hp[2 * seq[0]]; dy = hp[2 * seq[2] + 1] - hp[2 * seq[0] + 1];
+        const float height = -dx * base_b + dy * base_a;
+        const float area = width * height;
+        if (area <= minarea) {
+            minarea = area; b_left = seq[3]; b_a = base_a; b_w = width; b_b = base_b; b_h = height; b_bottom = seq[0];
+        }
+    }
+    const float A1 = b_a, B1 = b_b, A2 = -b_b, B2 = b_a;
+    const float C1 = A1 * hp[2 * b_left] + hp[2 * b_left + 1] * B1;
+    const float C2 = A2 * hp[2 * b_bottom] + hp[2 * b_bottom + 1] * B2;
+    const float idet = 1.f / (A1 * B2 - A2 * B1);
+    out[0] = (C1 * B2 - C2 * B1) * idet;
+    out[1] = (A1 * C2 - A2 * C1) * idet;
+    out[2] = A1 * b_w; out[3] = B1 * b_w;
+    out[4] = A2 * b_h; out[5] = B2 * b_h;
+}
+
+// dense symmetric solve by Gaussian elimination with partial pivoting; returns min/max |pivot| ratio
+template <int N>
+__device__ double solve_n(double a[N][N], double b[N], double x[N]) {
+    double pmin = 1e300, pmax = 0;
+    int perm[N];
+    for (int i = 0; i < N; ++i) perm[i] = i;
+    for (int c = 0; c < N; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < N; ++r) if (fabs(a[r][c]) > fabs(a[piv][c])) piv = r;
+        if (piv != c) {
+            for (int k = 0; k < N; ++k) { const double t = a[c][k]; a[c][k] = a[piv][k]; a[piv][k] = t; }
+            const double t = b[c]; b[c] = b[piv]; b[piv] = t;
+        }
+        const double d = a[c][c];
+        pmin = fmin(pmin, fabs(d)); pmax = fmax(pmax, fabs(d));
+        if (d == 0) continue;
+        for (int r = c + 1; r < N; ++r) {
+            const double f = a[r][c] / d;
+            for (int k = c; k < N; ++k) a[r][k] -= f * a[c][k];
+            b[r] -= f * b[c];
+        }
+    }
+    for (int r = N - 1; r >= 0; --r) {
+        double s = b[r];
+        for (int k = r + 1; k < N; ++k) s -= a[r][k] * x[k];
+        x[r] = a[r][r] != 0 ? s / a[r][r] : 0.0;
+    }
+    return pmax > 0 ? pmin / pmax : 0.0;
+}
+
+// cv::fitEllipse (fitEllipseNoDirect): returns width <= height
+__device__ void fit_ellipse(const int* pts, int n, float* bw, float* bh) {
+    float csx = 0.f, csy = 0.f;
+    for (int i = 0; i < n; ++i) { csx += (float)pts[2 * i]; csy += (float)pts[2 * i + 1]; }
+    const float cx = csx / (float)n, cy = csy / (float)n;
+    double s = 0;
+    for (int i = 0; i < n; ++i) s += fabs((double)((float)pts[2 * i] - cx)) + fabs((double)((float)pts[2 * i + 1] - cy));
+    const double eps32 = 1.1920928955078125e-07;
+    const double scale = 100.0 / (s > eps32 ? s : eps32);
+    double gfp[5];
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const float eps = attempt ? (float)(s / (n * 2) * 1e-3) : 0.f;
+        double ata[5][5] = {}, atb[5] = {};
+        for (int i = 0; i < n; ++i) {
+            float fxp = (float)pts[2 * i], fyp = (float)pts[2 * i + 1];
+            if (attempt) { fxp = fxp + (float)(((i & 1) * 2 - 1)) * eps; fyp = fyp + (float)((i & 2) - 1) * eps; }
+            const double px = (double)(fxp - cx) * scale, py = (double)(fyp - cy) * scale;
+            const double row[5] = {-px * px, -py * py, -px * py, px, py};
+            for (int a = 0; a < 5; ++a) {
+                atb[a] += row[a] * 10000.0;
+                for (int b = 0; b < 5; ++b) ata[a][b] += row[a] * row[b];
+            }
+        }
+        const double ratio = solve_n<5>(ata, atb, gfp);
+        // cv: if (w[0] * FLT_EPSILON > w[4]) perturb and refit; pivots of A^T A ~ singular values squared
+        if (attempt == 1 || !(ratio < eps32 * eps32)) {
+            // second pass keeps the perturbed points for the re-fit below
+            double rp[5];
+            double m2[2][2] = {{2 * gfp[0], gfp[2]}, {gfp[2], 2 * gfp[1]}}, b2[2] = {gfp[3], gfp[4]}, c2[2];
+            solve_n<2>(m2, b2, c2);
+            rp[0] = c2[0]; rp[1] = c2[1];
+            double a3[3][3] = {}, b3[3] = {}, g[3];
+            for (int i = 0; i < n; ++i) {
+                float fxp = (float)pts[2 * i], fyp = (float)pts[2 * i + 1];
+                if (attempt) { fxp = fxp + (float)(((i & 1) * 2 - 1)) * eps; fyp = fyp + (float)((i & 2) - 1) * eps; }
+                const double px = (double)(fxp - cx) * scale, py = (double)(fyp - cy) * scale;
+                const double row[3] = {(px - rp[0]) * (px - rp[0]), (py - rp[1]) * (py - rp[1]), (px - rp[0]) * (py - rp[1])};
+                for (int a = 0; a < 3; ++a) {
+                    b3[a] += row[a];
+                    for (int b = 0; b < 3; ++b) a3[a][b] += row[a] * row[b];
+                }
+            }
+            solve_n<3>(a3, b3, g);
+            rp[4] = -0.5 * atan2(g[2], g[1] - g[0]);
+            double t;
+            if (fabs(g[2]) > 1e-8) t = g[2] / sin(-2.0 * rp[4]);
+            else t = g[1] - g[0];
+            rp[2] = fabs(g[0] + g[1] - t);
+            if (rp[2] > 1e-8) rp[2] = sqrt(2.0 / rp[2]);
+            rp[3] = fabs(g[0] + g[1] + t);
+            if (rp[3] > 1e-8) rp[3] = sqrt(2.0 / rp[3]);
+            float w = (float)(rp[2] * 2 / scale), h = (float)(rp[3] * 2 / scale);
+            if (w > h) { const float tt = w; w = h; h = tt; }
+            *bw = w; *bh = h;
+            return;
+        }
+    }
+}
+
+struct MeasureP {
+    const int* count;     // [M]
+    const int* info;      // [M, C, 4]
+    const double* red;    // [M, C, 2]
+    const int* points;
+    int M, C, max_points;
+    int* work_i;          // [4 * max_points + 8 * M * C]
+    float* work_f;        // [5 * max_points + 16 * M * C]
+    double um_pix;
+    double* out;          // [M, C, 12]
+};
+
+__global__ void contour_measure_kernel(const MeasureP p) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= p.M * p.C) return;
+    const int m = t / p.C, c = t - m * p.C;
+    if (c >= p.count[m]) return;
+    const int* inf = p.info + (long)t * 4;
+    const int n = inf[2], off = inf[3];
+    double* o = p.out + (long)t * 12;
+    const double area = p.red[2 * t], perimeter = p.red[2 * t + 1];
+    const int* pts = p.points + 2L * off;
+    // scratch carved per contour by its point offset (each contour owns [off, off+n) of every pool)
+    int* order = p.work_i + off + 0L * p.max_points + 2L * t;
+    int* stack = p.work_i + 2L * off + 1L * p.max_points + 2L * p.M * p.C + 4L * t;   // up to 2n + 4
+    int* hull = p.work_i + off + 3L * p.max_points + 6L * p.M * p.C + 2L * t;
+    float* hp = p.work_f + 2L * off + 4L * t;
+    float* vect = p.work_f + 2L * off + 2L * p.max_points + 4L * p.M * p.C + 4L * t;
+    float* inv_len = p.work_f + off + 4L * p.max_points + 8L * p.M * p.C + 2L * t;
+
+    // ---- minAreaRect -> boxPoints -> int -> order_points -> dA, dB -------------------------------
+    float rcx = 0.f, rcy = 0.f, rw = 0.f, rh = 0.f, rang = 0.f;
+    int hn = 0;
+    if (n > 0) {
+        hn = convex_hull_idx(pts, n, order, stack, hull);
+        for (int i = 0; i < hn; ++i) { hp[2 * i] = (float)pts[2 * hull[i]]; hp[2 * i + 1] = (float)pts[2 * hull[i] + 1]; }
+    }
+    if (hn > 2) {
+        float q[6];
+        rotating_calipers(hp, hn, vect, inv_len, q);
+        rcx = q[0] + (q[2] + q[4]) * 0.5f;
+        rcy = q[1] + (q[3] + q[5]) * 0.5f;
+        rw = (float)sqrt((double)q[2] * q[2] + (double)q[3] * q[3]);
+        rh = (float)sqrt((double)q[4] * q[4] + (double)q[5] * q[5]);
+        rang = (float)atan2((double)q[3], (double)q[2]);
+    } else if (hn == 2) {
+        rcx = (hp[0] + hp[2]) * 0.5f; rcy = (hp[1] + hp[3]) * 0.5f;
+        const double dx = (double)hp[2] - (double)hp[0], dy = (double)hp[3] - (double)hp[1];
+        rw = (float)sqrt(dx * dx + dy * dy); rh = 0.f;
+        rang = (float)atan2(dy, dx);
+    } else if (hn == 1) { rcx = hp[0]; rcy = hp[1]; }
+    rang = (float)((double)rang * 180.0 / 3.141592653589793238462643383279502884);
+    // RotatedRect::points
+    const double ar = (double)rang * 3.141592653589793238462643383279502884 / 180.0;
+    const float b = (float)cos(ar) * 0.5f, a = (float)sin(ar) * 0.5f;
+    float bx[4], by[4];
+    bx[0] = rcx - a * rh - b * rw; by[0] = rcy + b * rh - a * rw;
+    bx[1] = rcx + a * rh - b * rw; by[1] = rcy - b * rh - a * rw;
+    bx[2] = 2.f * rcx - bx[0];     by[2] = 2.f * rcy - by[0];
+    bx[3] = 2.f * rcx - bx[1];     by[3] = 2.f * rcy - by[1];
+    int ix[4], iy[4];
+    for (int i = 0; i < 4; ++i) { ix[i] = (int)bx[i]; iy[i] = (int)by[i]; }  // np.array(box, dtype="int") truncates
+    // imutils.perspective.order_points: argsort by x (numpy quicksort on 4 items == insertion sort, stable)
+    int ord[4] = {0, 1, 2, 3};
+    for (int i = 1; i < 4; ++i) { int j = i; while (j > 0 && ix[ord[j]] < ix[ord[j - 1]]) { const int tt = ord[j]; ord[j] = ord[j - 1]; ord[j - 1] = tt; --j; } }
+    int l0 = ord[0], l1 = ord[1], r0 = ord[2], r1 = ord[3];
+    if (iy[l1] < iy[l0]) { const int tt = l0; l0 = l1; l1 = tt; }     // stable: swap only when strictly smaller
+    const int tl = l0, bl = l1;
+    const double d0 = sqrt((double)(ix[r0] - ix[tl]) * (ix[r0] - ix[tl]) + (double)(iy[r0] - iy[tl]) * (iy[r0] - iy[tl]));
+    const double d1 = sqrt((double)(ix[r1] - ix[tl]) * (ix[r1] - ix[tl]) + (double)(iy[r1] - iy[tl]) * (iy[r1] - iy[tl]));
+    // np.argsort(D)[::-1]: ascending stable then reversed -> on ties the later index comes first
+    int br, tr;
+    if (d1 >= d0) { br = r1; tr = r0; } else { br = r0; tr = r1; }
+    const double tltrx = (ix[tl] + ix[tr]) * 0.5, tltry = (iy[tl] + iy[tr]) * 0.5;
+    const double blbrx = (ix[bl] + ix[br]) * 0.5, blbry = (iy[bl] + iy[br]) * 0.5;
+    const double tlblx = (ix[tl] + ix[bl]) * 0.5, tlbly = (iy[tl] + iy[bl]) * 0.5;
+    const double trbrx = (ix[tr] + ix[br]) * 0.5, trbry = (iy[tr] + iy[br]) * 0.5;
+    const double dA = sqrt((tltrx - blbrx) * (tltrx - blbrx) + (tltry - blbry) * (tltry - blbry));
+    const double dB = sqrt((tlblx - trbrx) * (tlblx - trbrx) + (tlbly - trbry) * (tlbly - trbry));
+    const double um = p.um_pix;
+    const double PI = 3.141592653589793;
+    const double dmax = fmax(dA, dB), dmin = fmin(dA, dB);
+    const double aspect = (dA != 0 && dB != 0) ? dmax / dmin : 0.0;
+    double maj = 0, mnr = 0, ecc = 0;
+    if (n >= 5) {
+        float w, h;
+        fit_ellipse(pts, n, &w, &h);
+        maj = (double)w; mnr = (double)h;
+        const double ea = (maj > mnr ? maj : mnr) / 2.0, eb = (maj > mnr ? mnr : maj) / 2.0;
+        ecc = ea != 0 ? sqrt(1.0 - (eb * eb) / (ea * ea)) : 0.0;
+    }
+    o[0] = maj * um;                                   // major_axis_length
+    o[1] = mnr * um;                                   // minor_axis_length
+    o[2] = ecc;                                        // eccentricity
+    o[3] = dmin * um;                                  // Length
+    o[4] = dmax * um;                                  // Width
+    o[5] = sqrt(4 * area / PI) * um;                   // CircularED
+    o[6] = aspect;                                     // Aspect_Ratio
+    o[7] = perimeter != 0 ? 4 * PI * (area / (perimeter * perimeter)) * um : 0.0;  // Circularity
+    o[8] = perimeter * um;                             // Chords
+    o[9] = dmax * um;                                  // Feret_diam
+    o[10] = aspect != 0 ? 1.0 / aspect : 0.0;          // Roundness
+    o[11] = perimeter != 0 ? (2 * sqrt(PI * area)) / perimeter * um : 0.0;        // Sphericity
+}
+
+}  // namespace
+
+extern "C" int64_t demia_contour_work_ints(int M, int C, int max_points) { return 4L * max_points + 8L * M * C + 16; }
+extern "C" int64_t demia_contour_work_floats(int M, int C, int max_points) { return 5L * max_points + 16L * M * C + 16; }
+
+extern "C" int demia_mask_contours(const uint32_t* masks, const uint32_t* filled, const int32_t* bbox, int M, int H, int W, int C,
+                                   int max_points, int32_t* count, int32_t* info, double* red, int32_t* points,
+                                   int32_t* counters, void* stream) {
+    DEMIA_REQUIRE(masks && filled && bbox && count && info && red && points && counters && W % 32 == 0, "args");
+    DEMIA_REQUIRE((long)H * W < (1L << 31) && C > 0 && max_points > 0, "sizes");
+    if (M == 0) return DEMIA_OK;
+    hipError_t e = hipMemsetAsync(counters, 0, 2 * sizeof(int32_t), (hipStream_t)stream);
+    if (e != hipSuccess) { demia_set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return DEMIA_ELAUNCH; }
+    ContourP p{masks, filled, bbox, M, H, W, C, max_points, count, info, red, points, counters};
+    hipLaunchKernelGGL(contour_trace_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, p);
+    DEMIA_CHECK_LAUNCH("contour_trace_kernel");
+    return DEMIA_OK;
+}
+
+extern "C" int demia_contour_measure(const int32_t* count, const int32_t* info, const double* red, const int32_t* points, int M,
+                                     int C, int max_points, int32_t* work_i, float* work_f, double um_pix, double* out,
+                                     void* stream) {
+    DEMIA_REQUIRE(count && info && red && points && work_i && work_f && out, "args");
+    if (M * C == 0) return DEMIA_OK;
+    MeasureP p{count, info, red, points, M, C, max_points, work_i, work_f, um_pix, out};
+    hipLaunchKernelGGL(contour_measure_kernel, dim3(cdiv((long)M * C, 64)), dim3(64), 0, (hipStream_t)stream, p);
+    DEMIA_CHECK_LAUNCH("contour_measure_kernel");
+    return DEMIA_OK;
+}

@@ -1,0 +1,175 @@
+"""Device-resident sets of bit-packed instance masks and the HIP operations on them.
+
+Everything the reference does with dense ``(H, W)`` numpy masks after ``predictor(image)``
+(hole filling, cross erosion / dilation, overlap removal, connected-component test, pair
+intersection counts, tile placement, contour tracing and the measurement reductions) runs here on
+``[M, H, W/32]`` int32 tensors through the C ABI.  Only small tables (areas, boxes, pair counts,
+contour points, measurement rows) ever reach the host.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+class MaskOps:
+    """Thin, stateless wrapper of the packed-mask entry points for one device."""
+
+    def __init__(self, device: str = "cuda:0"):
+        if not torch.cuda.is_available():
+            raise _lib.HipExtensionMissing("no HIP device visible: packed-mask ops have no CPU fallback")
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+
+    def _stream(self) -> int:
+        return int(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # -- construction -------------------------------------------------------------------------
+    def from_dense(self, masks: np.ndarray) -> torch.Tensor:
+        """(M, H, W) bool/uint8 host array -> packed device tensor (test / interop helper)."""
+        m = np.ascontiguousarray(masks != 0)
+        M, H, W = m.shape
+        if W % 32:
+            raise ValueError("width must be a multiple of 32")
+        packed = np.packbits(m.reshape(M, H, W // 32, 32), axis=-1, bitorder="little").view(np.uint32)
+        return torch.from_numpy(packed.reshape(M, H, W // 32).view(np.int32)).to(self.device)
+
+    def to_dense(self, packed: torch.Tensor, W: int) -> np.ndarray:
+        M, H, wpr = packed.shape
+        out = torch.empty((M, H, W), dtype=torch.bool, device=self.device)
+        _lib.check(self.lib.demia_unpack_masks(_lib.ptr(packed), _lib.ptr(out), M, H, W, self._stream()), "demia_unpack_masks")
+        return out.cpu().numpy()
+
+    # -- reductions -----------------------------------------------------------------------------
+    def area_bbox(self, packed: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        M, H, wpr = packed.shape
+        area = torch.empty((M,), dtype=torch.int32, device=self.device)
+        bbox = torch.empty((M, 4), dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.demia_mask_area_bbox(_lib.ptr(packed), _lib.ptr(area), _lib.ptr(bbox), M, H, wpr * 32,
+                                                 self._stream()), "demia_mask_area_bbox")
+        return area, bbox
+
+    def column_counts(self, packed: torch.Tensor) -> torch.Tensor:
+        M, H, wpr = packed.shape
+        counts = torch.zeros((wpr * 32,), dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.demia_mask_column_counts(_lib.ptr(packed), M, H, wpr * 32, _lib.ptr(counts), self._stream()),
+                   "demia_mask_column_counts")
+        return counts
+
+    def pair_intersections(self, a: torch.Tensor, b: torch.Tensor, bbox_a: torch.Tensor, bbox_b: torch.Tensor,
+                           pi: np.ndarray, pj: np.ndarray) -> np.ndarray:
+        P = len(pi)
+        if P == 0:
+            return np.zeros((0,), dtype=np.int64)
+        _, H, wpr = a.shape
+        ti = torch.from_numpy(np.ascontiguousarray(pi, dtype=np.int32)).to(self.device)
+        tj = torch.from_numpy(np.ascontiguousarray(pj, dtype=np.int32)).to(self.device)
+        out = torch.empty((P,), dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.demia_mask_pair_intersections(_lib.ptr(a), _lib.ptr(b), _lib.ptr(ti), _lib.ptr(tj), _lib.ptr(bbox_a),
+                                                          _lib.ptr(bbox_b), _lib.ptr(out), P, H, wpr * 32, self._stream()),
+                   "demia_mask_pair_intersections")
+        return out.cpu().numpy().astype(np.int64)
+
+    # -- morphology -----------------------------------------------------------------------------
+    def fill_holes(self, packed: torch.Tensor, bbox: Optional[torch.Tensor] = None) -> torch.Tensor:
+        M, H, wpr = packed.shape
+        if bbox is None:
+            _, bbox = self.area_bbox(packed)
+        out = torch.empty_like(packed)
+        _lib.check(self.lib.demia_mask_fill_holes(_lib.ptr(packed), _lib.ptr(out), _lib.ptr(bbox), M, H, wpr * 32, self._stream()),
+                   "demia_mask_fill_holes")
+        return out
+
+    def _morph(self, packed: torch.Tensor, dilate: int) -> torch.Tensor:
+        M, H, wpr = packed.shape
+        out = torch.empty_like(packed)
+        _lib.check(self.lib.demia_mask_morph_cross(_lib.ptr(packed), _lib.ptr(out), M, H, wpr * 32, dilate, self._stream()),
+                   "demia_mask_morph_cross")
+        return out
+
+    def erode(self, packed: torch.Tensor) -> torch.Tensor:
+        return self._morph(packed, 0)
+
+    def dilate(self, packed: torch.Tensor) -> torch.Tensor:
+        return self._morph(packed, 1)
+
+    def overlap_prefix_(self, packed: torch.Tensor) -> torch.Tensor:
+        M, H, wpr = packed.shape
+        _lib.check(self.lib.demia_mask_overlap_prefix(_lib.ptr(packed), M, H, wpr * 32, self._stream()), "demia_mask_overlap_prefix")
+        return packed
+
+    def components_gt1(self, packed: torch.Tensor, bbox: Optional[torch.Tensor] = None) -> torch.Tensor:
+        M, H, wpr = packed.shape
+        if bbox is None:
+            _, bbox = self.area_bbox(packed)
+        scratch = torch.empty_like(packed)
+        flag = torch.empty((M,), dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.demia_mask_components_gt1(_lib.ptr(packed), _lib.ptr(scratch), _lib.ptr(bbox), _lib.ptr(flag), M, H,
+                                                      wpr * 32, self._stream()), "demia_mask_components_gt1")
+        return flag
+
+    def place_tiles(self, src: torch.Tensor, x_off: Sequence[int], y_off: Sequence[int], tile_h: int, tile_w: int,
+                    H: int, W: int) -> torch.Tensor:
+        T, sh, swpr = src.shape
+        dst = torch.empty((T, H, W // 32), dtype=torch.int32, device=self.device)
+        xo = torch.tensor(list(x_off), dtype=torch.int32, device=self.device)
+        yo = torch.tensor(list(y_off), dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.demia_mask_place_tiles(_lib.ptr(src), _lib.ptr(dst), _lib.ptr(xo), _lib.ptr(yo), T, sh, swpr * 32,
+                                                   tile_h, tile_w, H, W, self._stream()), "demia_mask_place_tiles")
+        return dst
+
+    # -- contours + measurements ----------------------------------------------------------------
+    def contours(self, packed: torch.Tensor, max_contours: int = 64, max_points: Optional[int] = None,
+                 um_pix: float = 1.0, measure: bool = True):
+        """Per mask: external contours in OpenCV's order, with area, perimeter and the 12 measurement
+        values.  Returns a list (per mask) of lists of dicts with keys ``points`` (P, 2) int32,
+        ``area``, ``perimeter`` and (if ``measure``) ``values`` (12,) float64."""
+        M, H, wpr = packed.shape
+        W = wpr * 32
+        if M == 0:
+            return []
+        area, bbox = self.area_bbox(packed)
+        filled = self.fill_holes(packed, bbox)
+        if max_points is None:
+            max_points = int(min(max(4 * int(area.sum().item()) // 8 + 4096 * M, 1 << 16), 1 << 26))
+        C = max_contours
+        count = torch.zeros((M,), dtype=torch.int32, device=self.device)
+        info = torch.zeros((M, C, 4), dtype=torch.int32, device=self.device)
+        red = torch.zeros((M, C, 2), dtype=torch.float64, device=self.device)
+        points = torch.empty((max_points, 2), dtype=torch.int32, device=self.device)
+        counters = torch.zeros((2,), dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.demia_mask_contours(_lib.ptr(packed), _lib.ptr(filled), _lib.ptr(bbox), M, H, W, C, max_points,
+                                                _lib.ptr(count), _lib.ptr(info), _lib.ptr(red), _lib.ptr(points),
+                                                _lib.ptr(counters), self._stream()), "demia_mask_contours")
+        vals = None
+        if measure:
+            wi = torch.empty((int(self.lib.demia_contour_work_ints(M, C, max_points)),), dtype=torch.int32, device=self.device)
+            wf = torch.empty((int(self.lib.demia_contour_work_floats(M, C, max_points)),), dtype=torch.float32, device=self.device)
+            vals = torch.zeros((M, C, 12), dtype=torch.float64, device=self.device)
+            _lib.check(self.lib.demia_contour_measure(_lib.ptr(count), _lib.ptr(info), _lib.ptr(red), _lib.ptr(points), M, C,
+                                                      max_points, _lib.ptr(wi), _lib.ptr(wf), float(um_pix), _lib.ptr(vals),
+                                                      self._stream()), "demia_contour_measure")
+        cnt = counters.cpu().numpy()
+        if cnt[1] != 0:
+            raise _lib.HipKernelError(f"contour extraction overflow (flags {int(cnt[1])}): raise max_contours / max_points")
+        count_h, info_h, red_h = count.cpu().numpy(), info.cpu().numpy(), red.cpu().numpy()
+        pts_h = points[: int(cnt[0])].cpu().numpy()
+        vals_h = vals.cpu().numpy() if vals is not None else None
+        out = []
+        for m in range(M):
+            recs = []
+            for c in range(int(count_h[m])):
+                sx, sy, n, off = (int(v) for v in info_h[m, c])
+                rec = dict(start=(sx, sy), points=pts_h[off: off + n].copy(), area=float(red_h[m, c, 0]),
+                           perimeter=float(red_h[m, c, 1]))
+                if vals_h is not None:
+                    rec["values"] = vals_h[m, c].copy()
+                recs.append(rec)
+            # cv2.findContours returns the contours in reverse discovery (raster) order
+            recs.sort(key=lambda r: (r["start"][1], r["start"][0]), reverse=True)
+            out.append(recs)
+        return out

@@ -1,0 +1,86 @@
+"""Index-based view of a set of device-resident packed masks for the host-side decision logic.
+
+The reference's dedup / constraint code asks three things of a mask: its bounding box, its pixel
+count and its intersection count with another mask.  ``DeviceMaskAlgebra`` answers them from HIP
+reductions (``demia_mask_area_bbox`` / ``demia_mask_pair_intersections``); the greedy decision
+loops (which are inherently sequential and tiny) then run on the host over these integers exactly as
+the reference runs them over dense arrays.
+"""
+from __future__ import annotations
+
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+
+def _overlap(b1, b2) -> bool:
+    return not (b1[3] < b2[1] or b2[3] < b1[1] or b1[2] < b2[0] or b2[2] < b1[0])
+
+
+class DeviceMaskAlgebra:
+    def __init__(self, ops, packed: torch.Tensor):
+        self.ops = ops
+        self.packed = packed
+        self.n = int(packed.shape[0])
+        if self.n:
+            a, b = ops.area_bbox(packed)
+            self._bbox_dev = b
+            self.area = a.cpu().numpy().astype(np.int64)
+            self.bbox = b.cpu().numpy().astype(np.int64)
+        else:
+            self._bbox_dev = torch.zeros((0, 4), dtype=torch.int32, device=packed.device)
+            self.area = np.zeros((0,), dtype=np.int64)
+            self.bbox = np.zeros((0, 4), dtype=np.int64)
+        self._cache: Dict[Tuple[int, int], int] = {}
+
+    def bbox_of(self, i: int) -> Optional[Tuple[int, int, int, int]]:
+        """(y_min, x_min, y_max, x_max) or None for an empty mask (spatial_constraints.py:70-89)."""
+        b = self.bbox[i]
+        return None if b[0] < 0 else (int(b[0]), int(b[1]), int(b[2]), int(b[3]))
+
+    def intersections(self, pi: Sequence[int], pj: Sequence[int]) -> np.ndarray:
+        pi = np.asarray(pi, dtype=np.int64)
+        pj = np.asarray(pj, dtype=np.int64)
+        out = self.ops.pair_intersections(self.packed, self.packed, self._bbox_dev, self._bbox_dev, pi, pj)
+        for a, b, v in zip(pi.tolist(), pj.tolist(), out.tolist()):
+            self._cache[(a, b)] = v
+            self._cache[(b, a)] = v
+        return out
+
+    def prefetch_overlapping_pairs(self, groups: Optional[Iterable[Sequence[int]]] = None) -> None:
+        """One launch for every bbox-overlapping pair (within each index group, or all-vs-all)."""
+        if self.n < 2:
+            return
+        groups = [list(range(self.n))] if groups is None else [list(g) for g in groups]
+        pi: List[int] = []
+        pj: List[int] = []
+        for g in groups:
+            g = [i for i in g if self.bbox[i, 0] >= 0]
+            if len(g) < 2:
+                continue
+            b = self.bbox[g]
+            ov = ~((b[:, None, 3] < b[None, :, 1]) | (b[None, :, 3] < b[:, None, 1]) |
+                   (b[:, None, 2] < b[None, :, 0]) | (b[None, :, 2] < b[:, None, 0]))
+            ii, jj = np.nonzero(np.triu(ov, 1))
+            for a, c in zip(ii.tolist(), jj.tolist()):
+                if (g[a], g[c]) not in self._cache:
+                    pi.append(g[a])
+                    pj.append(g[c])
+        if pi:
+            self.intersections(pi, pj)
+
+    def inter(self, i: int, j: int) -> int:
+        """|mask_i & mask_j| (0 without touching the GPU when the boxes cannot overlap)."""
+        if i == j:
+            return int(self.area[i])
+        bi, bj = self.bbox[i], self.bbox[j]
+        if bi[0] < 0 or bj[0] < 0 or not _overlap(bi, bj):
+            return 0
+        v = self._cache.get((i, j))
+        if v is None:
+            v = int(self.intersections([i], [j])[0])
+        return v
+
+    def union(self, i: int, j: int) -> int:
+        return int(self.area[i]) + int(self.area[j]) - self.inter(i, j)

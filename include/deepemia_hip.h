@@ -196,6 +196,55 @@ int demia_unpack_masks(const uint32_t* packed, uint8_t* out_bool, int64_t M, int
 /* per-mask popcount ("np.sum(mask)", inference.py:1688, 2599) and tight bbox [M,4] = y0,x0,y1,x1 (inclusive; -1 if empty) */
 int demia_mask_area_bbox(const uint32_t* packed, int32_t* area, int32_t* bbox, int64_t M, int H, int W, void* stream);
 
+/* a9-a15: packed-mask morphology (all masks [M, H, W/32] u32, W % 32 == 0; in != out) ------------
+ * Replace, on bit-packed device masks, what the reference does with scipy / scikit-image / numpy on
+ * dense host arrays:
+ *   fill_holes      scipy.ndimage.binary_fill_holes           (mask_utils.py:75; inference.py:193, 1780)
+ *   morph_cross     skimage erosion / dilation, 3x3 cross, 'reflect' border
+ *                                                             (mask_utils.py:76; inference.py:196-198, 1786-1796)
+ *   overlap_prefix  overlap += mask; mask[overlap > 1] = 0 over the masks of one call, in order
+ *                                                             (mask_utils.py:77-78)
+ *   components_gt1  skimage.measure.label(mask).max() > 1, 8-connected (mask_utils.py:79-81)
+ *   column_counts   np.sum(masks, axis=(0, 1)) (per-column pixel counts; `counts` pre-zeroed)
+ *                                                             (mask_utils.py:62)
+ *   pair_intersections  np.count_nonzero(a[pi[p]] & b[pj[p]]) (inference.py:431, 2710;
+ *                                                              spatial_constraints.py:143, 186)
+ *   place_tiles     cv2.resize(mask, (tile_w, tile_h), INTER_NEAREST) + paste into a zero (H, W)
+ *                   frame at (x_off, y_off)                   (inference.py:2399-2420)
+ * bbox = [M, 4] i32 (y0, x0, y1, x1) inclusive, -1 for empty masks (demia_mask_area_bbox).    */
+int demia_mask_fill_holes(const uint32_t* in, uint32_t* out, const int32_t* bbox, int64_t M, int H, int W, void* stream);
+int demia_mask_morph_cross(const uint32_t* in, uint32_t* out, int64_t M, int H, int W, int dilate, void* stream);
+int demia_mask_overlap_prefix(uint32_t* masks, int64_t M, int H, int W, void* stream);
+int demia_mask_components_gt1(const uint32_t* in, uint32_t* scratch, const int32_t* bbox, int32_t* flag,
+                              int64_t M, int H, int W, void* stream);
+int demia_mask_column_counts(const uint32_t* masks, int64_t M, int H, int W, int32_t* counts, void* stream);
+int demia_mask_pair_intersections(const uint32_t* a, const uint32_t* b, const int32_t* pi, const int32_t* pj,
+                                  const int32_t* bbox_a, const int32_t* bbox_b, int32_t* out, int64_t P,
+                                  int H, int W, void* stream);
+int demia_mask_place_tiles(const uint32_t* src, uint32_t* dst, const int32_t* x_off, const int32_t* y_off, int64_t T,
+                           int src_h, int src_w, int tile_h, int tile_w, int H, int W, void* stream);
+
+/* a17/a18: contours and morphometrics ---------------------------------------------------------
+ * demia_mask_contours = cv2.findContours(mask, RETR_EXTERNAL, CHAIN_APPROX_SIMPLE) per mask
+ * (inference.py:1164, 2605) + cv2.contourArea + cv2.arcLength(closed) (inference.py:1175, 2607;
+ * measurements.py:134-135).  `filled` = demia_mask_fill_holes(masks) (used to skip components
+ * nested in holes, as RETR_EXTERNAL does).
+ *   count [M]; info [M, C, 4] = start x, start y, n points, offset into `points`;
+ *   red [M, C, 2] f64 = area, perimeter; points [max_points, 2] i32 (x, y);
+ *   counters [2] i32: [0] points used, [1] error bits (1 candidates, 2 contours > C, 4 points).
+ * Contours of one mask come out unordered: OpenCV's order is descending (start y, start x).
+ * demia_contour_measure = calculate_measurements (measurements.py:114-233) per contour:
+ *   out [M, C, 12] f64 = major_axis_length, minor_axis_length, eccentricity, Length, Width,
+ *   CircularED, Aspect_Ratio, Circularity, Chords, Feret_diam, Roundness, Sphericity.        */
+int64_t demia_contour_work_ints(int M, int C, int max_points);
+int64_t demia_contour_work_floats(int M, int C, int max_points);
+int demia_mask_contours(const uint32_t* masks, const uint32_t* filled, const int32_t* bbox, int M, int H, int W, int C,
+                        int max_points, int32_t* count, int32_t* info, double* red, int32_t* points,
+                        int32_t* counters, void* stream);
+int demia_contour_measure(const int32_t* count, const int32_t* info, const double* red, const int32_t* points, int M,
+                          int C, int max_points, int32_t* work_i, float* work_f, double um_pix, double* out,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif
