@@ -86,6 +86,8 @@ EXPORTS = {
     "demia_resize_v_norm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_int,
                                        C.c_void_p]),
+    "demia_resize_linear_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "demia_stem_conv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                    C.c_int, C.c_int, C.c_void_p]),
     "demia_maxpool3x3s2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -109,10 +111,11 @@ EXPORTS = {
                                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "demia_contour_work_ints": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "demia_contour_work_floats": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
+    "demia_contour_work_doubles": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "demia_mask_contours": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "demia_contour_measure": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
-                                         C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]),
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]),
 }
 
 _lib = None

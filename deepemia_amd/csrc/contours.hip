@@ -153,13 +153,15 @@ __global__ __launch_bounds__(256) void contour_trace_kernel(const ContourP p) {
         if (!r.valid) continue;
         const int slot = atomicAdd(&ncont, 1);
         if (slot >= p.C) { atomicOr(&p.counters[1], 2); continue; }
-        const int off = atomicAdd(&p.counters[0], r.npts);
+        // each contour reserves 4 spare slots: the measurement kernel carves its scratch pools by this
+        // offset, and the hull stacks need up to n + 3 entries
+        const int off = atomicAdd(&p.counters[0], r.npts + 4);
         int* inf = p.info + ((long)m * p.C + slot) * 4;
         inf[0] = sx; inf[1] = sy; inf[2] = r.npts; inf[3] = off;
         double* rd = p.red + ((long)m * p.C + slot) * 2;
         rd[0] = (double)(r.area2 < 0 ? -r.area2 : r.area2) * 0.5;
         rd[1] = r.perimeter;
-        if (off + r.npts > p.max_points) { atomicOr(&p.counters[1], 4); inf[2] = 0; continue; }
+        if (off + r.npts + 4 > p.max_points) { atomicOr(&p.counters[1], 4); inf[2] = 0; continue; }
         trace_border<true>(im, sx, sy, p.points + 2L * off);
     }
     __syncthreads();
@@ -370,38 +372,54 @@ __device__ void rotating_calipers(const float* hp, int n, float* vect, float* in
     out[4] = A2 * b_h; out[5] = B2 * b_h;
 }
 
-// dense symmetric solve by Gaussian elimination with partial pivoting; returns min/max |pivot| ratio
-template <int N>
-__device__ double solve_n(double a[N][N], double b[N], double x[N]) {
-    double pmin = 1e300, pmax = 0;
-    int perm[N];
-    for (int i = 0; i < N; ++i) perm[i] = i;
-    for (int c = 0; c < N; ++c) {
-        int piv = c;
-        for (int r = c + 1; r < N; ++r) if (fabs(a[r][c]) > fabs(a[piv][c])) piv = r;
-        if (piv != c) {
-            for (int k = 0; k < N; ++k) { const double t = a[c][k]; a[c][k] = a[piv][k]; a[piv][k] = t; }
-            const double t = b[c]; b[c] = b[piv]; b[piv] = t;
-        }
-        const double d = a[c][c];
-        pmin = fmin(pmin, fabs(d)); pmax = fmax(pmax, fabs(d));
-        if (d == 0) continue;
-        for (int r = c + 1; r < N; ++r) {
-            const double f = a[r][c] / d;
-            for (int k = c; k < N; ++k) a[r][k] -= f * a[c][k];
-            b[r] -= f * b[c];
-        }
+// Least squares through a one-sided Jacobi (Hestenes) SVD, as cv::SVD::compute + cv::SVD::backSubst do:
+// A is n x K (row-major, overwritten), x = V diag(1/w) U^T b with singular values <= 2*DBL_EPSILON*sum(w)
+// treated as zero.  wmin/wmax return the extreme singular values.
+template <int K>
+__device__ void svd_lstsq(double* A, int n, const double* bvec, double bconst, double x[K], double* wmax, double* wmin) {
+    double V[K][K];
+    for (int i = 0; i < K; ++i) for (int j = 0; j < K; ++j) V[i][j] = i == j ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        bool changed = false;
+        for (int p = 0; p < K - 1; ++p)
+            for (int q = p + 1; q < K; ++q) {
+                double a = 0, b = 0, g = 0;
+                for (int i = 0; i < n; ++i) { const double u = A[i * K + p], v = A[i * K + q]; a += u * u; b += v * v; g += u * v; }
+                if (fabs(g) <= 2.220446049250313e-16 * sqrt(a * b)) continue;
+                changed = true;
+                const double zeta = (b - a) / (2.0 * g);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+                for (int i = 0; i < n; ++i) {
+                    const double u = A[i * K + p], v = A[i * K + q];
+                    A[i * K + p] = c * u - sn * v; A[i * K + q] = sn * u + c * v;
+                }
+                for (int i = 0; i < K; ++i) {
+                    const double u = V[i][p], v = V[i][q];
+                    V[i][p] = c * u - sn * v; V[i][q] = sn * u + c * v;
+                }
+            }
+        if (!changed) break;
     }
-    for (int r = N - 1; r >= 0; --r) {
-        double s = b[r];
-        for (int k = r + 1; k < N; ++k) s -= a[r][k] * x[k];
-        x[r] = a[r][r] != 0 ? s / a[r][r] : 0.0;
+    double w[K], utb[K], sum = 0;
+    *wmax = 0; *wmin = 1e300;
+    for (int j = 0; j < K; ++j) {
+        double nn = 0, d = 0;
+        for (int i = 0; i < n; ++i) { const double u = A[i * K + j]; nn += u * u; d += u * (bvec ? bvec[i] : bconst); }
+        w[j] = sqrt(nn); utb[j] = d; sum += w[j];
+        *wmax = fmax(*wmax, w[j]); *wmin = fmin(*wmin, w[j]);
     }
-    return pmax > 0 ? pmin / pmax : 0.0;
+    const double thr = sum * 2.0 * 2.220446049250313e-16;
+    for (int i = 0; i < K; ++i) x[i] = 0;
+    for (int j = 0; j < K; ++j) {
+        if (w[j] <= thr) continue;
+        const double f = utb[j] / (w[j] * w[j]);   // (u_j . b) / w_j, with u_j = a_j / w_j
+        for (int i = 0; i < K; ++i) x[i] += f * V[i][j];
+    }
 }
 
-// cv::fitEllipse (fitEllipseNoDirect): returns width <= height
-__device__ void fit_ellipse(const int* pts, int n, float* bw, float* bh) {
+// cv::fitEllipse (fitEllipseNoDirect): returns width <= height.  Ad: scratch of 5 * n doubles
+__device__ void fit_ellipse(const int* pts, int n, double* Ad, float* bw, float* bh) {
     float csx = 0.f, csy = 0.f;
     for (int i = 0; i < n; ++i) { csx += (float)pts[2 * i]; csy += (float)pts[2 * i + 1]; }
     const float cx = csx / (float)n, cy = csy / (float)n;
@@ -409,54 +427,48 @@ __device__ void fit_ellipse(const int* pts, int n, float* bw, float* bh) {
     for (int i = 0; i < n; ++i) s += fabs((double)((float)pts[2 * i] - cx)) + fabs((double)((float)pts[2 * i + 1] - cy));
     const double eps32 = 1.1920928955078125e-07;
     const double scale = 100.0 / (s > eps32 ? s : eps32);
-    double gfp[5];
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        const float eps = attempt ? (float)(s / (n * 2) * 1e-3) : 0.f;
-        double ata[5][5] = {}, atb[5] = {};
+    double gfp[5], wmax, wmin;
+    float eps = 0.f;
+    int attempt = 0;
+    auto point = [&](int i, double& px, double& py) {
+        float fxp = (float)pts[2 * i], fyp = (float)pts[2 * i + 1];
+        if (attempt) { fxp = fxp + (float)((i & 1) * 2 - 1) * eps; fyp = fyp + (float)((i & 2) - 1) * eps; }
+        px = (double)(fxp - cx) * scale; py = (double)(fyp - cy) * scale;
+    };
+    for (;; ++attempt) {
         for (int i = 0; i < n; ++i) {
-            float fxp = (float)pts[2 * i], fyp = (float)pts[2 * i + 1];
-            if (attempt) { fxp = fxp + (float)(((i & 1) * 2 - 1)) * eps; fyp = fyp + (float)((i & 2) - 1) * eps; }
-            const double px = (double)(fxp - cx) * scale, py = (double)(fyp - cy) * scale;
-            const double row[5] = {-px * px, -py * py, -px * py, px, py};
-            for (int a = 0; a < 5; ++a) {
-                atb[a] += row[a] * 10000.0;
-                for (int b = 0; b < 5; ++b) ata[a][b] += row[a] * row[b];
-            }
+            double px, py;
+            point(i, px, py);
+            Ad[i * 5 + 0] = -px * px; Ad[i * 5 + 1] = -py * py; Ad[i * 5 + 2] = -px * py; Ad[i * 5 + 3] = px; Ad[i * 5 + 4] = py;
         }
-        const double ratio = solve_n<5>(ata, atb, gfp);
-        // cv: if (w[0] * FLT_EPSILON > w[4]) perturb and refit; pivots of A^T A ~ singular values squared
-        if (attempt == 1 || !(ratio < eps32 * eps32)) {
-            // second pass keeps the perturbed points for the re-fit below
-            double rp[5];
-            double m2[2][2] = {{2 * gfp[0], gfp[2]}, {gfp[2], 2 * gfp[1]}}, b2[2] = {gfp[3], gfp[4]}, c2[2];
-            solve_n<2>(m2, b2, c2);
-            rp[0] = c2[0]; rp[1] = c2[1];
-            double a3[3][3] = {}, b3[3] = {}, g[3];
-            for (int i = 0; i < n; ++i) {
-                float fxp = (float)pts[2 * i], fyp = (float)pts[2 * i + 1];
-                if (attempt) { fxp = fxp + (float)(((i & 1) * 2 - 1)) * eps; fyp = fyp + (float)((i & 2) - 1) * eps; }
-                const double px = (double)(fxp - cx) * scale, py = (double)(fyp - cy) * scale;
-                const double row[3] = {(px - rp[0]) * (px - rp[0]), (py - rp[1]) * (py - rp[1]), (px - rp[0]) * (py - rp[1])};
-                for (int a = 0; a < 3; ++a) {
-                    b3[a] += row[a];
-                    for (int b = 0; b < 3; ++b) a3[a][b] += row[a] * row[b];
-                }
-            }
-            solve_n<3>(a3, b3, g);
-            rp[4] = -0.5 * atan2(g[2], g[1] - g[0]);
-            double t;
-            if (fabs(g[2]) > 1e-8) t = g[2] / sin(-2.0 * rp[4]);
-            else t = g[1] - g[0];
-            rp[2] = fabs(g[0] + g[1] - t);
-            if (rp[2] > 1e-8) rp[2] = sqrt(2.0 / rp[2]);
-            rp[3] = fabs(g[0] + g[1] + t);
-            if (rp[3] > 1e-8) rp[3] = sqrt(2.0 / rp[3]);
-            float w = (float)(rp[2] * 2 / scale), h = (float)(rp[3] * 2 / scale);
-            if (w > h) { const float tt = w; w = h; h = tt; }
-            *bw = w; *bh = h;
-            return;
-        }
+        svd_lstsq<5>(Ad, n, nullptr, 10000.0, gfp, &wmax, &wmin);
+        if (attempt == 1 || !(wmax * eps32 > wmin)) break;
+        eps = (float)(s / (n * 2) * 1e-3);
     }
+    double rp[5];
+    {
+        double m2[4] = {2 * gfp[0], gfp[2], gfp[2], 2 * gfp[1]}, b2[2] = {gfp[3], gfp[4]}, c2[2], a, b;
+        svd_lstsq<2>(m2, 2, b2, 0.0, c2, &a, &b);
+        rp[0] = c2[0]; rp[1] = c2[1];
+    }
+    double g[3];
+    for (int i = 0; i < n; ++i) {
+        double px, py;
+        point(i, px, py);
+        Ad[i * 3 + 0] = (px - rp[0]) * (px - rp[0]); Ad[i * 3 + 1] = (py - rp[1]) * (py - rp[1]); Ad[i * 3 + 2] = (px - rp[0]) * (py - rp[1]);
+    }
+    svd_lstsq<3>(Ad, n, nullptr, 1.0, g, &wmax, &wmin);
+    rp[4] = -0.5 * atan2(g[2], g[1] - g[0]);
+    double t;
+    if (fabs(g[2]) > 1e-8) t = g[2] / sin(-2.0 * rp[4]);
+    else t = g[1] - g[0];
+    rp[2] = fabs(g[0] + g[1] - t);
+    if (rp[2] > 1e-8) rp[2] = sqrt(2.0 / rp[2]);
+    rp[3] = fabs(g[0] + g[1] + t);
+    if (rp[3] > 1e-8) rp[3] = sqrt(2.0 / rp[3]);
+    float w = (float)(rp[2] * 2 / scale), h = (float)(rp[3] * 2 / scale);
+    if (w > h) { const float tt = w; w = h; h = tt; }
+    *bw = w; *bh = h;
 }
 
 struct MeasureP {
@@ -465,8 +477,9 @@ struct MeasureP {
     const double* red;    // [M, C, 2]
     const int* points;
     int M, C, max_points;
-    int* work_i;          // [4 * max_points + 8 * M * C]
-    float* work_f;        // [5 * max_points + 16 * M * C]
+    int* work_i;          // [4 * max_points]
+    float* work_f;        // [5 * max_points]
+    double* work_d;       // [5 * max_points]
     double um_pix;
     double* out;          // [M, C, 12]
 };
@@ -481,13 +494,14 @@ __global__ void contour_measure_kernel(const MeasureP p) {
     double* o = p.out + (long)t * 12;
     const double area = p.red[2 * t], perimeter = p.red[2 * t + 1];
     const int* pts = p.points + 2L * off;
-    // scratch carved per contour by its point offset (each contour owns [off, off+n) of every pool)
-    int* order = p.work_i + off + 0L * p.max_points + 2L * t;
-    int* stack = p.work_i + 2L * off + 1L * p.max_points + 2L * p.M * p.C + 4L * t;   // up to 2n + 4
-    int* hull = p.work_i + off + 3L * p.max_points + 6L * p.M * p.C + 2L * t;
-    float* hp = p.work_f + 2L * off + 4L * t;
-    float* vect = p.work_f + 2L * off + 2L * p.max_points + 4L * p.M * p.C + 4L * t;
-    float* inv_len = p.work_f + off + 4L * p.max_points + 8L * p.M * p.C + 2L * t;
+    // scratch carved per contour by its point offset: contour t owns slots [off, off + n + 4) of the point
+    // pool, hence disjoint ranges of every pool below (sizes are multiples of that range)
+    int* order = p.work_i + off;                                  // n
+    int* stack = p.work_i + 1L * p.max_points + 2L * off;          // <= n + 3 (two Sklansky stacks), 2n + 8 available
+    int* hull = p.work_i + 3L * p.max_points + off;               // n
+    float* hp = p.work_f + 2L * off;                               // 2n
+    float* vect = p.work_f + 2L * p.max_points + 2L * off;         // 2n
+    float* inv_len = p.work_f + 4L * p.max_points + off;           // n
 
     // ---- minAreaRect -> boxPoints -> int -> order_points -> dA, dB -------------------------------
     float rcx = 0.f, rcy = 0.f, rw = 0.f, rh = 0.f, rang = 0.f;
@@ -545,7 +559,7 @@ __global__ void contour_measure_kernel(const MeasureP p) {
     double maj = 0, mnr = 0, ecc = 0;
     if (n >= 5) {
         float w, h;
-        fit_ellipse(pts, n, &w, &h);
+        fit_ellipse(pts, n, p.work_d + 5L * off, &w, &h);
         maj = (double)w; mnr = (double)h;
         const double ea = (maj > mnr ? maj : mnr) / 2.0, eb = (maj > mnr ? mnr : maj) / 2.0;
         ecc = ea != 0 ? sqrt(1.0 - (eb * eb) / (ea * ea)) : 0.0;
@@ -568,6 +582,7 @@ __global__ void contour_measure_kernel(const MeasureP p) {
 
 extern "C" int64_t demia_contour_work_ints(int M, int C, int max_points) { return 4L * max_points + 8L * M * C + 16; }
 extern "C" int64_t demia_contour_work_floats(int M, int C, int max_points) { return 5L * max_points + 16L * M * C + 16; }
+extern "C" int64_t demia_contour_work_doubles(int M, int C, int max_points) { return 5L * max_points + 8L * M * C + 16; }
 
 extern "C" int demia_mask_contours(const uint32_t* masks, const uint32_t* filled, const int32_t* bbox, int M, int H, int W, int C,
                                    int max_points, int32_t* count, int32_t* info, double* red, int32_t* points,
@@ -584,11 +599,11 @@ extern "C" int demia_mask_contours(const uint32_t* masks, const uint32_t* filled
 }
 
 extern "C" int demia_contour_measure(const int32_t* count, const int32_t* info, const double* red, const int32_t* points, int M,
-                                     int C, int max_points, int32_t* work_i, float* work_f, double um_pix, double* out,
-                                     void* stream) {
-    DEMIA_REQUIRE(count && info && red && points && work_i && work_f && out, "args");
+                                     int C, int max_points, int32_t* work_i, float* work_f, double* work_d, double um_pix,
+                                     double* out, void* stream) {
+    DEMIA_REQUIRE(count && info && red && points && work_i && work_f && work_d && out, "args");
     if (M * C == 0) return DEMIA_OK;
-    MeasureP p{count, info, red, points, M, C, max_points, work_i, work_f, um_pix, out};
+    MeasureP p{count, info, red, points, M, C, max_points, work_i, work_f, work_d, um_pix, out};
     hipLaunchKernelGGL(contour_measure_kernel, dim3(cdiv((long)M * C, 64)), dim3(64), 0, (hipStream_t)stream, p);
     DEMIA_CHECK_LAUNCH("contour_measure_kernel");
     return DEMIA_OK;

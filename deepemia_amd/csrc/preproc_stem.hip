@@ -70,6 +70,35 @@ __global__ void resize_v_norm_kernel(const uint8_t* __restrict__ tmp, float* __r
     }
 }
 
+
+// cv2.resize(INTER_LINEAR) on 8-bit 3-channel images, OpenCV's fixed-point path:
+// horizontal: S[sx]*a0 + S[sx+1]*a1 (11-bit coefficients), vertical:
+// (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2.  Tables come from the host.
+__global__ void resize_linear_u8_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, long total, int H, int W,
+                                        int oh, int ow, const int* __restrict__ xofs, const short* __restrict__ ialpha,
+                                        const int* __restrict__ yofs, const short* __restrict__ ibeta) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int dx = (int)(i % ow);
+        const long t = i / ow;
+        const int dy = (int)(t % oh);
+        const long n = t / oh;
+        const int sx0 = xofs[2 * dx], sx1 = xofs[2 * dx + 1];
+        const int a0 = ialpha[2 * dx], a1 = ialpha[2 * dx + 1];
+        const int sy0 = yofs[2 * dy], sy1 = yofs[2 * dy + 1];
+        const int b0 = ibeta[2 * dy], b1 = ibeta[2 * dy + 1];
+        const uint8_t* r0 = src + ((n * H + sy0) * (long)W) * 3;
+        const uint8_t* r1 = src + ((n * H + sy1) * (long)W) * 3;
+        uint8_t* o = dst + i * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int h0 = (int)r0[sx0 * 3 + c] * a0 + (int)r0[sx1 * 3 + c] * a1;
+            const int h1 = (int)r1[sx0 * 3 + c] * a0 + (int)r1[sx1 * 3 + c] * a1;
+            const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            o[c] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+        }
+    }
+}
+
 // ---- stem: 7x7 s2 p3, 3(4) -> 64, + FrozenBN + ReLU ----------------------------------
 // block = 256 threads = 16x16 output pixels; thread = 4 adjacent pixels x 16 channels.
 // LDS: input patch 37 x 40 x 4 f32 and the whole 7x7x4x64 f32 filter bank.
@@ -289,5 +318,17 @@ extern "C" int demia_subsample2(const void* in, void* out, int N, int H, int W, 
         hipLaunchKernelGGL(subsample2_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
                            (const float*)in, (float*)out, total, H, W, C, Ho, Wo);
     DEMIA_CHECK_LAUNCH("subsample2_kernel");
+    return DEMIA_OK;
+}
+
+extern "C" int demia_resize_linear_u8(const uint8_t* src, uint8_t* dst, int N, int H, int W, int out_h, int out_w,
+                                      const int32_t* xofs, const int16_t* ialpha, const int32_t* yofs, const int16_t* ibeta,
+                                      void* stream) {
+    DEMIA_REQUIRE(src && dst && xofs && ialpha && yofs && ibeta, "args");
+    const long total = (long)N * out_h * out_w;
+    if (total == 0) return DEMIA_OK;
+    hipLaunchKernelGGL(resize_linear_u8_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, total, H, W,
+                       out_h, out_w, xofs, ialpha, yofs, ibeta);
+    DEMIA_CHECK_LAUNCH("resize_linear_u8_kernel");
     return DEMIA_OK;
 }

@@ -1,0 +1,74 @@
+"""Model discovery and loading kept as a drop-in (reference ``src/data/models.py:33-162``).
+
+``choose_and_use_model`` returns ``(predictor, metadata)`` exactly like the reference, but the
+predictor is the MI355X-native :class:`deepemia_amd.predictor.Predictor` instead of Detectron2's
+``DefaultPredictor``.  The checkpoint is the Detectron2 file the reference writes / reads
+(``<split_dir>/<dataset>/rcnn_r{50,101}/model_final_r{50,101}.pth``, ``torch.save({"model": sd})``).
+There is no quantised / CPU fallback branch: without a HIP device loading fails loudly.
+"""
+from __future__ import annotations
+
+import os
+from types import SimpleNamespace
+from typing import Dict, Tuple
+
+import torch
+
+from ..engine import MaskRCNNEngine
+from ..predictor import Predictor
+from ..utils.logger_utils import system_logger
+from .datasets import MetadataCatalog
+
+# BASELINE.json configs[1] runs bf16; parity (mask IoU >= 0.999 vs the fp32 CPU path) needs f32.
+DEFAULT_PRECISION = os.environ.get("DEEPEMIA_PRECISION", "f32")
+
+
+def get_trained_model_paths(base_dir: str, rcnn: int = 101) -> dict:
+    """``{dataset: path}`` of every ``<base_dir>/<dataset>/rcnn_r<rcnn>/model_final_r<rcnn>.pth``."""
+    out = {}
+    for dataset_name in os.listdir(base_dir):
+        path = os.path.join(base_dir, dataset_name, f"rcnn_r{rcnn}", f"model_final_r{rcnn}.pth")
+        if os.path.exists(path):
+            out[dataset_name] = path
+    return out
+
+
+def _cfg(rcnn: int, threshold: float, num_classes: int, weights: str) -> SimpleNamespace:
+    """The three overrides of ``models.py:140-144`` on top of mask_rcnn_R_<rcnn>_FPN_3x."""
+    roi = SimpleNamespace(SCORE_THRESH_TEST=threshold, NUM_CLASSES=num_classes)
+    model = SimpleNamespace(DEVICE="cuda", ROI_HEADS=roi, WEIGHTS=weights, DEPTH=rcnn)
+    return SimpleNamespace(MODEL=model)
+
+
+def read_d2_checkpoint(path: str) -> Dict[str, torch.Tensor]:
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    sd = ck["model"] if isinstance(ck, dict) and "model" in ck else ck
+    return {k: (v if isinstance(v, torch.Tensor) else torch.as_tensor(v)) for k, v in sd.items()}
+
+
+def load_model(cfg, model_path: str, dataset_name: str, is_quantized: bool = False) -> Predictor:
+    """``DefaultPredictor(cfg)`` replacement (``models.py:54-107``)."""
+    if is_quantized:
+        raise RuntimeError("Quantized model load failed.")  # the reference's caller falls back on this
+    cfg.MODEL.WEIGHTS = model_path
+    metadata = MetadataCatalog.get(f"{dataset_name}_train")
+    cfg.MODEL.ROI_HEADS.NUM_CLASSES = len(metadata.thing_classes)
+    sd = read_d2_checkpoint(model_path)
+    device = f"cuda:{torch.cuda.current_device()}" if torch.cuda.is_available() else "cuda:0"
+    eng = MaskRCNNEngine(sd, cfg.MODEL.DEPTH, cfg.MODEL.ROI_HEADS.NUM_CLASSES, cfg.MODEL.ROI_HEADS.SCORE_THRESH_TEST,
+                         device, DEFAULT_PRECISION)
+    if eng.unmatched_keys:
+        system_logger.warning(f"{model_path}: {len(eng.unmatched_keys)} checkpoint keys were not consumed: "
+                              f"{eng.unmatched_keys[:8]}{' ...' if len(eng.unmatched_keys) > 8 else ''}")
+    return Predictor(eng)
+
+
+def choose_and_use_model(model_paths: dict, dataset_name: str, threshold: float, metadata, rcnn: int = 101
+                         ) -> Tuple[Predictor, object]:
+    """``(predictor, metadata)`` or ``(None, None)`` when the dataset has no model (``models.py:110-162``)."""
+    if dataset_name not in model_paths:
+        system_logger.error(f"No model found for dataset {dataset_name}")
+        return None, None
+    cfg = _cfg(rcnn, threshold, len(metadata.thing_classes), model_paths[dataset_name])
+    system_logger.info(f"Using standard model for {dataset_name}")
+    return load_model(cfg, model_paths[dataset_name], dataset_name, is_quantized=False), metadata

@@ -85,6 +85,34 @@ def pil_bilinear_tables(in_size: int, out_size: int):
     return xmin.astype(np.int32), xsize.astype(np.int32), np.ascontiguousarray(ik)
 
 
+def cv_linear_tables(in_size: int, out_size: int, vertical: bool = False):
+    """OpenCV ``resize(INTER_LINEAR)`` 8-bit tables: source index pair and 11-bit coefficient pair per
+    output coordinate.  ``f = (float)((d + 0.5) * scale - 0.5)``; horizontally an index outside the
+    row zeroes the fraction and clamps, vertically the fraction is kept and only the ROW indices are
+    clipped (``resizeGeneric_`` / ``resizeGeneric_Invoker``); coefficients = ``saturate_cast<short>(c * 2048)``."""
+    inv_scale = float(out_size) / float(in_size)
+    scale = 1.0 / inv_scale
+    d = np.arange(out_size, dtype=np.float64)
+    f = ((d + 0.5) * scale - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int64)
+    f = (f - s.astype(np.float32)).astype(np.float32)
+    if vertical:
+        s0 = np.clip(s, 0, in_size - 1)
+        s1 = np.clip(s + 1, 0, in_size - 1)
+    else:
+        neg = s < 0
+        f[neg] = 0.0
+        s[neg] = 0
+        hi = s >= in_size - 1
+        f[hi] = 0.0
+        s[hi] = in_size - 1
+        s0, s1 = s, np.minimum(s + 1, in_size - 1)
+    ofs = np.stack([s0, s1], axis=1).astype(np.int32)
+    c = np.stack([np.float32(1.0) - f, f], axis=1).astype(np.float32) * np.float32(2048.0)
+    coef = np.clip(np.rint(c), -32768, 32767).astype(np.int16)
+    return np.ascontiguousarray(ofs), np.ascontiguousarray(coef)
+
+
 def cell_anchor_table() -> np.ndarray:
     out = np.zeros((5, 3, 4), dtype=np.float32)
     for l, size in enumerate(ANCHOR_SIZES):
@@ -266,6 +294,19 @@ class MaskRCNNEngine:
             self._tables[key] = dict(newh=newh, neww=neww, xm=t(xm), xs=t(xs), xk=t(xk), ksx=xk.shape[1],
                                      ym=t(ym), ys=t(ys), yk=t(yk), ksy=yk.shape[1], need_h=(w != neww))
         return self._tables[key]
+
+    def resize_linear_u8(self, images: torch.Tensor, out_h: int, out_w: int) -> torch.Tensor:
+        """``cv2.resize(img, (out_w, out_h), INTER_LINEAR)`` for a [N, H, W, 3] u8 device batch."""
+        n, h, w, _ = images.shape
+        xo, xa = cv_linear_tables(w, out_w)
+        yo, ya = cv_linear_tables(h, out_h, vertical=True)
+        t = lambda a: torch.from_numpy(a).to(self.device)
+        xo, xa, yo, ya = t(xo), t(xa), t(yo), t(ya)
+        out = torch.empty((n, out_h, out_w, 3), dtype=torch.uint8, device=self.device)
+        _lib.check(self.lib.demia_resize_linear_u8(_lib.ptr(images.contiguous()), _lib.ptr(out), n, h, w, out_h, out_w, _lib.ptr(xo),
+                                                   _lib.ptr(xa), _lib.ptr(yo), _lib.ptr(ya), self._stream()),
+                   "demia_resize_linear_u8")
+        return out
 
     # ------------------------------------------------------------------ stages
     def preprocess(self, images: torch.Tensor):

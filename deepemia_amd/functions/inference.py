@@ -1,0 +1,548 @@
+"""Tiled Mask R-CNN inference + morphometrics: the reference's ``run_inference`` pipeline
+(``src/functions/inference.py:499-1350``) re-built around device-resident data.
+
+Same entry point, config keys, decision rules (quirks included, SURVEY.md section 8 notes N1-N8) and output
+files as the reference; what differs is where the data lives and how the work is batched:
+
+* the image, its tiles and every mask stay in HBM; masks are bit-packed ``[M, H, W/32]``;
+* all tiles of an image go through the network in ONE batched forward per model, and the output of
+  a (model, image|tile) pair is computed once and reused by every class of the class loop (the
+  reference re-runs the same forward once per class and only filters the result,
+  ``inference.py:789,1411,1519``) -- identical results, ``num_classes`` times fewer forwards;
+* hole filling, cross morphology, overlap removal, component tests, IoU / containment counts,
+  contour tracing and the measurement reductions are HIP kernels (``deepemia_amd/csrc``); the
+  greedy keep/remove loops (sequential by definition, a few hundred integers) run on the host
+  over the kernels' integer tables.
+"""
+from __future__ import annotations
+
+import csv
+import math
+import os
+import time
+from pathlib import Path
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from ..data.datasets import DatasetCatalog, MetadataCatalog, read_dataset_info, register_datasets
+from ..data.models import choose_and_use_model, get_trained_model_paths
+from ..maskset import MaskOps
+from ..utils.config import get_config
+from ..utils.logger_utils import log_memory_usage, system_logger
+from ..utils.mask_algebra import DeviceMaskAlgebra
+from ..utils.mask_utils import (postprocess_masks_device, postprocess_masks_universal_device, process_masks_device,
+                                rle_encoding)
+from ..utils.spatial_constraints import apply_spatial_constraints_indices, load_spatial_constraints
+
+CSV_HEADER = ["Instance_ID", "Class", "Class_Name", "Major axis length", "Minor axis length", "Eccentricity", "C. Length",
+              "C. Width", "Circular eq. diameter", "Aspect ratio", "Circularity", "Chord length", "Ferret diameter",
+              "Roundness", "Sphericity", "Contrast d10", "Contrast d50", "Contrast d90", "Detected scale bar", "File name"]
+# measurement vector layout of demia_contour_measure -> CSV column order (inference.py:1209-1230)
+_VAL = {"major": 0, "minor": 1, "ecc": 2, "Length": 3, "Width": 4, "CircularED": 5, "Aspect": 6, "Circularity": 7,
+        "Chords": 8, "Feret": 9, "Roundness": 10, "Sphericity": 11}
+CLASS_COLORS = [(0, 255, 0), (255, 0, 0), (0, 0, 255), (255, 255, 0), (255, 0, 255), (0, 255, 255), (128, 0, 128), (255, 165, 0)]
+
+
+def is_image_file(filename: str) -> bool:
+    return filename.lower().endswith((".tif", ".tiff", ".png", ".jpg", ".jpeg", ".bmp", ".gif"))
+
+
+def get_image_folder_path(base_path: Optional[Path] = None) -> str:
+    """``inference.py:370-404``: ``<root>/DATASET/INFERENCE`` or its ``UPLOAD`` sub-folder."""
+    if base_path is None:
+        root = Path(get_config()["paths"].get("local_dataset_root", "~")).expanduser()
+        base_path = root / "DATASET" / "INFERENCE"
+    inference_path = str(base_path)
+    upload_path = os.path.join(inference_path, "UPLOAD")
+    if os.path.isdir(inference_path) and any(os.path.isfile(os.path.join(inference_path, f)) for f in os.listdir(inference_path)):
+        return inference_path
+    if os.path.exists(upload_path) and any(os.path.isfile(os.path.join(upload_path, f)) for f in os.listdir(upload_path)):
+        return upload_path
+    raise FileNotFoundError("No images found in INFERENCE or INFERENCE/UPLOAD folders.")
+
+
+def imread_bgr(path: str) -> Optional[np.ndarray]:
+    """``cv2.imread`` stand-in: 8-bit, 3-channel, BGR; ``None`` when the file cannot be decoded."""
+    from PIL import Image
+
+    try:
+        with Image.open(path) as im:
+            if im.mode in ("I;16", "I;16B", "I;16L", "I"):
+                a = np.asarray(im).astype(np.float64)
+                a = (a / 256.0) if a.max() > 255 else a
+                rgb = np.repeat(np.clip(a, 0, 255).astype(np.uint8)[:, :, None], 3, axis=2)
+            else:
+                rgb = np.asarray(im.convert("RGB"))
+    except Exception:
+        return None
+    return np.ascontiguousarray(rgb[:, :, ::-1])
+
+
+def detect_scale_bar(image, roi_config=None, dataset_name=None, draw_debug=False) -> Tuple[str, float]:
+    """The OCR scale-bar reader (``src/utils/scalebar_ocr.py``, EasyOCR) is out of scope
+    (SURVEY.md section 2 row 8); this is its documented fallback contract: ``("0", 1.0)``
+    (``scalebar_ocr.py:362-364``, ``inference.py:768-773``)."""
+    return "0", 1.0
+
+
+def calculate_image_quality_score(image: np.ndarray) -> float:
+    """``inference.py:256-285`` with OpenCV's BGR->gray fixed-point weights (B 1868, G 9617, R 4899 >> 14)."""
+    if image.ndim == 3:
+        b, g, r = (image[:, :, i].astype(np.int64) for i in range(3))
+        gray = ((b * 1868 + g * 9617 + r * 4899 + (1 << 13)) >> 14).astype(np.uint8)
+    else:
+        gray = image
+    return float(np.clip(0.4 * (np.mean(gray) / 255.0) + 0.6 * (np.std(gray) / 128.0), 0.0, 1.0))
+
+
+def get_confidence_threshold(image, target_class, small_classes, global_config) -> float:
+    """``inference.py:288-362``: reads the GLOBAL config (not the dataset override), as the reference does."""
+    inf = global_config.get("inference_settings", {})
+    ccfg = inf.get("class_specific_settings", {}).get(f"class_{target_class}", {})
+    base = ccfg.get("confidence_threshold", 0.3 if target_class in small_classes else 0.5)
+    if inf.get("confidence_mode", "auto") == "manual":
+        return base
+    q = calculate_image_quality_score(image)
+    if q < 0.3:
+        return base * 0.7
+    if q < 0.5:
+        return base * 0.85
+    return base
+
+
+def determine_small_classes(class_avg_sizes: Dict[int, float], threshold_percentile=50) -> set:
+    """``inference.py:1709-1736``."""
+    if not class_avg_sizes:
+        return set()
+    thr = np.percentile(list(class_avg_sizes.values()), threshold_percentile)
+    return {c for c, s in class_avg_sizes.items() if s <= thr}
+
+
+class _Detections:
+    """One predictor call's result, device-resident (masks packed) + small host tables."""
+
+    def __init__(self, packed: torch.Tensor, scores: np.ndarray, classes: np.ndarray, hw: Tuple[int, int]):
+        self.packed, self.scores, self.classes, self.hw = packed, scores, classes, hw
+
+
+class EmptyEnsembleTypeError(ValueError):
+    """Reference behaviour N4: ``np.array([]) + [masks...]`` raises and the image is skipped."""
+
+
+class InferencePipeline:
+    def __init__(self, predictors: Sequence, dataset_name: str, inf_settings: dict, global_config: dict):
+        self.predictors = list(predictors)
+        self.dataset_name = dataset_name
+        self.inf = inf_settings
+        self.gcfg = global_config
+        self.dev = self.predictors[0].engine.device
+        self.ops = MaskOps(str(self.dev))
+        l4 = global_config.get("l4_performance_optimizations", {})
+        self.parallel_mask_processing = l4.get("enable_parallel_mask_processing", True)
+        gens = global_config.get("inference_settings", {}).get("ensemble_settings", {})
+        # N3: weights always come from the import-time GLOBAL config, dict order R50, R101
+        self.ensemble_weights = list(gens.get("weights", {"R50": 0.6, "R101": 0.4}).values())
+        self.class_specific_settings = inf_settings.get("class_specific_settings", {})
+        self._cache: Dict[Tuple[int, str], List[_Detections]] = {}
+        self.forward_calls = 0
+
+    # ------------------------------------------------------------------ predictor plumbing
+    def _predict_batch(self, model_idx: int, key: str, images: torch.Tensor) -> List[_Detections]:
+        """Forward a batch of equally sized images once per (model, key); every class reuses it."""
+        ck = (model_idx, key)
+        if ck in self._cache:
+            return self._cache[ck]
+        pred = self.predictors[model_idx]
+        out: List[_Detections] = []
+        h, w = int(images.shape[1]), int(images.shape[2])
+        for b0 in range(0, images.shape[0], 16):
+            raw = pred.engine.forward(images[b0:b0 + 16].contiguous())
+            self.forward_calls += 1
+            counts = raw.count.cpu().numpy()
+            valid = raw.valid.cpu().numpy().astype(bool)
+            scores = raw.scores.cpu().numpy()
+            classes = raw.classes.cpu().numpy().astype(np.int64)
+            for b in range(raw.count.shape[0]):
+                n = int(counts[b])
+                sel = np.nonzero(valid[b, :n])[0]
+                packed = raw.packed[b, :n] if len(sel) == n else raw.packed[b, torch.from_numpy(sel).to(self.dev)]
+                out.append(_Detections(packed, scores[b, :n][sel], classes[b, :n][sel], (h, w)))
+        self._cache[ck] = out
+        return out
+
+    def clear_cache(self) -> None:
+        self._cache.clear()
+
+    # ------------------------------------------------------------------ a12
+    def _greedy_dedup(self, packed: torch.Tensor, thr: float) -> List[int]:
+        """``inference.py:1451-1459``: keep mask i unless IoU(mask_i, kept_j) > thr for a kept j."""
+        n = int(packed.shape[0])
+        alg = DeviceMaskAlgebra(self.ops, packed)
+        alg.prefetch_overlapping_pairs()
+        kept: List[int] = []
+        for i in range(n):
+            dup = False
+            for j in kept:
+                inter = alg.inter(i, j)
+                union = int(alg.area[i]) + int(alg.area[j]) - inter
+                if (inter / union if union > 0 else 0) > thr:
+                    dup = True
+                    break
+            if not dup:
+                kept.append(i)
+        return kept
+
+    # ------------------------------------------------------------------ a6 + a9 + a11 + a12
+    def _single_model_class_pass(self, det: _Detections, target_class: int, small_classes, confidence_threshold, iou_threshold):
+        sel = np.nonzero((det.classes == target_class))[0]
+        sel = sel[det.scores[sel] >= confidence_threshold]
+        if len(sel) == 0:
+            return None, [], []
+        scores = det.scores[sel]
+        masks = det.packed[torch.from_numpy(sel).to(self.dev)].contiguous()
+        is_small = target_class in small_classes
+        ccfg = self.class_specific_settings.get(f"class_{target_class}", {})
+        min_size = ccfg.get("min_size", 5 if is_small else 25)
+        processed = postprocess_masks_device(self.ops, masks, scores, min_crys_size=min_size)
+        if processed is None or processed.shape[0] == 0:
+            return None, [], []
+        if processed.shape[0] > 2 and self.parallel_mask_processing:
+            processed = process_masks_device(self.ops, processed)
+        thr = 0.5 if is_small else iou_threshold
+        keep = self._greedy_dedup(processed, thr)
+        kp = processed[torch.tensor(keep, dtype=torch.long, device=self.dev)].contiguous()
+        return kp, [scores[i] for i in keep], [target_class] * len(keep)
+
+    # ------------------------------------------------------------------ a10 + a14 (ensemble branch)
+    def _ensemble_class_pass(self, dets: Sequence[_Detections], target_class, small_classes, conf_threshold, iou_threshold):
+        all_masks, all_scores = [], []
+        is_small = target_class in small_classes
+        hw = dets[0].hw
+        for det, weight in zip(dets, self.ensemble_weights):
+            if len(det.scores) == 0:
+                continue
+            sel = np.nonzero((det.classes == target_class) & (det.scores >= conf_threshold))[0]
+            if len(sel) == 0:
+                continue
+            masks = det.packed[torch.from_numpy(sel).to(self.dev)].contiguous()
+            kept_masks, kept_idx = postprocess_masks_universal_device(self.ops, masks, hw, is_small)
+            if len(kept_idx) == 0:
+                continue
+            all_masks.append(kept_masks)
+            all_scores.extend(float(det.scores[sel][i]) * weight for i in kept_idx)
+        if not all_masks:
+            return "EMPTY_NDARRAY", [], []   # the reference returns three empty ndarrays here (N4)
+        packed = torch.cat(all_masks, dim=0)
+        return self.deduplicate_masks_smart(packed, all_scores, [target_class] * len(all_scores), iou_threshold)
+
+    # ------------------------------------------------------------------ a14
+    def deduplicate_masks_smart(self, packed: Optional[torch.Tensor], scores: Sequence[float], classes: Sequence[int],
+                                iou_threshold: float = 0.4):
+        """``inference.py:2552-2677`` bug-for-bug (N6); see oracle/postproc_ref.py for the dense twin."""
+        if packed is None or packed.shape[0] == 0:
+            return None, [], []
+        alg = DeviceMaskAlgebra(self.ops, packed)
+        cont = self.ops.contours(packed, max_contours=256, measure=False)
+        keep0 = []
+        for idx in range(alg.n):
+            if alg.bbox[idx, 0] < 0:
+                continue  # empty mask
+            if len(cont[idx]) > 0:
+                per = cont[idx][0]["perimeter"]
+                if per > 0 and (4 * np.pi * int(alg.area[idx])) / (per ** 2) < 0.15:
+                    continue
+            keep0.append(idx)
+        if not keep0:
+            return None, [], []
+        scores = [scores[i] for i in keep0]
+        classes = [classes[i] for i in keep0]
+        # stored as (y_min, y_max, x_min, x_max) ... (inference.py:2635)
+        bb = [(int(alg.bbox[i, 0]), int(alg.bbox[i, 2]), int(alg.bbox[i, 1]), int(alg.bbox[i, 3])) for i in keep0]
+
+        def overlap_literal(b1, b2):  # ... unpacked as (y_min, x_min, y_max, x_max) (inference.py:2685)
+            y1_min, x1_min, y1_max, x1_max = b1
+            y2_min, x2_min, y2_max, x2_max = b2
+            if x1_max < x2_min or x2_max < x1_min:
+                return False
+            if y1_max < y2_min or y2_max < y1_min:
+                return False
+            return True
+
+        alg.prefetch_overlapping_pairs([[keep0[i] for i in range(len(keep0)) if classes[i] == c] for c in set(classes)])
+        sorted_indices = np.argsort(np.asarray(scores, dtype=np.float64), kind="stable")[::-1]
+        keep, removed = [], set()
+        for idx in sorted_indices:
+            if idx in removed:
+                continue
+            keep.append(int(idx))
+            for other in sorted_indices[idx + 1:]:   # sliced by mask index, not rank (N6)
+                if other in removed or classes[other] != classes[idx]:
+                    continue
+                if not overlap_literal(bb[idx], bb[other]):
+                    continue
+                inter = alg.inter(keep0[idx], keep0[other])
+                if inter == 0:
+                    continue
+                union = int(alg.area[keep0[idx]]) + int(alg.area[keep0[other]]) - inter
+                if union and inter / union > iou_threshold:
+                    removed.add(int(other))
+        sel = torch.tensor([keep0[i] for i in keep], dtype=torch.long, device=self.dev)
+        return packed[sel].contiguous(), [scores[i] for i in keep], [classes[i] for i in keep]
+
+    # ------------------------------------------------------------------ a1 + a2
+    def _make_tiles(self, image_dev: torch.Tensor, tile_size: int, overlap_ratio: float):
+        h, w = int(image_dev.shape[0]), int(image_dev.shape[1])
+        stride = int(tile_size * (1 - overlap_ratio))
+        offs = [(x, y) for y in range(0, h, stride) for x in range(0, w, stride)]
+        tiles = torch.zeros((len(offs), tile_size, tile_size, 3), dtype=torch.uint8, device=self.dev)
+        for i, (x, y) in enumerate(offs):
+            ye, xe = min(y + tile_size, h), min(x + tile_size, w)
+            tiles[i, : ye - y, : xe - x] = image_dev[y:ye, x:xe]
+        return tiles, offs
+
+    # ------------------------------------------------------------------ a13 + the tile pipeline
+    def tile_based_inference_pipeline(self, model_ids: Sequence[int], image_key: str, image_dev: torch.Tensor, target_class,
+                                      small_classes, confidence_threshold, tile_size=512, overlap_ratio=0.1, upscale_factor=2.0,
+                                      iou_threshold=0.7, edge_filter_enabled=True):
+        """``inference.py:2299-2485`` for one class."""
+        h, w = int(image_dev.shape[0]), int(image_dev.shape[1])
+        if w % 32 or tile_size % 32:
+            raise ValueError("image width and tile_size must be multiples of 32 (bit-packed masks)")
+        ensemble = len(model_ids) > 1
+
+        def class_pass(dets_per_model):
+            if ensemble:
+                return self._ensemble_class_pass(dets_per_model, target_class, small_classes, confidence_threshold, iou_threshold)
+            return self._single_model_class_pass(dets_per_model[0], target_class, small_classes, confidence_threshold, iou_threshold)
+
+        full = [self._predict_batch(m, image_key + "|full", image_dev[None])[0] for m in model_ids]
+        full_masks, full_scores, full_classes = class_pass(full)
+        tiles, offs = self._make_tiles(image_dev, tile_size, overlap_ratio)
+        uh, uw = int(tile_size * upscale_factor), int(tile_size * upscale_factor)
+        if (uh, uw) != (tile_size, tile_size):
+            tiles = self.predictors[0].engine.resize_linear_u8(tiles, uh, uw)
+        if uw % 32:
+            raise ValueError("upscaled tile width must be a multiple of 32")
+        tile_dets = [self._predict_batch(m, f"{image_key}|tiles{tile_size}/{overlap_ratio}/{upscale_factor}", tiles) for m in model_ids]
+        tile_masks, tile_scores, tile_classes = [], [], []
+        edge = int(tile_size * overlap_ratio / 2)
+        for t, (x_off, y_off) in enumerate(offs):
+            tm, ts, tc = class_pass([d[t] for d in tile_dets])
+            if tm is None or isinstance(tm, str) or tm.shape[0] == 0:
+                continue
+            n = int(tm.shape[0])
+            small = self.ops.place_tiles(tm, [0] * n, [0] * n, tile_size, tile_size, tile_size, tile_size)
+            keep = list(range(n))
+            if edge_filter_enabled:
+                _, bb = self.ops.area_bbox(small)
+                bb = bb.cpu().numpy()
+                keep = [i for i in range(n) if not (bb[i, 0] < 0 or bb[i, 0] < edge or bb[i, 2] > tile_size - edge
+                                                    or bb[i, 1] < edge or bb[i, 3] > tile_size - edge)]
+            if not keep:
+                continue
+            sel = torch.tensor(keep, dtype=torch.long, device=self.dev)
+            glob = self.ops.place_tiles(small[sel].contiguous(), [x_off] * len(keep), [y_off] * len(keep), tile_size, tile_size, h, w)
+            tile_masks.append(glob)
+            tile_scores.extend(ts[i] for i in keep)
+            tile_classes.extend(tc[i] for i in keep)
+        if isinstance(full_masks, str):        # N4: ndarray + list
+            if tile_masks:
+                raise EmptyEnsembleTypeError("operands could not be broadcast together (empty ensemble result + tile masks)")
+            return None, [], []
+        parts = ([full_masks] if full_masks is not None and full_masks.shape[0] else []) + tile_masks
+        if not parts:
+            return None, [], []
+        packed = torch.cat(parts, dim=0)
+        return self.deduplicate_masks_smart(packed, list(full_scores) + list(tile_scores), list(full_classes) + list(tile_classes), 0.4)
+
+    # ------------------------------------------------------------------ a8
+    def calculate_average_mask_sizes(self, sample_images: Sequence[Tuple[str, torch.Tensor]]) -> Dict[int, float]:
+        """``inference.py:1626-1706``: first predictor, first <= 5 images, detections with score >= 0.7."""
+        sizes: Dict[int, List[int]] = {}
+        for key, img in sample_images[:5]:
+            det = self._predict_batch(0, key + "|full", img[None])[0]
+            conf = det.scores >= 0.7
+            if not conf.any():
+                continue
+            area, _ = self.ops.area_bbox(det.packed.contiguous())
+            area = area.cpu().numpy()
+            for a, c in zip(area[conf], det.classes[conf]):
+                sizes.setdefault(int(c), []).append(int(a))
+        return {c: float(np.mean(v)) for c, v in sizes.items() if v}
+
+
+def run_inference(dataset_name, output_dir, visualize=True, threshold=0.65, draw_id=False, dataset_format="json",
+                  draw_scalebar=False):
+    """Drop-in for ``src/functions/inference.py:499`` (same signature, outputs and skip-image semantics)."""
+    global_config = get_config()
+    dataset_config = get_config(dataset_name=dataset_name)
+    inf = dataset_config.get("inference_overrides", {}) or dataset_config.get("inference_settings", {})
+    confidence_mode = inf.get("confidence_mode", "auto")
+    class_specific_settings = inf.get("class_specific_settings", {})
+    tile_cfg = inf.get("tile_settings", {})
+    tile_size = tile_cfg.get("tile_size", 512)
+    overlap_ratio = tile_cfg.get("overlap_ratio", 0.1)
+    upscale_factor = tile_cfg.get("upscale_factor", 2.0)
+    edge_filter_enabled = tile_cfg.get("edge_filter_enabled", True)
+    ens = inf.get("ensemble_settings", {})
+    gens = global_config.get("inference_settings", {}).get("ensemble_settings", {})
+    ensemble_enabled = ens.get("enabled", gens.get("enabled", True))
+    ensemble_small_only = ens.get("small_classes_only", gens.get("small_classes_only", True))
+    classes_to_infer = inf.get("inference_settings", {}).get("classes_to_infer", None)
+    split_dir = str(Path(global_config["paths"]["split_dir"]).expanduser().resolve())
+    category_json = str(Path(global_config["paths"]["category_json"]).expanduser().resolve())
+
+    dataset_info = read_dataset_info(category_json)
+    register_datasets(dataset_info, dataset_name, dataset_format=dataset_format)
+    DatasetCatalog.get(f"{dataset_name}_train")
+    metadata = MetadataCatalog.get(f"{dataset_name}_train")
+    num_classes = len(metadata.thing_classes)
+
+    predictors, models = [], []
+    for r in (50, 101):
+        paths = get_trained_model_paths(split_dir, r)
+        if dataset_name in paths:
+            try:
+                p, _ = choose_and_use_model(paths, dataset_name, threshold, metadata, r)
+                if p is not None:
+                    p.model.eval()
+                    predictors.append(p)
+                    models.append(r)
+            except Exception as e:
+                system_logger.warning(f"Failed to load R{r} model: {e}")
+    if not predictors:
+        raise FileNotFoundError(f"No trained models found for dataset '{dataset_name}'")
+    system_logger.info(f"Loaded models: {', '.join(f'R{r}' for r in models)}")
+
+    inpath = get_image_folder_path()
+    os.makedirs(output_dir, exist_ok=True)
+    images_name = [f for f in os.listdir(inpath) if is_image_file(f)]
+    pipe = InferencePipeline(predictors, dataset_name, inf, global_config)
+    dev = pipe.dev
+    spatial_cfg = load_spatial_constraints(dataset_name)
+
+    def load(name):
+        img = imread_bgr(os.path.join(inpath, name))
+        return None if img is None else torch.from_numpy(img).to(dev)
+
+    sample = []
+    for name in images_name[:5]:
+        t = load(name)
+        if t is not None:
+            sample.append((name, t))
+    small_classes = determine_small_classes(pipe.calculate_average_mask_sizes(sample), 50)
+    system_logger.info(f"Small classes: {sorted(small_classes)}")
+
+    Img_ID, EncodedPixels = [], []
+    dedup_results: Dict[str, dict] = {}
+    processed = set()
+    t_all = time.perf_counter()
+    for gi, name in enumerate(images_name):
+        t0 = time.perf_counter()
+        log_memory_usage(f"Before image {gi + 1}/{len(images_name)}: {name}")
+        image_dev = load(name)
+        if image_dev is None:
+            system_logger.warning(f"Could not load image: {name}")
+            continue
+        try:
+            image_host = None
+            parts, all_scores, all_classes = [], [], []
+            targets = range(num_classes) if classes_to_infer is None else [c for c in classes_to_infer if c < num_classes]
+            for target_class in targets:
+                is_small = target_class in small_classes
+                ccfg = class_specific_settings.get(f"class_{target_class}", {})
+                if confidence_mode == "manual":
+                    conf = ccfg.get("confidence_threshold", 0.3 if is_small else 0.5)
+                else:
+                    if image_host is None:
+                        image_host = image_dev.cpu().numpy()
+                    conf = get_confidence_threshold(image_host, target_class, small_classes, global_config)
+                iou_thresh = ccfg.get("iou_threshold", 0.5 if is_small else 0.7)
+                use_ens = ensemble_enabled and (not ensemble_small_only or is_small)
+                model_ids = list(range(len(predictors))) if (use_ens and len(predictors) > 1) else [0]
+                m, s, c = pipe.tile_based_inference_pipeline(model_ids, name, image_dev, target_class, small_classes, conf,
+                                                             tile_size, overlap_ratio, upscale_factor, iou_thresh,
+                                                             edge_filter_enabled)
+                if m is not None and m.shape[0]:
+                    parts.append(m)
+                    all_scores.extend(s)
+                    all_classes.extend(c)
+            packed = torch.cat(parts, dim=0) if parts else None
+            packed, scores, classes = pipe.deduplicate_masks_smart(packed, all_scores, all_classes, iou_threshold=0.7)
+            if packed is not None and packed.shape[0]:
+                keep = apply_spatial_constraints_indices(DeviceMaskAlgebra(pipe.ops, packed), scores, classes, spatial_cfg)
+                packed = packed[torch.tensor(keep, dtype=torch.long, device=dev)].contiguous()
+                scores, classes = [scores[i] for i in keep], [classes[i] for i in keep]
+            n_final = 0 if packed is None else int(packed.shape[0])
+            dedup_results[name] = {"masks": packed, "scores": scores, "classes": classes,
+                                   "hw": (int(image_dev.shape[0]), int(image_dev.shape[1]))}
+            processed.add(name)
+            if n_final:
+                dense = pipe.ops.to_dense(packed, int(image_dev.shape[1]))
+                for i in range(n_final):
+                    Img_ID.append(name.rsplit(".", 1)[0])
+                    EncodedPixels.append(" ".join(map(str, rle_encoding(dense[i]))))
+                del dense
+            system_logger.info(f"Image {name}: {n_final} instances in {time.perf_counter() - t0:.2f}s")
+        except Exception as e:  # reference semantics: log, skip the image, continue (inference.py:928-931)
+            system_logger.error(f"Error processing image {name}: {e}", exc_info=True)
+        finally:
+            pipe.clear_cache()
+            log_memory_usage(f"After image {gi + 1}/{len(images_name)}: {name}")
+    total = time.perf_counter() - t_all
+    system_logger.info(f"Inference complete: {len(processed)}/{len(images_name)} images, avg "
+                       f"{total / max(len(images_name), 1):.2f}s/image, {pipe.forward_calls} batched forwards")
+    unprocessed = set(images_name) - processed
+    if unprocessed:
+        system_logger.warning(f"Unprocessed images: {sorted(unprocessed)}")
+    with open(os.path.join(output_dir, "R50_flip_results.csv"), "w", newline="") as f:
+        wri = csv.writer(f)
+        wri.writerow(["ImageId", "EncodedPixels"])
+        for a, b in zip(Img_ID, EncodedPixels):
+            wri.writerow([a, b])
+
+    write_measurements(pipe.ops, dedup_results, inpath, output_dir, metadata, dataset_name, draw_scalebar)
+    with open(os.path.join(output_dir, "class_color_legend.txt"), "w") as f:
+        f.write("Class Color Legend (BGR)\n")
+        for i, cname in enumerate(metadata.thing_classes):
+            f.write(f"Class {i} ({cname}): {CLASS_COLORS[i % len(CLASS_COLORS)]}\n")
+    return dedup_results
+
+
+def write_measurements(ops: MaskOps, dedup_results: Dict[str, dict], test_img_path: str, output_dir: str, metadata,
+                       dataset_name: str, draw_scalebar: bool = False) -> str:
+    """Measurement phase (``inference.py:983-1291``): one CSV row per external contour that passes
+    the area gate, 20 columns, ``None`` -> empty field, floats through ``csv.writer``."""
+    csv_filename = os.path.join(output_dir, "measurements_results.csv")
+    with open(csv_filename, "w", newline="") as csvfile:
+        w = csv.writer(csvfile)
+        w.writerow(CSV_HEADER)
+        for test_img in [f for f in os.listdir(test_img_path) if is_image_file(f)]:
+            data = dedup_results.get(test_img)
+            if data is None:
+                continue   # skipped image: the reference finds no masks for it (dedup_results.get(..., {}))
+            psum, um_pix = detect_scale_bar(None, roi_config=None, dataset_name=dataset_name)   # N8: the second call's values
+            packed, classes = data["masks"], data["classes"]
+            if packed is None or packed.shape[0] == 0:
+                continue
+            h, wd = data["hw"]
+            min_area = max(5, h * wd * 0.000005 * 0.05)
+            recs = ops.contours(packed, max_contours=256, um_pix=um_pix)
+            rows = []
+            for instance_id, (cls, contours) in enumerate(zip(classes, recs), 1):
+                cls = int(cls)
+                cname = metadata.thing_classes[cls] if cls < len(metadata.thing_classes) else f"class_{cls}"
+                for c in contours:
+                    if c["area"] < min_area:
+                        continue
+                    v = c["values"]
+                    rows.append([f"{test_img}_{instance_id}", cls, cname, float(v[0]), float(v[1]), float(v[2]), float(v[3]),
+                                 float(v[4]), float(v[5]), float(v[6]), float(v[7]), float(v[8]), float(v[9]), float(v[10]),
+                                 float(v[11]), None, None, None, psum, test_img])
+            for r in rows:
+                w.writerow(r)
+            csvfile.flush()
+    system_logger.info(f"Measurements complete. Results: {csv_filename}")
+    return csv_filename

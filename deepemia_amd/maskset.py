@@ -149,9 +149,10 @@ class MaskOps:
         if measure:
             wi = torch.empty((int(self.lib.demia_contour_work_ints(M, C, max_points)),), dtype=torch.int32, device=self.device)
             wf = torch.empty((int(self.lib.demia_contour_work_floats(M, C, max_points)),), dtype=torch.float32, device=self.device)
+            wd = torch.empty((int(self.lib.demia_contour_work_doubles(M, C, max_points)),), dtype=torch.float64, device=self.device)
             vals = torch.zeros((M, C, 12), dtype=torch.float64, device=self.device)
             _lib.check(self.lib.demia_contour_measure(_lib.ptr(count), _lib.ptr(info), _lib.ptr(red), _lib.ptr(points), M, C,
-                                                      max_points, _lib.ptr(wi), _lib.ptr(wf), float(um_pix), _lib.ptr(vals),
+                                                      max_points, _lib.ptr(wi), _lib.ptr(wf), _lib.ptr(wd), float(um_pix), _lib.ptr(vals),
                                                       self._stream()), "demia_contour_measure")
         cnt = counters.cpu().numpy()
         if cnt[1] != 0:

@@ -93,6 +93,7 @@ def random_d2_state_dict(
     mask_bias: float = 2.0,
     residual_gain: float = 0.25,
     head_gain: float = 30.0,
+    mask_gain: float = 1.0,
 ) -> Dict[str, torch.Tensor]:
     """Seeded random Mask R-CNN R{depth}-FPN weights in Detectron2 0.6 key layout.
 
@@ -107,7 +108,8 @@ def random_d2_state_dict(
       1.0) -- keeps the residual stream O(1) through 33 blocks.
     * ``head_gain``: multiplies the N(0, .01)/N(0, .001) std of RPN logits /
       deltas, ``cls_score`` and ``bbox_pred`` so that logits are not all ~0.
-    * ``mask_bias``: ``mask_head.predictor.bias`` (+2 -> solid masks).
+    * ``mask_bias``: ``mask_head.predictor.bias`` (+2 -> solid masks); ``mask_gain`` scales the
+      predictor weights (larger -> blobby, non-rectangular masks for the morphology tests).
     * the 1x1 / FC prediction layers (RPN logits and deltas, ``cls_score``, ``bbox_pred``)
       get zero-mean rows, so class scores are balanced and detections saturate at 100.
     """
@@ -174,7 +176,7 @@ def random_d2_state_dict(
     # ConvTranspose2d weight layout is (in, out, kh, kw)
     sd[mh + "deconv.weight"] = _kaiming_normal_fan_out((256, 256, 2, 2), g)
     sd[mh + "deconv.bias"] = torch.zeros(256)
-    sd[mh + "predictor.weight"] = torch.randn((k, 256, 1, 1), generator=g) * 0.001 * head_gain
+    sd[mh + "predictor.weight"] = zero_mean_rows(torch.randn((k, 256, 1, 1), generator=g)) * 0.001 * head_gain * mask_gain
     sd[mh + "predictor.bias"] = torch.full((k,), float(mask_bias))
     return sd
 

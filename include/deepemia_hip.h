@@ -91,6 +91,13 @@ int demia_resize_v_norm(const uint8_t* tmp, void* dst, int N, int H, int newW, i
                         const int32_t* ymin, const int32_t* ysize, const int32_t* yk, int ksy,
                         const float* mean3, int dtype, void* stream);
 
+/* a2: tile upscale, cv2.resize(tile, (w*f, h*f), INTER_LINEAR) on u8 BGR (inference.py:2379-2382) ------
+ * OpenCV's fixed-point bilinear: xofs/yofs [out, 2] i32 source indices, ialpha/ibeta [out, 2] i16
+ * 11-bit coefficients (host tables, deepemia_amd.engine.cv_linear_tables). src [N,H,W,3] -> dst [N,oh,ow,3] */
+int demia_resize_linear_u8(const uint8_t* src, uint8_t* dst, int N, int H, int W, int out_h, int out_w,
+                           const int32_t* xofs, const int16_t* ialpha, const int32_t* yofs, const int16_t* ibeta,
+                           void* stream);
+
 /* a3: ResNet stem: conv 7x7 s2 p3 (3->64) + FrozenBN + ReLU, then maxpool 3x3 s2 p1 ----
  *   in   [N, PH + 6, PW + 8, 4] f32 (see above)    w [7, 8, 4, 64] f32 (kh, kw, c, co; kw 7 and c 3 zero)
  *   mid  [N, PH/2, PW/2, 64]   out [N, PH/4, PW/4, 64]                              */
@@ -238,12 +245,13 @@ int demia_mask_place_tiles(const uint32_t* src, uint32_t* dst, const int32_t* x_
  *   CircularED, Aspect_Ratio, Circularity, Chords, Feret_diam, Roundness, Sphericity.        */
 int64_t demia_contour_work_ints(int M, int C, int max_points);
 int64_t demia_contour_work_floats(int M, int C, int max_points);
+int64_t demia_contour_work_doubles(int M, int C, int max_points);
 int demia_mask_contours(const uint32_t* masks, const uint32_t* filled, const int32_t* bbox, int M, int H, int W, int C,
                         int max_points, int32_t* count, int32_t* info, double* red, int32_t* points,
                         int32_t* counters, void* stream);
 int demia_contour_measure(const int32_t* count, const int32_t* info, const double* red, const int32_t* points, int M,
-                          int C, int max_points, int32_t* work_i, float* work_f, double um_pix, double* out,
-                          void* stream);
+                          int C, int max_points, int32_t* work_i, float* work_f, double* work_d, double um_pix,
+                          double* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,115 @@
+#!/usr/bin/env python3
+"""``main.py --task inference`` drop-in for deepEMIA (reference ``main.py:241-342,456-528``).
+
+Same flags and defaults as the reference CLI.  Only the ``inference`` task is implemented (the hot
+path this build accelerates); ``prepare`` / ``train`` / ``evaluate`` / ``setup`` are reported as out
+of scope.  Google Cloud Storage is optional: the reference shells out to ``gsutil`` unconditionally
+(``main.py:383-398,473``) and ``--download`` / ``--upload`` cannot be switched off there; here the
+GCS steps run only when ``gsutil`` exists and ``DEEPEMIA_OFFLINE`` is not set, so the CLI also runs
+on a box without network.  Inference inputs are deleted after the run only if they were downloaded.
+"""
+from __future__ import annotations
+
+import argparse
+import glob
+import logging
+import os
+import shutil
+import subprocess
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+
+def build_parser() -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser(description="deepEMIA hot path on MI355X", formatter_class=argparse.RawDescriptionHelpFormatter)
+    p.add_argument("--task", type=str, required=True, choices=["prepare", "train", "evaluate", "inference", "setup"])
+    p.add_argument("--dataset_name", type=str, required=False)
+    p.add_argument("--threshold", type=float, default=0.65)
+    p.add_argument("--dataset_format", type=str, default="json", choices=["json", "coco"])
+    p.add_argument("--visualize", action="store_true", default=False)
+    p.add_argument("--download", action="store_true", default=True)
+    p.add_argument("--upload", action="store_true", default=True)
+    p.add_argument("--id", dest="draw_id", action="store_true")
+    p.set_defaults(draw_id=False)
+    p.add_argument("--rcnn", type=str, default="101", choices=["50", "101", "combo"])
+    p.add_argument("--augment", action="store_true")
+    p.add_argument("--optimize", action="store_true")
+    p.add_argument("--n-trials", type=int, default=10)
+    p.add_argument("--verbosity", type=str, default="info", choices=["debug", "info", "warning", "error"])
+    p.add_argument("--no-gpu-check", action="store_true")
+    p.add_argument("--draw-scalebar", action="store_true", default=False)
+    return p
+
+
+def gcs_available() -> bool:
+    return not os.environ.get("DEEPEMIA_OFFLINE") and shutil.which("gsutil") is not None
+
+
+def main(argv=None) -> int:
+    args = build_parser().parse_args(argv)
+    from deepemia_amd.utils.config import get_config
+    from deepemia_amd.utils.gpu_check import check_gpu_availability, log_device_info
+    from deepemia_amd.utils.logger_utils import set_console_log_level, system_logger
+
+    set_console_log_level({"debug": logging.DEBUG, "info": logging.INFO, "warning": logging.WARNING,
+                           "error": logging.ERROR}[args.verbosity])
+    if args.task != "inference":
+        system_logger.error(f"task '{args.task}' is outside the scope of this build (inference hot path only)")
+        return 2
+    if not args.dataset_name:
+        system_logger.error("--dataset_name is required for --task inference")
+        return 2
+    config = get_config()
+    if not args.no_gpu_check:
+        log_device_info()
+    check_gpu_availability(require_gpu=True, interactive=False)
+    split_dir = Path(config["paths"]["split_dir"]).expanduser().resolve()
+    local_root = Path(config["paths"].get("local_dataset_root", "~")).expanduser().resolve()
+    category_json = Path(config["paths"]["category_json"]).expanduser().resolve()
+    bucket = config.get("bucket")
+    online = gcs_available() and bool(bucket)
+    downloaded = False
+    if online and args.download:
+        try:
+            subprocess.run(["gsutil", "cp", f"gs://{bucket}/dataset_info.json", str(category_json)], check=True)
+            inf_dir = local_root / "DATASET" / "INFERENCE"
+            if inf_dir.exists():
+                shutil.rmtree(inf_dir)
+            (local_root / "DATASET").mkdir(parents=True, exist_ok=True)
+            subprocess.run(["gsutil", "-m", "cp", "-r", f"gs://{bucket}/DATASET/INFERENCE", str(local_root / "DATASET")], check=True)
+            downloaded = True
+        except (subprocess.CalledProcessError, OSError) as e:
+            system_logger.error(f"GCS download failed: {e}")
+            raise
+    else:
+        system_logger.info("GCS disabled (no gsutil / DEEPEMIA_OFFLINE): using local dataset_info.json and DATASET/INFERENCE")
+    for pattern in ("*.png", "*.csv", "*.jpg"):     # reference main.py:462-468
+        for f in glob.glob(pattern):
+            try:
+                os.remove(f)
+            except OSError:
+                pass
+    from deepemia_amd.functions.inference import run_inference
+
+    t0 = time.perf_counter()
+    run_inference(args.dataset_name, str(split_dir), visualize=args.visualize, threshold=args.threshold, draw_id=args.draw_id,
+                  dataset_format=args.dataset_format, draw_scalebar=args.draw_scalebar)
+    system_logger.info(f"Inference task finished in {time.perf_counter() - t0:.2f}s; results in {split_dir}")
+    if online and args.upload:
+        try:
+            stamp = time.strftime("%Y%m%d_%H%M%S")
+            subprocess.run(["gsutil", "-m", "cp", str(split_dir / "*.csv"), f"gs://{bucket}/Archive/{stamp}_{args.dataset_name}/"],
+                           check=False)
+        except OSError as e:
+            system_logger.warning(f"GCS upload skipped: {e}")
+    if downloaded:
+        shutil.rmtree(local_root / "DATASET" / "INFERENCE", ignore_errors=True)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,175 @@
+"""ORACLE (test infrastructure, never shipped): dense-numpy restatement of the reference's
+per-image orchestration -- ``run_inference`` class loop (``src/functions/inference.py:789-868``),
+``tile_based_inference_pipeline`` (``2299-2485``), ``run_class_specific_inference`` (``1353-1461``),
+``run_ensemble_inference`` (``1464-1598``), the measurement phase (``1148-1230``) -- on top of
+``oracle/maskrcnn_ref.py`` (predictor) and ``oracle/postproc_ref.py`` (everything after it).
+Parity unpinned as a whole (the reference cannot be imported here: cv2 / detectron2 missing);
+its parts are pinned as their own headers say.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Sequence, Tuple
+
+import numpy as np
+
+from . import maskrcnn_ref as NN
+from . import postproc_ref as P
+
+
+def cv_resize_linear_u8(img: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
+    """cv2.resize(img, (out_w, out_h), INTER_LINEAR) on uint8 HxWxC: OpenCV's fixed-point path
+    (11-bit coefficients; vertical: (((b0*(r0>>4))>>16) + ((b1*(r1>>4))>>16) + 2) >> 2)."""
+    h, w = img.shape[:2]
+
+    def tables(n_in, n_out, vertical):
+        scale = 1.0 / (float(n_out) / float(n_in))
+        d = np.arange(n_out, dtype=np.float64)
+        f = ((d + 0.5) * scale - 0.5).astype(np.float32)
+        s = np.floor(f).astype(np.int64)
+        f = (f - s.astype(np.float32)).astype(np.float32)
+        if vertical:
+            s0, s1 = np.clip(s, 0, n_in - 1), np.clip(s + 1, 0, n_in - 1)
+        else:
+            f[s < 0] = 0.0
+            s[s < 0] = 0
+            f[s >= n_in - 1] = 0.0
+            s[s >= n_in - 1] = n_in - 1
+            s0, s1 = s, np.minimum(s + 1, n_in - 1)
+        c0 = np.rint((np.float32(1.0) - f) * np.float32(2048.0)).astype(np.int64)
+        c1 = np.rint(f * np.float32(2048.0)).astype(np.int64)
+        return s0, s1, c0, c1
+
+    x0, x1, a0, a1 = tables(w, out_w, False)
+    y0, y1, b0, b1 = tables(h, out_h, True)
+    src = img.astype(np.int64)
+    hor = src[:, x0] * a0[None, :, None] + src[:, x1] * a1[None, :, None]
+    r0, r1 = hor[y0], hor[y1]
+    v = (((b0[:, None, None] * (r0 >> 4)) >> 16) + ((b1[:, None, None] * (r1 >> 4)) >> 16) + 2) >> 2
+    return np.clip(v, 0, 255).astype(np.uint8)
+
+
+class RefPipeline:
+    def __init__(self, state_dicts: Dict[int, dict], num_classes: int, threshold: float, inf_settings: dict,
+                 global_inf_settings: dict, parallel_mask_processing: bool = True):
+        self.models = [(d, state_dicts[d]) for d in (50, 101) if d in state_dicts]
+        self.K = num_classes
+        self.threshold = threshold
+        self.inf = inf_settings
+        self.weights = list(global_inf_settings.get("ensemble_settings", {}).get("weights", {"R50": 0.6, "R101": 0.4}).values())
+        self.class_settings = inf_settings.get("class_specific_settings", {})
+        self.parallel = parallel_mask_processing
+        self._cache = {}
+        self.forward_calls = 0
+
+    def predict(self, mi: int, key, image: np.ndarray):
+        ck = (mi, key)
+        if ck not in self._cache:
+            d, sd = self.models[mi]
+            o = NN.predict(image, sd, d, self.threshold)
+            self.forward_calls += 1
+            self._cache[ck] = (o["pred_masks"].numpy(), o["scores"].numpy(), o["pred_classes"].numpy())
+        return self._cache[ck]
+
+    # inference.py:1353-1461 / 1464-1598
+    def class_pass(self, model_ids, key, image, target_class, small_classes, conf, iou_threshold):
+        hw = image.shape[:2]
+        if len(model_ids) == 1:
+            m, s, c = self.predict(model_ids[0], key, image)
+            return P.single_model_class_pass(m, s, c, hw, target_class, small_classes, conf, iou_threshold,
+                                             self.class_settings, self.parallel)
+        all_masks, all_scores = [], []
+        is_small = target_class in small_classes
+        for mi, weight in zip(model_ids, self.weights):
+            m, s, c = self.predict(mi, key, image)
+            if len(s) == 0:
+                continue
+            sel = (c == target_class) & (s >= conf)
+            for mask, score in zip(m[sel], s[sel]):
+                cleaned = P.postprocess_masks_universal(np.array([mask]), hw, is_small)
+                if cleaned:
+                    all_masks.append(cleaned[0])
+                    all_scores.append(float(score) * weight)
+        if len(all_masks) == 0:
+            return "EMPTY_NDARRAY", [], []
+        return P.deduplicate_masks_smart(all_masks, all_scores, [target_class] * len(all_masks), iou_threshold)
+
+    # inference.py:2299-2485
+    def tile_pipeline(self, model_ids, key, image, target_class, small_classes, conf, tile_size, overlap, upscale,
+                      iou_threshold, edge_filter=True):
+        h, w = image.shape[:2]
+        fm, fs, fc = self.class_pass(model_ids, (key, "full"), image, target_class, small_classes, conf, iou_threshold)
+        tiles = P.generate_tiles_with_overlap(image, tile_size, overlap)
+        tm_all, ts_all, tc_all = [], [], []
+        for ti, (tile, x_off, y_off) in enumerate(tiles):
+            th, tw = tile.shape[:2]
+            uh, uw = int(th * upscale), int(tw * upscale)
+            up = tile if (uh, uw) == (th, tw) else cv_resize_linear_u8(tile, uh, uw)
+            tm, ts, tc = self.class_pass(model_ids, (key, "tile", ti, tile_size, overlap, upscale), up, target_class,
+                                         small_classes, conf, iou_threshold)
+            if isinstance(tm, str) or len(tm) == 0:
+                continue
+            for mask, score, cls in zip(tm, ts, tc):
+                small = P.resize_nearest(np.asarray(mask).astype(np.uint8), th, tw).astype(bool)
+                if edge_filter and P.is_edge_mask(small, tile_size, overlap):
+                    continue
+                g = np.zeros((h, w), dtype=bool)
+                ye, xe = min(y_off + th, h), min(x_off + tw, w)
+                g[y_off:ye, x_off:xe] = small[: ye - y_off, : xe - x_off]
+                tm_all.append(g)
+                ts_all.append(score)
+                tc_all.append(cls)
+        if isinstance(fm, str):
+            if tm_all:
+                raise ValueError("operands could not be broadcast together")  # N4
+            return [], [], []
+        return P.deduplicate_masks_smart(list(fm) + tm_all, list(fs) + ts_all, list(fc) + tc_all, 0.4)
+
+    # inference.py:1626-1736
+    def small_classes(self, sample: Sequence[Tuple[str, np.ndarray]]):
+        sizes: Dict[int, List[int]] = {}
+        for key, img in sample[:5]:
+            m, s, c = self.predict(0, (key, "full"), img)
+            for mask, cls in zip(m[s >= 0.7], c[s >= 0.7]):
+                sizes.setdefault(int(cls), []).append(int(np.sum(mask)))
+        avg = {c: float(np.mean(v)) for c, v in sizes.items() if v}
+        if not avg:
+            return set()
+        thr = np.percentile(list(avg.values()), 50)
+        return {c for c, s in avg.items() if s <= thr}
+
+    # inference.py:789-868
+    def run_image(self, key: str, image: np.ndarray, small_classes, confidence_mode: str, spatial_cfg: dict,
+                  ensemble_enabled=True, ensemble_small_only=True):
+        tile_cfg = self.inf.get("tile_settings", {})
+        ts, ov, up = tile_cfg.get("tile_size", 512), tile_cfg.get("overlap_ratio", 0.1), tile_cfg.get("upscale_factor", 2.0)
+        edge = tile_cfg.get("edge_filter_enabled", True)
+        masks, scores, classes = [], [], []
+        for tc in range(self.K):
+            is_small = tc in small_classes
+            ccfg = self.class_settings.get(f"class_{tc}", {})
+            assert confidence_mode == "manual", "oracle pipeline covers manual confidence mode"
+            conf = ccfg.get("confidence_threshold", 0.3 if is_small else 0.5)
+            iou_t = ccfg.get("iou_threshold", 0.5 if is_small else 0.7)
+            use_ens = ensemble_enabled and (not ensemble_small_only or is_small)
+            mids = list(range(len(self.models))) if (use_ens and len(self.models) > 1) else [0]
+            m, s, c = self.tile_pipeline(mids, key, image, tc, small_classes, conf, ts, ov, up, iou_t, edge)
+            masks.extend(m)
+            scores.extend(s)
+            classes.extend(c)
+        masks, scores, classes = P.deduplicate_masks_smart(masks, scores, classes, 0.7)
+        masks, scores, classes = P.apply_spatial_constraints(masks, scores, classes, spatial_cfg)
+        self._cache.clear()
+        return masks, scores, classes
+
+
+def measurement_rows(name: str, masks, classes, thing_classes, um_pix=1.0, psum="0"):
+    """inference.py:1148-1230 -> list of 20-column rows (+ a trailing flag: ellipse fit numerically unstable)."""
+    rows = []
+    for iid, (mask, cls) in enumerate(zip(masks, classes), 1):
+        cls = int(cls)
+        for r in P.measure_mask(np.asarray(mask) > 0, um_pix):
+            rows.append([f"{name}_{iid}", cls, thing_classes[cls], r["major_axis_length"], r["minor_axis_length"], r["eccentricity"],
+                         r["Length"], r["Width"], r["CircularED"], r["Aspect_Ratio"], r["Circularity"], r["Chords"],
+                         r["Feret_diam"], r["Roundness"], r["Sphericity"], None, None, None, psum, name,
+                         r["_ellipse_unstable"]])
+    return rows

@@ -491,8 +491,51 @@ def order_points(pts: np.ndarray) -> np.ndarray:
     return np.array([tl, tr, br, bl], dtype="float32")
 
 
-def fit_ellipse(c: np.ndarray):
-    """cv2.fitEllipse (fitEllipseNoDirect, OpenCV 4.x): returns ((cx, cy), (w, h), angle), w <= h."""
+def _jacobi_lstsq(A: np.ndarray, b: np.ndarray):
+    """Least squares through a one-sided Jacobi (Hestenes) SVD -- the algorithm behind cv::SVD::compute --
+    and cv::SVD::backSubst's rule that singular values <= 2 * DBL_EPSILON * sum(w) count as zero.
+    Returns (x, singular values)."""
+    A = A.astype(np.float64).copy()
+    n, K = A.shape
+    V = np.eye(K)
+    eps = np.finfo(np.float64).eps
+    for _ in range(40):
+        changed = False
+        for p in range(K - 1):
+            for q in range(p + 1, K):
+                a = float(np.sum(A[:, p] * A[:, p]))
+                bb = float(np.sum(A[:, q] * A[:, q]))
+                g = float(np.sum(A[:, p] * A[:, q]))
+                if abs(g) <= eps * math.sqrt(a * bb):
+                    continue
+                changed = True
+                z = (bb - a) / (2.0 * g)
+                with np.errstate(over="ignore"):
+                    zz = np.float64(z) * np.float64(z)
+                t = (1.0 if z >= 0 else -1.0) / (abs(z) + math.sqrt(1.0 + zz))
+                c = 1.0 / math.sqrt(1.0 + t * t)
+                sn = c * t
+                u, v = A[:, p].copy(), A[:, q].copy()
+                A[:, p], A[:, q] = c * u - sn * v, sn * u + c * v
+                u, v = V[:, p].copy(), V[:, q].copy()
+                V[:, p], V[:, q] = c * u - sn * v, sn * u + c * v
+        if not changed:
+            break
+    w = np.sqrt(np.sum(A * A, axis=0))
+    utb = A.T @ b
+    thr = w.sum() * 2 * eps
+    x = np.zeros(K)
+    for j in range(K):
+        if w[j] > thr:
+            x += utb[j] / (w[j] * w[j]) * V[:, j]
+    return x, w
+
+
+def fit_ellipse_ex(c: np.ndarray):
+    """cv2.fitEllipse (fitEllipseNoDirect, OpenCV 4.x): ((cx, cy), (w, h), angle) with w <= h, plus a
+    flag telling that the fit is numerically unstable (OpenCV's own degenerate branch fired, or one of
+    the two least-squares systems has a singular-value ratio below 1e-6): there the result depends on
+    the rounding of the SVD, in OpenCV as much as here, and parity checks skip it."""
     pts = c.reshape(-1, 2).astype(np.float32)
     n = len(pts)
     assert n >= 5
@@ -512,20 +555,25 @@ def fit_ellipse(c: np.ndarray):
         return np.stack([-px * px, -py * py, -px * py, px, py], axis=1), px, py
 
     A, px, py = design(q)
-    w_ = np.linalg.svd(A, compute_uv=False)
-    if w_[0] * eps32 > w_[4]:
+    gfp, w5 = _jacobi_lstsq(A, np.full(n, 10000.0))
+    unstable = False
+    if w5.max() * eps32 > w5.min():
+        unstable = True
         eps = f32(s / (n * 2) * 1e-3)
         i = np.arange(n)
         ofs = np.stack([((i & 1) * 2 - 1) * eps, ((i & 2) - 1) * eps], axis=1).astype(np.float32)
         pts = (pts + ofs).astype(np.float32)
         q = (pts - np.array([cx, cy], dtype=np.float32)).astype(np.float32)
         A, px, py = design(q)
-    gfp = np.linalg.lstsq(A, np.full(n, 10000.0), rcond=None)[0]
+        gfp, w5 = _jacobi_lstsq(A, np.full(n, 10000.0))
     M = np.array([[2 * gfp[0], gfp[2]], [gfp[2], 2 * gfp[1]]])
     rp = np.zeros(5)
-    rp[:2] = np.linalg.lstsq(M, np.array([gfp[3], gfp[4]]), rcond=None)[0]
+    rp[:2], w2 = _jacobi_lstsq(M, np.array([gfp[3], gfp[4]]))
     A3 = np.stack([(px - rp[0]) ** 2, (py - rp[1]) ** 2, (px - rp[0]) * (py - rp[1])], axis=1)
-    g = np.linalg.lstsq(A3, np.ones(n), rcond=None)[0]
+    g, w3 = _jacobi_lstsq(A3, np.ones(n))
+    for wv in (w5, w2, w3):
+        if wv.max() == 0 or wv.min() / wv.max() < 1e-6:
+            unstable = True
     rp[4] = -0.5 * math.atan2(g[2], g[1] - g[0])
     t = g[2] / math.sin(-2.0 * rp[4]) if abs(g[2]) > 1e-8 else g[1] - g[0]
     rp[2] = abs(g[0] + g[1] - t)
@@ -534,10 +582,11 @@ def fit_ellipse(c: np.ndarray):
     rp[3] = abs(g[0] + g[1] + t)
     if rp[3] > 1e-8:
         rp[3] = math.sqrt(2.0 / rp[3])
-    bcx = f32(f32(rp[0] / scale) + cx)
-    bcy = f32(f32(rp[1] / scale) + cy)
-    bw = f32(rp[2] * 2 / scale)
-    bh = f32(rp[3] * 2 / scale)
+    with np.errstate(over="ignore", invalid="ignore"):
+        bcx = f32(f32(rp[0] / scale) + cx)
+        bcy = f32(f32(rp[1] / scale) + cy)
+        bw = f32(rp[2] * 2 / scale)
+        bh = f32(rp[3] * 2 / scale)
     ang = f32(0)
     if bw > bh:
         bw, bh = bh, bw
@@ -546,7 +595,11 @@ def fit_ellipse(c: np.ndarray):
         ang = f32(ang + 360)
     if ang > 360:
         ang = f32(ang - 360)
-    return (float(bcx), float(bcy)), (float(bw), float(bh)), float(ang)
+    return ((float(bcx), float(bcy)), (float(bw), float(bh)), float(ang)), unstable
+
+
+def fit_ellipse(c: np.ndarray):
+    return fit_ellipse_ex(c)[0]
 
 
 # ------------------------------------------------------------------ a18
@@ -577,8 +630,9 @@ def calculate_measurements(c: np.ndarray, um_pix: float = 1.0, pixels_per_metric
     sphericity = (2 * math.sqrt(math.pi * dimArea)) / dimPerimeter * um_pix if dimPerimeter != 0 else 0
     circularity = 4 * math.pi * (dimArea / dimPerimeter ** 2) * um_pix if dimPerimeter != 0 else 0
     feret = diaFeret * um_pix
+    unstable = False
     if len(c) >= 5:
-        _, (maj, mnr), _ = fit_ellipse(c)
+        (_, (maj, mnr), _), unstable = fit_ellipse_ex(c)
         a, b = (maj / 2.0, mnr / 2.0) if maj > mnr else (mnr / 2.0, maj / 2.0)
         ecc = math.sqrt(1 - (b ** 2 / a ** 2)) if a != 0 else 0
         maj_l, min_l = maj / pixels_per_metric * um_pix, mnr / pixels_per_metric * um_pix
@@ -587,7 +641,7 @@ def calculate_measurements(c: np.ndarray, um_pix: float = 1.0, pixels_per_metric
     return {"major_axis_length": maj_l, "minor_axis_length": min_l, "eccentricity": ecc, "Length": length,
             "Width": width, "CircularED": circ_ed, "Aspect_Ratio": aspect, "Circularity": circularity,
             "Chords": chords, "Feret_diam": feret, "Roundness": roundness, "Sphericity": sphericity,
-            "contrast_d10": None, "contrast_d50": None, "contrast_d90": None}
+            "contrast_d10": None, "contrast_d50": None, "contrast_d90": None, "_ellipse_unstable": unstable}
 
 
 def measure_mask(mask: np.ndarray, um_pix: float = 1.0) -> List[Dict[str, float]]:

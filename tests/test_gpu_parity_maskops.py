@@ -170,6 +170,8 @@ def test_contours_and_measurements_vs_oracle(ops):
             assert abs(rec["perimeter"] - P.arc_length(c)) <= 1e-9 * max(1.0, P.arc_length(c))
             exp = P.calculate_measurements(c, um_pix=0.37)
             for j, key in enumerate(keys):
+                if exp["_ellipse_unstable"] and j < 3:
+                    continue   # degenerate ellipse fit: rounding-dependent in OpenCV itself
                 e = float(exp[key])
                 assert abs(rec["values"][j] - e) <= 1e-7 * max(1.0, abs(e)), (i, key, rec["values"][j], e)
     # known answers (rectangle 10 x 20 px): area (w-1)(h-1), perimeter 2(w-1)+2(h-1)
