@@ -357,6 +357,40 @@ class InferencePipeline:
         packed = torch.cat(parts, dim=0)
         return self.deduplicate_masks_smart(packed, list(full_scores) + list(tile_scores), list(full_classes) + list(tile_classes), 0.4)
 
+    # ------------------------------------------------------------------ batch of independent tiles (configs[1] / [4])
+    def process_tile_batch(self, key: str, tiles: torch.Tensor, small_classes, class_thresholds: Dict[int, Tuple[float, float]],
+                           spatial_cfg: Optional[dict] = None, um_pix: float = 1.0, model_ids: Sequence[int] = (0,)):
+        """The per-tile unit of work of the headline metric: one batched forward for B independent
+        tiles, then per tile the class loop (a6, a9, a11, a12), the cross-class dedup (a14, 0.7), the
+        spatial constraints (a15) and the contour measurements (a17, a18).  Returns per tile
+        ``(packed_masks, scores, classes, measurement_records)`` -- everything but the CSV text."""
+        dets = [self._predict_batch(m, key, tiles) for m in model_ids]
+        h, w = int(tiles.shape[1]), int(tiles.shape[2])
+        out = []
+        for t in range(tiles.shape[0]):
+            parts, scores, classes = [], [], []
+            for cls, (conf, iou_thr) in class_thresholds.items():
+                if len(model_ids) > 1:
+                    m, s, c = self._ensemble_class_pass([d[t] for d in dets], cls, small_classes, conf, iou_thr)
+                else:
+                    m, s, c = self._single_model_class_pass(dets[0][t], cls, small_classes, conf, iou_thr)
+                if m is None or isinstance(m, str) or m.shape[0] == 0:
+                    continue
+                parts.append(m)
+                scores.extend(s)
+                classes.extend(c)
+            packed = torch.cat(parts, dim=0) if parts else None
+            packed, scores, classes = self.deduplicate_masks_smart(packed, scores, classes, iou_threshold=0.7)
+            recs = []
+            if packed is not None and packed.shape[0]:
+                if spatial_cfg is not None and spatial_cfg.get("enabled", False):
+                    keep = apply_spatial_constraints_indices(DeviceMaskAlgebra(self.ops, packed), scores, classes, spatial_cfg)
+                    packed = packed[torch.tensor(keep, dtype=torch.long, device=self.dev)].contiguous()
+                    scores, classes = [scores[i] for i in keep], [classes[i] for i in keep]
+                recs = self.ops.contours(packed, max_contours=256, um_pix=um_pix) if packed.shape[0] else []
+            out.append((packed, scores, classes, recs))
+        return out
+
     # ------------------------------------------------------------------ a8
     def calculate_average_mask_sizes(self, sample_images: Sequence[Tuple[str, torch.Tensor]]) -> Dict[int, float]:
         """``inference.py:1626-1706``: first predictor, first <= 5 images, detections with score >= 0.7."""
