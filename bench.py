@@ -28,10 +28,16 @@ import torch
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}  # dense MFMA peaks, MI355X_MICROARCH.md
 
 
+CLASS_THRESHOLDS = {0: (0.3, 0.7), 1: (0.3, 0.5)}   # class -> (confidence, IoU) as in config.yaml class_0 / class_1
+SMALL_CLASSES = {1}
+
+
 def cpu_baseline(depth: int, size: int, thr: float, sd) -> dict:
-    """Time the CPU oracle (a port of the reference's Detectron2 CPU path) on one tile."""
+    """Time the CPU oracle (a port of the reference's CPU path: Detectron2 predictor restatement +
+    the dense numpy/scipy post-processing and measurements) on one tile."""
     from deepemia_amd import synth
     from oracle import maskrcnn_ref
+    from oracle import postproc_ref as P
 
     img = synth.em_tile(0, size)
     try:
@@ -41,10 +47,21 @@ def cpu_baseline(depth: int, size: int, thr: float, sd) -> dict:
     torch.set_num_threads(max(1, min(16, ncpu)))  # the GPU box gives one GPU a 16-core share
     t0 = time.perf_counter()
     out = maskrcnn_ref.predict(img, sd, depth, thr)
+    t1 = time.perf_counter()
+    pm, ps, pc = out["pred_masks"].numpy(), out["scores"].numpy(), out["pred_classes"].numpy()
+    masks, scores, classes = [], [], []
+    for cls, (conf, iou_thr) in CLASS_THRESHOLDS.items():
+        m, s, c = P.single_model_class_pass(pm, ps, pc, img.shape[:2], cls, SMALL_CLASSES, conf, iou_thr, None, True)
+        masks += list(m)
+        scores += list(s)
+        classes += list(c)
+    masks, scores, classes = P.deduplicate_masks_smart(masks, scores, classes, 0.7)
+    rows = sum(len(P.measure_mask(np.asarray(m) > 0)) for m in masks)
     dt = time.perf_counter() - t0
     return {"value": 1.0 / dt, "unit": "tiles/s", "cores": int(torch.get_num_threads()), "kind": "port",
-            "sample": f"1 synthetic {size}x{size} tile, R{depth}-FPN fp32 torch-CPU restatement of "
-                      f"DefaultPredictor (oracle/maskrcnn_ref.py), {int(out['scores'].shape[0])} instances, {dt:.1f} s"}
+            "sample": f"1 synthetic {size}x{size} tile through the whole per-tile path (R{depth}-FPN fp32 torch-CPU restatement "
+                      f"of DefaultPredictor, oracle/maskrcnn_ref.py: {t1 - t0:.1f} s; class loop + mask morphology + dedup + contour "
+                      f"measurements, oracle/postproc_ref.py: {dt - (t1 - t0):.1f} s); {len(masks)} instances, {rows} CSV rows"}
 
 
 def main() -> None:
@@ -58,6 +75,7 @@ def main() -> None:
     ap.add_argument("--size", type=int, default=2048)
     ap.add_argument("--threshold", type=float, default=0.3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--forward-only", action="store_true", help="time predictor(tile) only, without the per-tile post-processing")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -73,11 +91,14 @@ def main() -> None:
         torch.cuda.set_device(0)
     dev = f"cuda:{local_rank if world > 1 else 0}"
 
-    from deepemia_amd import synth
+    from deepemia_amd import parallel, synth
     from deepemia_amd.engine import MaskRCNNEngine
+    from deepemia_amd.functions.inference import InferencePipeline
+    from deepemia_amd.predictor import Predictor
 
     sd = synth.random_d2_state_dict(args.depth, 2, seed=0)
     eng = MaskRCNNEngine(sd, args.depth, 2, args.threshold, dev, args.precision)
+    pipe = InferencePipeline([Predictor(eng)], "bench", {}, {})
     tiles = np.stack([synth.em_tile(rank * args.batch + i, args.size) for i in range(args.batch)])
     x = torch.from_numpy(tiles).to(dev)
 
@@ -87,18 +108,42 @@ def main() -> None:
             dist.barrier()
             torch.cuda.synchronize()
 
+    def step(i):
+        """One pass of the hot path over this rank's batch of tiles."""
+        if args.forward_only:
+            raw = eng.forward(x)
+            return int(raw.count.sum().item()), 0
+        pipe.clear_cache()
+        res = pipe.process_tile_batch(f"step{i}", x, SMALL_CLASSES, CLASS_THRESHOLDS)
+        n_inst = sum(0 if r[0] is None else int(r[0].shape[0]) for r in res)
+        n_rows = sum(len(c) for r in res for c in r[3])
+        if dist is not None:
+            # the one exchange of the path: instance tables of every rank's tiles (unit id = global tile index)
+            parts = [r[0] for r in res if r[0] is not None and r[0].shape[0]]
+            packed = torch.cat(parts) if parts else None
+            scores = [s_ for r in res for s_ in r[1]]
+            classes = [c_ for r in res for c_ in r[2]]
+            units = [rank * args.batch + t for t, r in enumerate(res) for _ in r[1]]
+            if packed is not None:
+                a, b = pipe.ops.area_bbox(packed)
+                hdr, pay = parallel.encode_instance_table(packed, scores, classes, units, b.cpu().numpy(), a.cpu().numpy())
+            else:
+                hdr = torch.zeros((0, 8), dtype=torch.int32, device=dev)
+                pay = torch.zeros((0,), dtype=torch.int32, device=dev)
+            parallel.all_gather_instance_tables(hdr, pay)
+        return n_inst, n_rows
+
     det_total = 0
-    for _ in range(args.warmup):
-        raw = eng.forward(x)
+    for i in range(args.warmup):
+        step(-1 - i)
     sync_all()
     eng.conv_events = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        raw = eng.forward(x)
+    for i in range(args.steps):
+        det_total, rows_total = step(i)
     sync_all()
     dt = time.perf_counter() - t0
     events, eng.conv_events = eng.conv_events, None
-    det_total = int(raw.count.sum().item())
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -116,10 +161,13 @@ def main() -> None:
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"configs[1]: R{args.depth}-FPN, {args.size}x{args.size} synthetic EM tiles, "
-                                   f"{args.batch} tiles per GPU per step, resize 800 -> backbone/FPN/RPN/ROI heads -> "
-                                   f"mask paste to bit-packed {args.size}^2 masks; random-init Detectron2-layout weights, "
-                                   f"K=2, threshold {args.threshold}",
-                       "tiles_per_step_per_gpu": args.batch, "detections_last_step_rank0": det_total},
+                                   f"{args.batch} tiles per GPU per step; per tile: resize 800 -> backbone/FPN/RPN/ROI heads -> mask paste to "
+                                   f"bit-packed {args.size}^2 masks" + ("" if args.forward_only else " -> class loop (fill holes, closing, overlap "
+                                   "removal, component test, opening, greedy IoU dedup) -> cross-class dedup -> contour trace + 12 measurements") +
+                                   f"; random-init Detectron2-layout weights, K=2, threshold {args.threshold}"
+                                   + ("; all-gather of instance tables over ranks" if world > 1 and not args.forward_only else ""),
+                       "tiles_per_step_per_gpu": args.batch, "instances_last_step_rank0": det_total,
+                       "csv_rows_last_step_rank0": rows_total, "stage": "predictor only" if args.forward_only else "whole per-tile path"},
             "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (implicit-GEMM conv, all tile configs)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "launches_per_step": launches // max(args.steps, 1),
