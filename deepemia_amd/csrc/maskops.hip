@@ -130,10 +130,14 @@ __global__ void morph_cross_kernel(const uint32_t* __restrict__ in, uint32_t* __
 }
 
 // ---- sequential overlap removal across the masks of one call (score order) -----------------------
-__global__ void overlap_prefix_kernel(uint32_t* __restrict__ masks, int M, long words_per_mask) {
+// seg (optional): segment id per mask, non-decreasing; the accumulator restarts at every segment
+// boundary, so the masks of many (tile, class) calls are processed by ONE launch.
+__global__ void overlap_prefix_kernel(uint32_t* __restrict__ masks, const int* __restrict__ seg, int M, long words_per_mask) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < words_per_mask; i += (long)gridDim.x * blockDim.x) {
         uint32_t seen = 0u;
+        int cur = seg ? seg[0] : 0;
         for (int m = 0; m < M; ++m) {
+            if (seg && seg[m] != cur) { cur = seg[m]; seen = 0u; }
             const uint32_t c = masks[m * words_per_mask + i];
             masks[m * words_per_mask + i] = c & ~seen;
             seen |= c;
@@ -208,14 +212,23 @@ __global__ __launch_bounds__(1024) void components_gt1_kernel(const uint32_t* __
 }
 
 // ---- per-column pixel counts over all masks of a call (counts must be zeroed by the caller) ------
-__global__ void column_counts_kernel(const uint32_t* __restrict__ masks, long rows, int W, int* __restrict__ counts) {
+// seg (optional): segment id per mask; counts is [S, W], one row per segment.
+__global__ void column_counts_kernel(const uint32_t* __restrict__ masks, const int* __restrict__ seg, long rows, int H, int W,
+                                     int* __restrict__ counts) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= W) return;
     const int wpr = W >> 5, wx = x >> 5, b = x & 31;
     const long r0 = (long)blockIdx.y * 512, r1 = min(r0 + 512, rows);
     int c = 0;
-    for (long r = r0; r < r1; ++r) c += (masks[r * wpr + wx] >> b) & 1u;
-    if (c) atomicAdd(&counts[x], c);
+    int cur = seg ? seg[r0 / H] : 0;
+    for (long r = r0; r < r1; ++r) {
+        if (seg) {
+            const int sg = seg[r / H];
+            if (sg != cur) { if (c) atomicAdd(&counts[(long)cur * W + x], c); c = 0; cur = sg; }
+        }
+        c += (masks[r * wpr + wx] >> b) & 1u;
+    }
+    if (c) atomicAdd(&counts[(long)cur * W + x], c);
 }
 
 // ---- |a & b| for a list of pairs: block per pair over the bbox intersection ----------------------
@@ -302,11 +315,11 @@ extern "C" int demia_mask_morph_cross(const uint32_t* in, uint32_t* out, int64_t
     return DEMIA_OK;
 }
 
-extern "C" int demia_mask_overlap_prefix(uint32_t* masks, int64_t M, int H, int W, void* stream) {
+extern "C" int demia_mask_overlap_prefix(uint32_t* masks, const int32_t* seg, int64_t M, int H, int W, void* stream) {
     DEMIA_REQUIRE(masks && W % 32 == 0, "args");
     const long wpm = (long)H * (W / 32);
     if (M == 0 || wpm == 0) return DEMIA_OK;
-    hipLaunchKernelGGL(overlap_prefix_kernel, dim3(grid_for(wpm, 256)), dim3(256), 0, (hipStream_t)stream, masks, (int)M, wpm);
+    hipLaunchKernelGGL(overlap_prefix_kernel, dim3(grid_for(wpm, 256)), dim3(256), 0, (hipStream_t)stream, masks, seg, (int)M, wpm);
     DEMIA_CHECK_LAUNCH("overlap_prefix_kernel");
     return DEMIA_OK;
 }
@@ -320,13 +333,14 @@ extern "C" int demia_mask_components_gt1(const uint32_t* in, uint32_t* scratch, 
     return DEMIA_OK;
 }
 
-extern "C" int demia_mask_column_counts(const uint32_t* masks, int64_t M, int H, int W, int32_t* counts, void* stream) {
+extern "C" int demia_mask_column_counts(const uint32_t* masks, const int32_t* seg, int64_t M, int H, int W, int32_t* counts,
+                                        void* stream) {
     DEMIA_REQUIRE(masks && counts && W % 32 == 0, "args");
     if (W == 0) return DEMIA_OK;
     const long rows = (long)M * H;
     if (rows == 0) return DEMIA_OK;
-    hipLaunchKernelGGL(column_counts_kernel, dim3(cdiv(W, 256), cdiv(rows, 512)), dim3(256), 0, (hipStream_t)stream, masks, rows,
-                       W, counts);
+    hipLaunchKernelGGL(column_counts_kernel, dim3(cdiv(W, 256), cdiv(rows, 512)), dim3(256), 0, (hipStream_t)stream, masks, seg, rows,
+                       H, W, counts);
     DEMIA_CHECK_LAUNCH("column_counts_kernel");
     return DEMIA_OK;
 }

@@ -358,14 +358,10 @@ class InferencePipeline:
         return self.deduplicate_masks_smart(packed, list(full_scores) + list(tile_scores), list(full_classes) + list(tile_classes), 0.4)
 
     # ------------------------------------------------------------------ batch of independent tiles (configs[1] / [4])
-    def process_tile_batch(self, key: str, tiles: torch.Tensor, small_classes, class_thresholds: Dict[int, Tuple[float, float]],
-                           spatial_cfg: Optional[dict] = None, um_pix: float = 1.0, model_ids: Sequence[int] = (0,)):
-        """The per-tile unit of work of the headline metric: one batched forward for B independent
-        tiles, then per tile the class loop (a6, a9, a11, a12), the cross-class dedup (a14, 0.7), the
-        spatial constraints (a15) and the contour measurements (a17, a18).  Returns per tile
-        ``(packed_masks, scores, classes, measurement_records)`` -- everything but the CSV text."""
+    def process_tile_batch_unbatched(self, key: str, tiles: torch.Tensor, small_classes, class_thresholds: Dict[int, Tuple[float, float]],
+                                     spatial_cfg: Optional[dict] = None, um_pix: float = 1.0, model_ids: Sequence[int] = (0,)):
+        """Reference-shaped loop (tile by tile, class by class) -- kept as the checker of the batched version below."""
         dets = [self._predict_batch(m, key, tiles) for m in model_ids]
-        h, w = int(tiles.shape[1]), int(tiles.shape[2])
         out = []
         for t in range(tiles.shape[0]):
             parts, scores, classes = [], [], []
@@ -389,6 +385,174 @@ class InferencePipeline:
                     scores, classes = [scores[i] for i in keep], [classes[i] for i in keep]
                 recs = self.ops.contours(packed, max_contours=256, um_pix=um_pix) if packed.shape[0] else []
             out.append((packed, scores, classes, recs))
+        return out
+
+    def _single_class_pass_batched(self, dets: Sequence[_Detections], target_class: int, small_classes, conf, iou_threshold):
+        """a6 + a9 + a11 + a12 for ONE class over MANY tiles with one launch per kernel: the masks of all tiles are
+        concatenated and carry a segment id (tile index); overlap removal and column counts are segment-aware, every
+        other kernel is per mask anyway.  Returns per tile (index tensor into the returned big tensor, scores)."""
+        T = len(dets)
+        dev = self.dev
+        sels, parts = [], []
+        for det in dets:
+            sel = np.nonzero(det.classes == target_class)[0]
+            sel = sel[det.scores[sel] >= conf]
+            sels.append(sel)
+            if len(sel):
+                parts.append(det.packed[torch.from_numpy(sel).to(dev)])
+        lens = [len(x) for x in sels]
+        empty = [([], []) for _ in range(T)]
+        if sum(lens) == 0:
+            return None, empty
+        packed = torch.cat(parts, dim=0)
+        is_small = target_class in small_classes
+        min_size = self.class_specific_settings.get(f"class_{target_class}", {}).get("min_size", 5 if is_small else 25)
+        seg_np = np.repeat(np.arange(T, dtype=np.int32), lens)
+        seg = torch.from_numpy(seg_np).to(dev)
+        ncols = (self.ops.column_counts(packed, seg, T) > min_size).sum(dim=1).cpu().numpy()
+        keep_idx, new_lens, start = [], [0] * T, 0
+        for t in range(T):
+            n = lens[t]
+            if n:
+                sc = dets[t].scores[sels[t]]
+                if bool(sc.all()) < 0.5:
+                    n_keep = 0                                   # `ori_score.all() < score_threshold` (mask_utils.py:59)
+                else:
+                    n_keep = n if ncols[t] >= n else int(ncols[t])  # the column-count truncation quirk (62-68)
+                keep_idx.extend(range(start, start + n_keep))
+                new_lens[t] = n_keep
+            start += n
+        if sum(new_lens) == 0:
+            return None, empty
+        if len(keep_idx) != packed.shape[0]:
+            packed = packed[torch.tensor(keep_idx, dtype=torch.long, device=dev)].contiguous()
+            seg_np = np.repeat(np.arange(T, dtype=np.int32), new_lens)
+            seg = torch.from_numpy(seg_np).to(dev)
+        closed = self.ops.erode(self.ops.dilate(self.ops.fill_holes(packed)))
+        self.ops.overlap_prefix_(closed, seg)
+        closed[self.ops.components_gt1(closed).bool()] = 0
+        if self.parallel_mask_processing:
+            big = np.nonzero(np.asarray(new_lens)[seg_np] > 2)[0]
+            if len(big) == closed.shape[0]:
+                closed = process_masks_device(self.ops, closed)
+            elif len(big):
+                bi = torch.from_numpy(big).to(dev)
+                closed[bi] = process_masks_device(self.ops, closed[bi].contiguous())
+        thr = 0.5 if is_small else iou_threshold
+        alg = DeviceMaskAlgebra(self.ops, closed)
+        bounds = np.concatenate(([0], np.cumsum(new_lens)))
+        alg.prefetch_overlapping_pairs([list(range(bounds[t], bounds[t + 1])) for t in range(T) if new_lens[t] > 1])
+        out = []
+        for t in range(T):
+            kept: List[int] = []
+            for i in range(bounds[t], bounds[t + 1]):
+                dup = False
+                for j in kept:
+                    inter = alg.inter(i, j)
+                    union = int(alg.area[i]) + int(alg.area[j]) - inter
+                    if (inter / union if union > 0 else 0) > thr:
+                        dup = True
+                        break
+                if not dup:
+                    kept.append(i)
+            sc = dets[t].scores[sels[t]] if lens[t] else []
+            out.append((kept, [sc[i - bounds[t]] for i in kept]))
+        return closed, out
+
+    def process_tile_batch(self, key: str, tiles: torch.Tensor, small_classes, class_thresholds: Dict[int, Tuple[float, float]],
+                           spatial_cfg: Optional[dict] = None, um_pix: float = 1.0, model_ids: Sequence[int] = (0,)):
+        """The per-tile unit of work of the headline metric: one batched forward for B independent tiles, then per
+        tile the class loop (a6, a9, a11, a12), the cross-class dedup (a14, 0.7), the spatial constraints (a15) and the
+        contour measurements (a17, a18).  Every kernel is launched ONCE for all tiles (segment-aware where the
+        reference's loop carries state), so 256 CUs see hundreds of masks per launch instead of a few dozen.
+        Same results as :meth:`process_tile_batch_unbatched`.  Returns per tile ``(packed, scores, classes, records)``."""
+        if len(model_ids) > 1:
+            return self.process_tile_batch_unbatched(key, tiles, small_classes, class_thresholds, spatial_cfg, um_pix, model_ids)
+        dets = self._predict_batch(model_ids[0], key, tiles)
+        T, dev = len(dets), self.dev
+        per_tile_parts: List[List[torch.Tensor]] = [[] for _ in range(T)]
+        per_tile_scores: List[list] = [[] for _ in range(T)]
+        per_tile_classes: List[list] = [[] for _ in range(T)]
+        for cls, (conf, iou_thr) in class_thresholds.items():
+            big, res = self._single_class_pass_batched(dets, cls, small_classes, conf, iou_thr)
+            if big is None:
+                continue
+            for t, (kept, sc) in enumerate(res):
+                if kept:
+                    per_tile_parts[t].append(big[torch.tensor(kept, dtype=torch.long, device=dev)])
+                    per_tile_scores[t].extend(sc)
+                    per_tile_classes[t].extend([cls] * len(kept))
+        # ---- cross-class dedup (a14) for all tiles: one contour launch, one pair-count launch -------------------
+        lens = [sum(int(p.shape[0]) for p in per_tile_parts[t]) for t in range(T)]
+        out = [(None, [], [], []) for _ in range(T)]
+        if sum(lens) == 0:
+            return out
+        allp = torch.cat([p for t in range(T) for p in per_tile_parts[t]], dim=0)
+        bounds = np.concatenate(([0], np.cumsum(lens)))
+        alg = DeviceMaskAlgebra(self.ops, allp)
+        cont = self.ops.contours(allp, max_contours=256, measure=False)
+        keep0_all, groups = [], []
+        for t in range(T):
+            k0 = []
+            for idx in range(bounds[t], bounds[t + 1]):
+                if alg.bbox[idx, 0] < 0:
+                    continue
+                if len(cont[idx]) > 0:
+                    per = cont[idx][0]["perimeter"]
+                    if per > 0 and (4 * np.pi * int(alg.area[idx])) / (per ** 2) < 0.15:
+                        continue
+                k0.append(idx)
+            keep0_all.append(k0)
+            cl = [per_tile_classes[t][i - bounds[t]] for i in k0]
+            for c in set(cl):
+                g = [k0[i] for i in range(len(k0)) if cl[i] == c]
+                if len(g) > 1:
+                    groups.append(g)
+        alg.prefetch_overlapping_pairs(groups)
+        final_idx: List[List[int]] = []
+        for t in range(T):
+            k0 = keep0_all[t]
+            scores = [per_tile_scores[t][i - bounds[t]] for i in k0]
+            classes = [per_tile_classes[t][i - bounds[t]] for i in k0]
+            bb = [(int(alg.bbox[i, 0]), int(alg.bbox[i, 2]), int(alg.bbox[i, 1]), int(alg.bbox[i, 3])) for i in k0]
+            keep, removed = [], set()
+            if k0:
+                order = np.argsort(np.asarray(scores, dtype=np.float64), kind="stable")[::-1]
+                for idx in order:
+                    if idx in removed:
+                        continue
+                    keep.append(int(idx))
+                    for other in order[idx + 1:]:
+                        if other in removed or classes[other] != classes[idx]:
+                            continue
+                        b1, b2 = bb[idx], bb[other]
+                        if b1[3] < b2[1] or b2[3] < b1[1] or b1[2] < b2[0] or b2[2] < b1[0]:
+                            continue                       # the mixed-axis pre-filter of N6, literally
+                        inter = alg.inter(k0[idx], k0[other])
+                        if inter == 0:
+                            continue
+                        union = int(alg.area[k0[idx]]) + int(alg.area[k0[other]]) - inter
+                        if union and inter / union > 0.7:
+                            removed.add(int(other))
+            gl = [k0[i] for i in keep]
+            sc, cl = [scores[i] for i in keep], [classes[i] for i in keep]
+            if gl and spatial_cfg is not None and spatial_cfg.get("enabled", False):
+                sub = allp[torch.tensor(gl, dtype=torch.long, device=dev)].contiguous()
+                kk = apply_spatial_constraints_indices(DeviceMaskAlgebra(self.ops, sub), sc, cl, spatial_cfg)
+                gl, sc, cl = [gl[i] for i in kk], [sc[i] for i in kk], [cl[i] for i in kk]
+            final_idx.append(gl)
+            out[t] = (None, sc, cl, [])
+        flat = [i for gl in final_idx for i in gl]
+        if not flat:
+            return out
+        finalp = allp[torch.tensor(flat, dtype=torch.long, device=dev)].contiguous()
+        recs = self.ops.contours(finalp, max_contours=256, um_pix=um_pix)
+        pos = 0
+        for t in range(T):
+            n = len(final_idx[t])
+            if n:
+                out[t] = (finalp[pos:pos + n], out[t][1], out[t][2], recs[pos:pos + n])
+            pos += n
         return out
 
     # ------------------------------------------------------------------ a8

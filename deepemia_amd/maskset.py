@@ -53,11 +53,14 @@ class MaskOps:
                                                  self._stream()), "demia_mask_area_bbox")
         return area, bbox
 
-    def column_counts(self, packed: torch.Tensor) -> torch.Tensor:
+    def column_counts(self, packed: torch.Tensor, seg: Optional[torch.Tensor] = None, n_seg: int = 1) -> torch.Tensor:
+        """Per-column pixel counts over all masks ([W]), or per segment ([n_seg, W]) when ``seg`` (int32,
+        non-decreasing segment id per mask) is given."""
         M, H, wpr = packed.shape
-        counts = torch.zeros((wpr * 32,), dtype=torch.int32, device=self.device)
-        _lib.check(self.lib.demia_mask_column_counts(_lib.ptr(packed), M, H, wpr * 32, _lib.ptr(counts), self._stream()),
-                   "demia_mask_column_counts")
+        shape = (wpr * 32,) if seg is None else (n_seg, wpr * 32)
+        counts = torch.zeros(shape, dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.demia_mask_column_counts(_lib.ptr(packed), _lib.ptr(seg), M, H, wpr * 32, _lib.ptr(counts),
+                                                     self._stream()), "demia_mask_column_counts")
         return counts
 
     def pair_intersections(self, a: torch.Tensor, b: torch.Tensor, bbox_a: torch.Tensor, bbox_b: torch.Tensor,
@@ -97,9 +100,10 @@ class MaskOps:
     def dilate(self, packed: torch.Tensor) -> torch.Tensor:
         return self._morph(packed, 1)
 
-    def overlap_prefix_(self, packed: torch.Tensor) -> torch.Tensor:
+    def overlap_prefix_(self, packed: torch.Tensor, seg: Optional[torch.Tensor] = None) -> torch.Tensor:
         M, H, wpr = packed.shape
-        _lib.check(self.lib.demia_mask_overlap_prefix(_lib.ptr(packed), M, H, wpr * 32, self._stream()), "demia_mask_overlap_prefix")
+        _lib.check(self.lib.demia_mask_overlap_prefix(_lib.ptr(packed), _lib.ptr(seg), M, H, wpr * 32, self._stream()),
+                   "demia_mask_overlap_prefix")
         return packed
 
     def components_gt1(self, packed: torch.Tensor, bbox: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -218,13 +218,15 @@ int demia_mask_area_bbox(const uint32_t* packed, int32_t* area, int32_t* bbox, i
  *                                                              spatial_constraints.py:143, 186)
  *   place_tiles     cv2.resize(mask, (tile_w, tile_h), INTER_NEAREST) + paste into a zero (H, W)
  *                   frame at (x_off, y_off)                   (inference.py:2399-2420)
- * bbox = [M, 4] i32 (y0, x0, y1, x1) inclusive, -1 for empty masks (demia_mask_area_bbox).    */
+ * bbox = [M, 4] i32 (y0, x0, y1, x1) inclusive, -1 for empty masks (demia_mask_area_bbox).
+ * seg (overlap_prefix, column_counts): NULL, or a non-decreasing segment id per mask so that the masks of
+ * many (tile, class) calls share ONE launch; column_counts then fills counts[S, W] (pre-zeroed).   */
 int demia_mask_fill_holes(const uint32_t* in, uint32_t* out, const int32_t* bbox, int64_t M, int H, int W, void* stream);
 int demia_mask_morph_cross(const uint32_t* in, uint32_t* out, int64_t M, int H, int W, int dilate, void* stream);
-int demia_mask_overlap_prefix(uint32_t* masks, int64_t M, int H, int W, void* stream);
+int demia_mask_overlap_prefix(uint32_t* masks, const int32_t* seg, int64_t M, int H, int W, void* stream);
 int demia_mask_components_gt1(const uint32_t* in, uint32_t* scratch, const int32_t* bbox, int32_t* flag,
                               int64_t M, int H, int W, void* stream);
-int demia_mask_column_counts(const uint32_t* masks, int64_t M, int H, int W, int32_t* counts, void* stream);
+int demia_mask_column_counts(const uint32_t* masks, const int32_t* seg, int64_t M, int H, int W, int32_t* counts, void* stream);
 int demia_mask_pair_intersections(const uint32_t* a, const uint32_t* b, const int32_t* pi, const int32_t* pj,
                                   const int32_t* bbox_a, const int32_t* bbox_b, int32_t* out, int64_t P,
                                   int H, int W, void* stream);

@@ -144,3 +144,34 @@ def test_cli_inference_matches_oracle_pipeline(case, tmp_path, monkeypatch, gpu_
         ref_masks[n] = m
         ref_rows.extend(PR.measurement_rows(n, m, c, CLASSES))
     _compare(split, images, ref_rows, ref_masks)
+
+
+def test_batched_tile_pipeline_equals_tile_by_tile(gpu_device):
+    """process_tile_batch launches every kernel once for all tiles (segment-aware); it must give exactly what the
+    reference-shaped tile-by-tile, class-by-class loop gives -- at the full 2048^2 tile size of BASELINE configs[1]."""
+    from deepemia_amd import synth
+    from deepemia_amd.engine import MaskRCNNEngine
+    from deepemia_amd.functions.inference import InferencePipeline
+    from deepemia_amd.predictor import Predictor
+
+    sd = synth.random_d2_state_dict(50, 2, seed=0, mask_bias=0.5, mask_gain=6.0)
+    pipe = InferencePipeline([Predictor(MaskRCNNEngine(sd, 50, 2, 0.3, gpu_device, "f32"))], "t", {}, {})
+    x = torch.from_numpy(np.stack([synth.em_tile(60 + i, 2048) for i in range(3)])).to(gpu_device)
+    thr = {0: (0.3, 0.7), 1: (0.35, 0.5)}
+    spatial = {"enabled": True, "containment_rules": {}, "overlap_rules": {0: {"allow_overlap": False, "max_iou_threshold": 0.3}}}
+    a = pipe.process_tile_batch("k", x, {1}, thr, spatial_cfg=spatial, um_pix=0.5)
+    b = pipe.process_tile_batch_unbatched("k", x, {1}, thr, spatial_cfg=spatial, um_pix=0.5)
+    assert len(a) == len(b) == 3
+    total = 0
+    for (pa, sa, ca, ra), (pb, sb, cb, rb) in zip(a, b):
+        assert (pa is None) == (pb is None)
+        if pa is None:
+            continue
+        assert torch.equal(pa, pb) and sa == sb and ca == cb and len(ra) == len(rb)
+        total += pa.shape[0]
+        for ia, ib in zip(ra, rb):
+            assert len(ia) == len(ib)
+            for u, v in zip(ia, ib):
+                assert np.array_equal(u["points"], v["points"]) and u["area"] == v["area"]
+                assert np.array_equal(u["values"], v["values"])
+    assert total > 50
