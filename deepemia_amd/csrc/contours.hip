@@ -22,12 +22,16 @@ namespace {
 __constant__ int c_dx[8] = {1, 1, 0, -1, -1, -1, 0, 1};
 __constant__ int c_dy[8] = {0, -1, -1, -1, 0, 1, 1, 1};
 
+// Bit image of one mask restricted to its bbox region [ry0, ry0+rh) x word columns [wx0, wx0+rw): everything
+// outside the region is background by construction, so probes there return 0 without touching memory.
+// `p` points at the region's first word (LDS copy when it fits, else the mask in HBM/L2), `stride` = words per row.
 struct BitImg {
     const uint32_t* p;
-    int H, W, wpr;
+    int H, W, stride, ry0, wx0, rh, rw;
     __device__ __forceinline__ int get(int x, int y) const {
-        if ((unsigned)x >= (unsigned)W || (unsigned)y >= (unsigned)H) return 0;
-        return (p[(long)y * wpr + (x >> 5)] >> (x & 31)) & 1u;
+        const int ly = y - ry0, lx = (x >> 5) - wx0;
+        if (x < 0 || (unsigned)ly >= (unsigned)rh || (unsigned)lx >= (unsigned)rw) return 0;
+        return (p[ly * stride + lx] >> (x & 31)) & 1u;
     }
 };
 
@@ -93,6 +97,7 @@ __device__ TraceResult trace_border(const BitImg& im, int sx, int sy, int* __res
 }
 
 constexpr int CAND_MAX = 4096;
+constexpr int TRACE_LDS_WORDS = 12288;   // 48 KiB region image (e.g. 384 rows x 1024 px)
 
 struct ContourP {
     const uint32_t* masks;
@@ -110,28 +115,37 @@ struct ContourP {
 __global__ __launch_bounds__(256) void contour_trace_kernel(const ContourP p) {
     __shared__ int cand[CAND_MAX];
     __shared__ int ncand, ncont;
+    __shared__ uint32_t region[TRACE_LDS_WORDS];
     const int m = blockIdx.x, tid = threadIdx.x;
     const int wpr = p.W >> 5;
-    BitImg im{p.masks + (long)m * p.H * wpr, p.H, p.W, wpr};
+    const uint32_t* mk = p.masks + (long)m * p.H * wpr;
     const uint32_t* fl = p.filled + (long)m * p.H * wpr;
     const int y0 = p.bbox[m * 4 + 0], x0 = p.bbox[m * 4 + 1], y1 = p.bbox[m * 4 + 2], x1 = p.bbox[m * 4 + 3];
     if (tid == 0) { ncand = 0; ncont = 0; }
+    BitImg im{mk, p.H, p.W, wpr, 0, 0, 0, 0};
+    if (y0 >= 0) {
+        const int wx0 = x0 >> 5, rw = (x1 >> 5) - wx0 + 1, rh = y1 - y0 + 1;
+        const bool use_lds = rh * rw <= TRACE_LDS_WORDS;
+        if (use_lds)
+            for (int i = tid; i < rh * rw; i += blockDim.x) region[i] = mk[(long)(y0 + i / rw) * wpr + wx0 + i % rw];
+        im = BitImg{use_lds ? region : mk + (long)y0 * wpr + wx0, p.H, p.W, use_lds ? rw : wpr, y0, wx0, rh, rw};
+    }
     __syncthreads();
     if (y0 >= 0) {
         const int wx0 = x0 >> 5, rw = (x1 >> 5) - wx0 + 1, rh = y1 - y0 + 1;
         for (int i = tid; i < rh * rw; i += blockDim.x) {
             const int y = y0 + i / rw, wx = wx0 + i % rw;
             const long o = (long)y * wpr + wx;
-            const uint32_t mm = im.p[o];
+            const uint32_t mm = mk[o];
             if (!mm) continue;
-            const uint32_t ml = (mm << 1) | (wx > 0 ? im.p[o - 1] >> 31 : 0u);
+            const uint32_t ml = (mm << 1) | (wx > 0 ? mk[o - 1] >> 31 : 0u);
             const uint32_t f = fl[o];
             const uint32_t fleft = (f << 1) | (wx > 0 ? fl[o - 1] >> 31 : 0u);
             uint32_t u = 0u, ul = 0u, ur = 0u;
             if (y > 0) {
-                u = im.p[o - wpr];
-                ul = (u << 1) | (wx > 0 ? im.p[o - wpr - 1] >> 31 : 0u);
-                ur = (u >> 1) | (wx < wpr - 1 ? im.p[o - wpr + 1] << 31 : 0u);
+                u = mk[o - wpr];
+                ul = (u << 1) | (wx > 0 ? mk[o - wpr - 1] >> 31 : 0u);
+                ur = (u >> 1) | (wx < wpr - 1 ? mk[o - wpr + 1] << 31 : 0u);
             }
             uint32_t c = mm & ~ml & ~fleft & ~u & ~ul & ~ur;
             while (c) {

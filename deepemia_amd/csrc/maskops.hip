@@ -44,10 +44,44 @@ __device__ __forceinline__ uint32_t span_mask(int wx, int x0, int x1) {
 }
 
 // ---- fill holes: block per mask --------------------------------------------------------------
-// R = background reachable from outside (4-connected).  `out` holds R during the iteration.
+// R = background reachable from outside (4-connected).  The bbox region (+1 ring) of the mask and of R is
+// staged in LDS when it fits (2 x 8192 words = 64 KiB: e.g. 256 rows x 1024 px), so the fixed-point iteration
+// runs at LDS latency; larger regions iterate in place in HBM/L2.
+constexpr int FILL_LDS_WORDS = 8192;
+
+__device__ void flood_bg_iterate(const uint32_t* __restrict__ M, uint32_t* R, int stride, int rh, int rw, int max_iter, int* changed) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int iter = 0; iter < max_iter; ++iter) {
+        if (tid == 0) *changed = 0;
+        __syncthreads();
+        bool ch = false;
+        for (int i = tid; i < rh * rw; i += nt) {
+            const int ly = i / rw, lx = i - ly * rw;
+            const int o = ly * stride + lx;
+            const uint32_t bg = ~M[o];
+            const uint32_t r = R[o];
+            uint32_t n = r;
+            if (ly > 0) n |= R[o - stride];
+            if (ly < rh - 1) n |= R[o + stride];
+            uint32_t lr = (r << 1) | (r >> 1);
+            if (lx > 0) lr |= R[o - 1] >> 31;
+            if (lx < rw - 1) lr |= R[o + 1] << 31;
+            uint32_t c = (n | lr) & bg;
+            c = fill_up(c, bg);
+            c = fill_down(c, bg);
+            if (c != r) { R[o] = c; ch = true; }
+        }
+        if (ch) *changed = 1;
+        __syncthreads();
+        if (!*changed) break;
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(1024) void fill_holes_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
                                                           const int* __restrict__ bbox, int H, int W) {
     __shared__ int changed;
+    __shared__ uint32_t lds[2 * FILL_LDS_WORDS];
     const long m = blockIdx.x;
     const int wpr = W >> 5;
     const uint32_t* src = in + m * (long)H * wpr;
@@ -58,18 +92,23 @@ __global__ __launch_bounds__(1024) void fill_holes_kernel(const uint32_t* __rest
         for (int i = tid; i < H * wpr; i += nt) dst[i] = 0u;
         return;
     }
-    // everything outside the bbox rows/words is copied (no holes there)
     const int ry0 = max(y0 - 1, 0), ry1 = min(y1 + 1, H - 1);
     const int wx0 = max((x0 - 1) >> 5, 0), wx1 = min((x1 + 1) >> 5, wpr - 1);
     const int rw = wx1 - wx0 + 1, rh = ry1 - ry0 + 1;
+    const bool use_lds = rh * rw <= FILL_LDS_WORDS;
+    // everything outside the bbox rows/words is copied (no holes there)
     for (int i = tid; i < H * wpr; i += nt) {
         const int y = i / wpr, wx = i - y * wpr;
         if (y < ry0 || y > ry1 || wx < wx0 || wx > wx1) dst[i] = src[i];
     }
+    uint32_t* Mreg = use_lds ? lds : nullptr;
+    uint32_t* Rreg = use_lds ? lds + FILL_LDS_WORDS : dst + (long)ry0 * wpr + wx0;
+    const int stride = use_lds ? rw : wpr;
     // seeds: background outside the tight bbox, or on the image frame
     for (int i = tid; i < rh * rw; i += nt) {
-        const int y = ry0 + i / rw, wx = wx0 + i % rw;
-        const uint32_t bg = ~src[(long)y * wpr + wx];
+        const int ly = i / rw, lx = i - ly * rw;
+        const int y = ry0 + ly, wx = wx0 + lx;
+        const uint32_t mk = src[(long)y * wpr + wx];
         uint32_t seed;
         if (y < y0 || y > y1 || y == 0 || y == H - 1) seed = 0xFFFFFFFFu;
         else {
@@ -77,37 +116,15 @@ __global__ __launch_bounds__(1024) void fill_holes_kernel(const uint32_t* __rest
             if (wx == 0) seed |= 1u;
             if (wx == wpr - 1) seed |= 0x80000000u;
         }
-        dst[(long)y * wpr + wx] = bg & seed;
+        if (use_lds) Mreg[ly * stride + lx] = mk;
+        Rreg[ly * stride + lx] = ~mk & seed;
     }
     __syncthreads();
-    for (int iter = 0; iter < 2 * (H + W); ++iter) {
-        if (tid == 0) changed = 0;
-        __syncthreads();
-        bool ch = false;
-        for (int i = tid; i < rh * rw; i += nt) {
-            const int y = ry0 + i / rw, wx = wx0 + i % rw;
-            const long o = (long)y * wpr + wx;
-            const uint32_t bg = ~src[o];
-            const uint32_t r = dst[o];
-            uint32_t n = r;
-            if (y > ry0) n |= dst[o - wpr];
-            if (y < ry1) n |= dst[o + wpr];
-            uint32_t lr = (r << 1) | (r >> 1);
-            if (wx > wx0) lr |= dst[o - 1] >> 31;
-            if (wx < wx1) lr |= dst[o + 1] << 31;
-            uint32_t c = (n | lr) & bg;
-            c = fill_up(c, bg);
-            c = fill_down(c, bg);
-            if (c != r) { dst[o] = c; ch = true; }
-        }
-        if (ch) changed = 1;
-        __syncthreads();
-        if (!changed) break;
-        __syncthreads();
-    }
+    const uint32_t* Mptr = use_lds ? Mreg : src + (long)ry0 * wpr + wx0;
+    flood_bg_iterate(Mptr, Rreg, stride, rh, rw, 2 * (H + W), &changed);
     for (int i = tid; i < rh * rw; i += nt) {
-        const long o = (long)(ry0 + i / rw) * wpr + wx0 + i % rw;
-        dst[o] = ~dst[o];
+        const int ly = i / rw, lx = i - ly * rw;
+        dst[(long)(ry0 + ly) * wpr + wx0 + lx] = ~Rreg[ly * stride + lx];
     }
 }
 
@@ -146,31 +163,36 @@ __global__ void overlap_prefix_kernel(uint32_t* __restrict__ masks, const int* _
 }
 
 // ---- more than one 8-connected component?  block per mask, `scratch` same shape as the masks -----
+// Flood the component of the first set pixel (8-connected) and compare with the mask; the bbox region
+// is staged in LDS when it fits, `scratch` is only touched by the out-of-LDS fallback.
 __global__ __launch_bounds__(1024) void components_gt1_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ scratch,
                                                               const int* __restrict__ bbox, int* __restrict__ flag,
                                                               int H, int W) {
     __shared__ int changed;
     __shared__ int first;
+    __shared__ uint32_t lds[2 * FILL_LDS_WORDS];
     const long m = blockIdx.x;
     const int wpr = W >> 5;
     const uint32_t* src = in + m * (long)H * wpr;
-    uint32_t* R = scratch + m * (long)H * wpr;
     const int y0 = bbox[m * 4 + 0], x0 = bbox[m * 4 + 1], y1 = bbox[m * 4 + 2], x1 = bbox[m * 4 + 3];
     const int tid = threadIdx.x, nt = blockDim.x;
     if (y0 < 0) { if (tid == 0) flag[m] = 0; return; }
     const int wx0 = x0 >> 5, wx1 = x1 >> 5;
     const int rw = wx1 - wx0 + 1, rh = y1 - y0 + 1;
+    const bool use_lds = rh * rw <= FILL_LDS_WORDS;
+    const int stride = use_lds ? rw : wpr;
+    uint32_t* R = use_lds ? lds + FILL_LDS_WORDS : scratch + m * (long)H * wpr + (long)y0 * wpr + wx0;
+    const uint32_t* Mk = use_lds ? lds : src + (long)y0 * wpr + wx0;
     if (tid == 0) first = 0x7FFFFFFF;
     __syncthreads();
-    // seed = first set pixel of the first bbox row
     for (int i = tid; i < rw; i += nt)
         if (src[(long)y0 * wpr + wx0 + i]) atomicMin(&first, i);
     __syncthreads();
     for (int i = tid; i < rh * rw; i += nt) {
-        const int yy = i / rw, ww = i % rw;
-        uint32_t v = 0u;
-        if (yy == 0 && ww == first) { const uint32_t s = src[(long)y0 * wpr + wx0 + ww]; v = s & (0u - s); }
-        R[(long)(y0 + yy) * wpr + wx0 + ww] = v;
+        const int ly = i / rw, lx = i - ly * rw;
+        const uint32_t mk = src[(long)(y0 + ly) * wpr + wx0 + lx];
+        if (use_lds) lds[ly * stride + lx] = mk;
+        R[ly * stride + lx] = (ly == 0 && lx == first) ? (mk & (0u - mk)) : 0u;
     }
     __syncthreads();
     for (int iter = 0; iter < 2 * (H + W); ++iter) {
@@ -178,16 +200,15 @@ __global__ __launch_bounds__(1024) void components_gt1_kernel(const uint32_t* __
         __syncthreads();
         bool ch = false;
         for (int i = tid; i < rh * rw; i += nt) {
-            const int y = y0 + i / rw, wx = wx0 + i % rw;
-            const long o = (long)y * wpr + wx;
-            const uint32_t fg = src[o];
+            const int ly = i / rw, lx = i - ly * rw;
+            const int o = ly * stride + lx;
+            const uint32_t fg = Mk[o];
             const uint32_t r = R[o];
-            uint32_t v = r;  // vertical neighbourhood incl. self
-            uint32_t lcar = 0u, rcar = 0u;
-            if (wx > wx0) lcar = R[o - 1];
-            if (wx < wx1) rcar = R[o + 1];
-            if (y > y0) { v |= R[o - wpr]; if (wx > wx0) lcar |= R[o - wpr - 1]; if (wx < wx1) rcar |= R[o - wpr + 1]; }
-            if (y < y1) { v |= R[o + wpr]; if (wx > wx0) lcar |= R[o + wpr - 1]; if (wx < wx1) rcar |= R[o + wpr + 1]; }
+            uint32_t v = r, lcar = 0u, rcar = 0u;
+            if (lx > 0) lcar = R[o - 1];
+            if (lx < rw - 1) rcar = R[o + 1];
+            if (ly > 0) { v |= R[o - stride]; if (lx > 0) lcar |= R[o - stride - 1]; if (lx < rw - 1) rcar |= R[o - stride + 1]; }
+            if (ly < rh - 1) { v |= R[o + stride]; if (lx > 0) lcar |= R[o + stride - 1]; if (lx < rw - 1) rcar |= R[o + stride + 1]; }
             uint32_t c = v | (v << 1) | (v >> 1) | (lcar >> 31) | (rcar << 31);
             c &= fg;
             c = fill_up(c, fg);
@@ -203,8 +224,8 @@ __global__ __launch_bounds__(1024) void components_gt1_kernel(const uint32_t* __
     __syncthreads();
     bool diff = false;
     for (int i = tid; i < rh * rw; i += nt) {
-        const long o = (long)(y0 + i / rw) * wpr + wx0 + i % rw;
-        if (R[o] != src[o]) diff = true;
+        const int ly = i / rw, lx = i - ly * rw;
+        if (R[ly * stride + lx] != Mk[ly * stride + lx]) diff = true;
     }
     if (diff) changed = 1;
     __syncthreads();
@@ -212,23 +233,20 @@ __global__ __launch_bounds__(1024) void components_gt1_kernel(const uint32_t* __
 }
 
 // ---- per-column pixel counts over all masks of a call (counts must be zeroed by the caller) ------
-// seg (optional): segment id per mask; counts is [S, W], one row per segment.
-__global__ void column_counts_kernel(const uint32_t* __restrict__ masks, const int* __restrict__ seg, long rows, int H, int W,
-                                     int* __restrict__ counts) {
+// seg (optional): segment id per mask; counts is [S, W], one row per segment.  One block per mask walks
+// only the mask's bbox rows (bbox from demia_mask_area_bbox).
+__global__ void column_counts_kernel(const uint32_t* __restrict__ masks, const int* __restrict__ seg, const int* __restrict__ bbox,
+                                     int H, int W, int* __restrict__ counts) {
+    const int m = blockIdx.y;
+    const int y0 = bbox[m * 4 + 0], x0 = bbox[m * 4 + 1], y1 = bbox[m * 4 + 2], x1 = bbox[m * 4 + 3];
+    if (y0 < 0) return;
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    if (x >= W) return;
+    if (x >= W || x < x0 || x > x1) return;
     const int wpr = W >> 5, wx = x >> 5, b = x & 31;
-    const long r0 = (long)blockIdx.y * 512, r1 = min(r0 + 512, rows);
+    const uint32_t* src = masks + (long)m * H * wpr;
     int c = 0;
-    int cur = seg ? seg[r0 / H] : 0;
-    for (long r = r0; r < r1; ++r) {
-        if (seg) {
-            const int sg = seg[r / H];
-            if (sg != cur) { if (c) atomicAdd(&counts[(long)cur * W + x], c); c = 0; cur = sg; }
-        }
-        c += (masks[r * wpr + wx] >> b) & 1u;
-    }
-    if (c) atomicAdd(&counts[(long)cur * W + x], c);
+    for (int y = y0; y <= y1; ++y) c += (src[(long)y * wpr + wx] >> b) & 1u;
+    if (c) atomicAdd(&counts[(long)(seg ? seg[m] : 0) * W + x], c);
 }
 
 // ---- |a & b| for a list of pairs: block per pair over the bbox intersection ----------------------
@@ -333,14 +351,15 @@ extern "C" int demia_mask_components_gt1(const uint32_t* in, uint32_t* scratch, 
     return DEMIA_OK;
 }
 
-extern "C" int demia_mask_column_counts(const uint32_t* masks, const int32_t* seg, int64_t M, int H, int W, int32_t* counts,
-                                        void* stream) {
+extern "C" int demia_mask_column_counts(const uint32_t* masks, const int32_t* seg, const int32_t* bbox, int64_t M, int H, int W,
+                                        int32_t* counts, void* stream) {
     DEMIA_REQUIRE(masks && counts && W % 32 == 0, "args");
     if (W == 0) return DEMIA_OK;
-    const long rows = (long)M * H;
-    if (rows == 0) return DEMIA_OK;
-    hipLaunchKernelGGL(column_counts_kernel, dim3(cdiv(W, 256), cdiv(rows, 512)), dim3(256), 0, (hipStream_t)stream, masks, seg, rows,
-                       H, W, counts);
+    DEMIA_REQUIRE(bbox, "bbox");
+    if (M == 0) return DEMIA_OK;
+    DEMIA_REQUIRE(M <= 65535, "M <= 65535");
+    hipLaunchKernelGGL(column_counts_kernel, dim3(cdiv(W, 256), (int)M), dim3(256), 0, (hipStream_t)stream, masks, seg, bbox, H, W,
+                       counts);
     DEMIA_CHECK_LAUNCH("column_counts_kernel");
     return DEMIA_OK;
 }

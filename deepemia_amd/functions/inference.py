@@ -149,17 +149,24 @@ class InferencePipeline:
         self.forward_calls = 0
 
     # ------------------------------------------------------------------ predictor plumbing
-    def _predict_batch(self, model_idx: int, key: str, images: torch.Tensor) -> List[_Detections]:
-        """Forward a batch of equally sized images once per (model, key); every class reuses it."""
-        ck = (model_idx, key)
-        if ck in self._cache:
-            return self._cache[ck]
+    def forward_async(self, model_idx: int, images: torch.Tensor):
+        """Enqueue the batched forward(s) on the CURRENT stream and return without synchronising: the handle
+        (raw device results + an event) is turned into host tables later by :meth:`finish_forward`, so a caller
+        can overlap this batch's network with the previous batch's post-processing on another stream."""
         pred = self.predictors[model_idx]
-        out: List[_Detections] = []
-        h, w = int(images.shape[1]), int(images.shape[2])
+        raws = []
         for b0 in range(0, images.shape[0], 16):
-            raw = pred.engine.forward(images[b0:b0 + 16].contiguous())
+            raws.append(pred.engine.forward(images[b0:b0 + 16].contiguous()))
             self.forward_calls += 1
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.dev))
+        return raws, ev, (int(images.shape[1]), int(images.shape[2]))
+
+    def finish_forward(self, handle) -> List[_Detections]:
+        raws, ev, (h, w) = handle
+        torch.cuda.current_stream(self.dev).wait_event(ev)
+        out: List[_Detections] = []
+        for raw in raws:
             counts = raw.count.cpu().numpy()
             valid = raw.valid.cpu().numpy().astype(bool)
             scores = raw.scores.cpu().numpy()
@@ -169,8 +176,14 @@ class InferencePipeline:
                 sel = np.nonzero(valid[b, :n])[0]
                 packed = raw.packed[b, :n] if len(sel) == n else raw.packed[b, torch.from_numpy(sel).to(self.dev)]
                 out.append(_Detections(packed, scores[b, :n][sel], classes[b, :n][sel], (h, w)))
-        self._cache[ck] = out
         return out
+
+    def _predict_batch(self, model_idx: int, key: str, images: torch.Tensor) -> List[_Detections]:
+        """Forward a batch of equally sized images once per (model, key); every class reuses it."""
+        ck = (model_idx, key)
+        if ck not in self._cache:
+            self._cache[ck] = self.finish_forward(self.forward_async(model_idx, images))
+        return self._cache[ck]
 
     def clear_cache(self) -> None:
         self._cache.clear()
@@ -181,18 +194,7 @@ class InferencePipeline:
         n = int(packed.shape[0])
         alg = DeviceMaskAlgebra(self.ops, packed)
         alg.prefetch_overlapping_pairs()
-        kept: List[int] = []
-        for i in range(n):
-            dup = False
-            for j in kept:
-                inter = alg.inter(i, j)
-                union = int(alg.area[i]) + int(alg.area[j]) - inter
-                if (inter / union if union > 0 else 0) > thr:
-                    dup = True
-                    break
-            if not dup:
-                kept.append(i)
-        return kept
+        return self._greedy_keep(alg, range(n), thr)
 
     # ------------------------------------------------------------------ a6 + a9 + a11 + a12
     def _single_model_class_pass(self, det: _Detections, target_class: int, small_classes, confidence_threshold, iou_threshold):
@@ -271,23 +273,7 @@ class InferencePipeline:
             return True
 
         alg.prefetch_overlapping_pairs([[keep0[i] for i in range(len(keep0)) if classes[i] == c] for c in set(classes)])
-        sorted_indices = np.argsort(np.asarray(scores, dtype=np.float64), kind="stable")[::-1]
-        keep, removed = [], set()
-        for idx in sorted_indices:
-            if idx in removed:
-                continue
-            keep.append(int(idx))
-            for other in sorted_indices[idx + 1:]:   # sliced by mask index, not rank (N6)
-                if other in removed or classes[other] != classes[idx]:
-                    continue
-                if not overlap_literal(bb[idx], bb[other]):
-                    continue
-                inter = alg.inter(keep0[idx], keep0[other])
-                if inter == 0:
-                    continue
-                union = int(alg.area[keep0[idx]]) + int(alg.area[keep0[other]]) - inter
-                if union and inter / union > iou_threshold:
-                    removed.add(int(other))
+        keep = self._dedup_smart_order(alg, keep0, scores, classes, bb, iou_threshold)
         sel = torch.tensor([keep0[i] for i in keep], dtype=torch.long, device=self.dev)
         return packed[sel].contiguous(), [scores[i] for i in keep], [classes[i] for i in keep]
 
@@ -444,23 +430,59 @@ class InferencePipeline:
         alg.prefetch_overlapping_pairs([list(range(bounds[t], bounds[t + 1])) for t in range(T) if new_lens[t] > 1])
         out = []
         for t in range(T):
-            kept: List[int] = []
-            for i in range(bounds[t], bounds[t + 1]):
-                dup = False
-                for j in kept:
-                    inter = alg.inter(i, j)
-                    union = int(alg.area[i]) + int(alg.area[j]) - inter
-                    if (inter / union if union > 0 else 0) > thr:
-                        dup = True
-                        break
-                if not dup:
-                    kept.append(i)
+            kept = self._greedy_keep(alg, range(bounds[t], bounds[t + 1]), thr)
             sc = dets[t].scores[sels[t]] if lens[t] else []
             out.append((kept, [sc[i - bounds[t]] for i in kept]))
         return closed, out
 
+    @staticmethod
+    def _dedup_smart_order(alg: DeviceMaskAlgebra, k0: Sequence[int], scores, classes, bb, iou_threshold: float) -> List[int]:
+        """Step 2 of ``deduplicate_masks_smart`` (``inference.py:2640-2671``), one candidate row at a time:
+        ``sorted_indices[idx+1:]`` sliced by MASK INDEX and the mixed-axis bbox pre-filter are kept literally (N6)."""
+        k0a = np.asarray(k0, dtype=np.int64)
+        cls = np.asarray(classes)
+        b = np.asarray(bb, dtype=np.int64).reshape(-1, 4)       # stored (y_min, y_max, x_min, x_max) ...
+        order = np.argsort(np.asarray(scores, dtype=np.float64), kind="stable")[::-1]
+        removed = np.zeros(len(k0), dtype=bool)
+        keep: List[int] = []
+        for idx in order:
+            if removed[idx]:
+                continue
+            keep.append(int(idx))
+            others = order[idx + 1:]
+            if len(others) == 0:
+                continue
+            b1, b2 = b[idx], b[others]                           # ... read as (y_min, x_min, y_max, x_max)
+            cand = (~removed[others]) & (cls[others] == cls[idx]) & \
+                ~((b1[3] < b2[:, 1]) | (b2[:, 3] < b1[1]) | (b1[2] < b2[:, 0]) | (b2[:, 2] < b1[0]))
+            oc = others[cand]
+            if len(oc) == 0:
+                continue
+            inter = alg.inter_row(int(k0a[idx]), k0a[oc])
+            union = alg.area[k0a[idx]] + alg.area[k0a[oc]] - inter
+            iou = np.divide(inter, union, out=np.zeros(len(oc), dtype=np.float64), where=union > 0)
+            removed[oc[(inter > 0) & (iou > iou_threshold)]] = True
+        return keep
+
+    @staticmethod
+    def _greedy_keep(alg: DeviceMaskAlgebra, indices, thr: float) -> List[int]:
+        """``inference.py:1451-1459`` over an index range, IoU row at a time (same integer counts, same float64
+        division as the scalar loop)."""
+        kept: List[int] = []
+        for i in indices:
+            if kept:
+                ka = np.asarray(kept, dtype=np.int64)
+                inter = alg.inter_row(i, ka)
+                union = alg.area[i] + alg.area[ka] - inter
+                iou = np.divide(inter, union, out=np.zeros(len(ka), dtype=np.float64), where=union > 0)
+                if (iou > thr).any():
+                    continue
+            kept.append(i)
+        return kept
+
     def process_tile_batch(self, key: str, tiles: torch.Tensor, small_classes, class_thresholds: Dict[int, Tuple[float, float]],
-                           spatial_cfg: Optional[dict] = None, um_pix: float = 1.0, model_ids: Sequence[int] = (0,)):
+                           spatial_cfg: Optional[dict] = None, um_pix: float = 1.0, model_ids: Sequence[int] = (0,),
+                           dets: Optional[List[_Detections]] = None):
         """The per-tile unit of work of the headline metric: one batched forward for B independent tiles, then per
         tile the class loop (a6, a9, a11, a12), the cross-class dedup (a14, 0.7), the spatial constraints (a15) and the
         contour measurements (a17, a18).  Every kernel is launched ONCE for all tiles (segment-aware where the
@@ -468,7 +490,8 @@ class InferencePipeline:
         Same results as :meth:`process_tile_batch_unbatched`.  Returns per tile ``(packed, scores, classes, records)``."""
         if len(model_ids) > 1:
             return self.process_tile_batch_unbatched(key, tiles, small_classes, class_thresholds, spatial_cfg, um_pix, model_ids)
-        dets = self._predict_batch(model_ids[0], key, tiles)
+        if dets is None:
+            dets = self._predict_batch(model_ids[0], key, tiles)
         T, dev = len(dets), self.dev
         per_tile_parts: List[List[torch.Tensor]] = [[] for _ in range(T)]
         per_tile_scores: List[list] = [[] for _ in range(T)]
@@ -515,25 +538,7 @@ class InferencePipeline:
             scores = [per_tile_scores[t][i - bounds[t]] for i in k0]
             classes = [per_tile_classes[t][i - bounds[t]] for i in k0]
             bb = [(int(alg.bbox[i, 0]), int(alg.bbox[i, 2]), int(alg.bbox[i, 1]), int(alg.bbox[i, 3])) for i in k0]
-            keep, removed = [], set()
-            if k0:
-                order = np.argsort(np.asarray(scores, dtype=np.float64), kind="stable")[::-1]
-                for idx in order:
-                    if idx in removed:
-                        continue
-                    keep.append(int(idx))
-                    for other in order[idx + 1:]:
-                        if other in removed or classes[other] != classes[idx]:
-                            continue
-                        b1, b2 = bb[idx], bb[other]
-                        if b1[3] < b2[1] or b2[3] < b1[1] or b1[2] < b2[0] or b2[2] < b1[0]:
-                            continue                       # the mixed-axis pre-filter of N6, literally
-                        inter = alg.inter(k0[idx], k0[other])
-                        if inter == 0:
-                            continue
-                        union = int(alg.area[k0[idx]]) + int(alg.area[k0[other]]) - inter
-                        if union and inter / union > 0.7:
-                            removed.add(int(other))
+            keep = self._dedup_smart_order(alg, k0, scores, classes, bb, 0.7) if k0 else []
             gl = [k0[i] for i in keep]
             sc, cl = [scores[i] for i in keep], [classes[i] for i in keep]
             if gl and spatial_cfg is not None and spatial_cfg.get("enabled", False):

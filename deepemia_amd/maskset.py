@@ -59,8 +59,9 @@ class MaskOps:
         M, H, wpr = packed.shape
         shape = (wpr * 32,) if seg is None else (n_seg, wpr * 32)
         counts = torch.zeros(shape, dtype=torch.int32, device=self.device)
-        _lib.check(self.lib.demia_mask_column_counts(_lib.ptr(packed), _lib.ptr(seg), M, H, wpr * 32, _lib.ptr(counts),
-                                                     self._stream()), "demia_mask_column_counts")
+        _, bbox = self.area_bbox(packed)
+        _lib.check(self.lib.demia_mask_column_counts(_lib.ptr(packed), _lib.ptr(seg), _lib.ptr(bbox), M, H, wpr * 32,
+                                                     _lib.ptr(counts), self._stream()), "demia_mask_column_counts")
         return counts
 
     def pair_intersections(self, a: torch.Tensor, b: torch.Tensor, bbox_a: torch.Tensor, bbox_b: torch.Tensor,

@@ -33,6 +33,19 @@ class DeviceMaskAlgebra:
             self.area = np.zeros((0,), dtype=np.int64)
             self.bbox = np.zeros((0, 4), dtype=np.int64)
         self._cache: Dict[Tuple[int, int], int] = {}
+        # dense view for the vectorised greedy loops: I[i, j] = |mask_i & mask_j| where known (pairs whose
+        # boxes cannot overlap are known to be 0 without asking the GPU)
+        self.I = np.zeros((self.n, self.n), dtype=np.int64)
+        if self.n:
+            b = self.bbox
+            emp = b[:, 0] < 0
+            far = ((b[:, None, 3] < b[None, :, 1]) | (b[None, :, 3] < b[:, None, 1]) |
+                   (b[:, None, 2] < b[None, :, 0]) | (b[None, :, 2] < b[:, None, 0]) | emp[:, None] | emp[None, :])
+            self.known = far
+            np.fill_diagonal(self.I, self.area)
+            np.fill_diagonal(self.known, True)
+        else:
+            self.known = np.zeros((0, 0), dtype=bool)
 
     def bbox_of(self, i: int) -> Optional[Tuple[int, int, int, int]]:
         """(y_min, x_min, y_max, x_max) or None for an empty mask (spatial_constraints.py:70-89)."""
@@ -46,7 +59,19 @@ class DeviceMaskAlgebra:
         for a, b, v in zip(pi.tolist(), pj.tolist(), out.tolist()):
             self._cache[(a, b)] = v
             self._cache[(b, a)] = v
+        self.I[pi, pj] = out
+        self.I[pj, pi] = out
+        self.known[pi, pj] = True
+        self.known[pj, pi] = True
         return out
+
+    def inter_row(self, i: int, js: np.ndarray) -> np.ndarray:
+        """|mask_i & mask_j| for an index array (one GPU launch for whatever is not known yet)."""
+        js = np.asarray(js, dtype=np.int64)
+        miss = js[~self.known[i, js]]
+        if len(miss):
+            self.intersections(np.full(len(miss), i, dtype=np.int64), miss)
+        return self.I[i, js]
 
     def prefetch_overlapping_pairs(self, groups: Optional[Iterable[Sequence[int]]] = None) -> None:
         """One launch for every bbox-overlapping pair (within each index group, or all-vs-all)."""

@@ -226,7 +226,8 @@ int demia_mask_morph_cross(const uint32_t* in, uint32_t* out, int64_t M, int H, 
 int demia_mask_overlap_prefix(uint32_t* masks, const int32_t* seg, int64_t M, int H, int W, void* stream);
 int demia_mask_components_gt1(const uint32_t* in, uint32_t* scratch, const int32_t* bbox, int32_t* flag,
                               int64_t M, int H, int W, void* stream);
-int demia_mask_column_counts(const uint32_t* masks, const int32_t* seg, int64_t M, int H, int W, int32_t* counts, void* stream);
+int demia_mask_column_counts(const uint32_t* masks, const int32_t* seg, const int32_t* bbox, int64_t M, int H, int W,
+                             int32_t* counts, void* stream);
 int demia_mask_pair_intersections(const uint32_t* a, const uint32_t* b, const int32_t* pi, const int32_t* pj,
                                   const int32_t* bbox_a, const int32_t* bbox_b, int32_t* out, int64_t P,
                                   int H, int W, void* stream);
