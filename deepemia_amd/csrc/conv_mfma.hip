@@ -307,7 +307,13 @@ int launch_cfg(ConvP p, hipStream_t st) {
 
 template <typename T, typename TO>
 int launch_typed(ConvP p, int bn, hipStream_t st) {
-    if (bn == 128) return launch_cfg<T, TO, 2, 2, 2, 2>(p, st);
+    if (bn == 128) {
+        // 128x128 tiles need >= 2 workgroups per CU to keep one MFMA pipe busy while the other wave waits on
+        // LDS / global loads; mid-size layers (res4 / res5 at small batch) get 64x128 tiles to double the grid
+        const long blocks128 = (long)cdiv(p.M, 128) * cdiv(p.CoutPad, 128);
+        if (blocks128 < 3 * 256) return launch_cfg<T, TO, 2, 2, 1, 2>(p, st);
+        return launch_cfg<T, TO, 2, 2, 2, 2>(p, st);
+    }
     if (bn == 64) return launch_cfg<T, TO, 4, 1, 1, 2>(p, st);
     return launch_cfg<T, TO, 4, 1, 1, 1>(p, st);
 }

@@ -1,0 +1,33 @@
+"""Dev script: per-conv-launch achieved TFLOP/s (R101, 2048^2, B tiles)."""
+import sys, numpy as np, torch
+sys.path.insert(0, '.')
+from deepemia_amd import synth, engine as E
+prec = sys.argv[1]; B = int(sys.argv[2])
+sd = synth.random_d2_state_dict(101, 2, 0)
+eng = E.MaskRCNNEngine(sd, 101, 2, 0.3, 'cuda:0', prec)
+x = torch.from_numpy(np.stack([synth.em_tile(i, 2048) for i in range(B)])).cuda()
+log = []
+orig = eng.conv
+def conv(xx, L, **kw):
+    n, h, w, cin = xx.shape
+    ho = (h + 2 * L.pad - L.kh) // L.stride + 1; wo = (w + 2 * L.pad - L.kw) // L.stride + 1
+    log.append((n * ho * wo, L.cout, L.kh * L.kw * cin, L.kh, L.stride))
+    return orig(xx, L, **kw)
+eng.conv = conv
+for _ in range(2): eng.forward(x)
+torch.cuda.synchronize(); log.clear(); eng.conv_events = []
+for _ in range(3): eng.forward(x)
+torch.cuda.synchronize()
+ev = eng.conv_events; n = len(ev) // 3
+agg = {}
+for i in range(n):
+    t = np.mean([ev[i + k * n][0].elapsed_time(ev[i + k * n][1]) for k in range(3)]); fl = ev[i][2]
+    key = log[i]
+    a = agg.setdefault(key, [0, 0.0, 0.0]); a[0] += 1; a[1] += t; a[2] += fl
+tot_t = sum(a[1] for a in agg.values()); tot_f = sum(a[2] for a in agg.values())
+print(f'total conv {tot_t:.2f} ms, {tot_f/tot_t/1e9:.1f} TF/s')
+for key, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    M, co, K, kh, st = key
+    bm, bn = 128, (128 if co >= 128 else (64 if co >= 64 else 32))
+    blocks = -(-M // bm) * -(-((co + 31) // 32 * 32) // bn)
+    print(f'M={M:7d} Cout={co:5d} K={K:6d} k{kh} s{st} x{a[0]:3d} time={a[1]:7.3f} ms ({a[1]/tot_t*100:4.1f}%) {a[2]/a[1]/1e9:7.1f} TF/s blocks={blocks}')
