@@ -486,6 +486,7 @@ __device__ void fit_ellipse(const int* pts, int n, double* Ad, float* bw, float*
 }
 
 struct MeasureP {
+    const int* select;    // [M] or NULL: masks with select[m] == 0 are skipped
     const int* count;     // [M]
     const int* info;      // [M, C, 4]
     const double* red;    // [M, C, 2]
@@ -502,7 +503,7 @@ __global__ void contour_measure_kernel(const MeasureP p) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= p.M * p.C) return;
     const int m = t / p.C, c = t - m * p.C;
-    if (c >= p.count[m]) return;
+    if (c >= p.count[m] || (p.select && !p.select[m])) return;
     const int* inf = p.info + (long)t * 4;
     const int n = inf[2], off = inf[3];
     double* o = p.out + (long)t * 12;
@@ -612,12 +613,13 @@ extern "C" int demia_mask_contours(const uint32_t* masks, const uint32_t* filled
     return DEMIA_OK;
 }
 
-extern "C" int demia_contour_measure(const int32_t* count, const int32_t* info, const double* red, const int32_t* points, int M,
+extern "C" int demia_contour_measure(const int32_t* select, const int32_t* count, const int32_t* info, const double* red,
+                                     const int32_t* points, int M,
                                      int C, int max_points, int32_t* work_i, float* work_f, double* work_d, double um_pix,
                                      double* out, void* stream) {
     DEMIA_REQUIRE(count && info && red && points && work_i && work_f && work_d && out, "args");
     if (M * C == 0) return DEMIA_OK;
-    MeasureP p{count, info, red, points, M, C, max_points, work_i, work_f, work_d, um_pix, out};
+    MeasureP p{select, count, info, red, points, M, C, max_points, work_i, work_f, work_d, um_pix, out};
     hipLaunchKernelGGL(contour_measure_kernel, dim3(cdiv((long)M * C, 64)), dim3(64), 0, (hipStream_t)stream, p);
     DEMIA_CHECK_LAUNCH("contour_measure_kernel");
     return DEMIA_OK;

@@ -513,17 +513,17 @@ class InferencePipeline:
         allp = torch.cat([p for t in range(T) for p in per_tile_parts[t]], dim=0)
         bounds = np.concatenate(([0], np.cumsum(lens)))
         alg = DeviceMaskAlgebra(self.ops, allp)
-        cont = self.ops.contours(allp, max_contours=256, measure=False)
+        cset = self.ops.trace(allp, max_contours=256)       # traced ONCE: reused for the final measurements
+        per0 = cset.first_contour_perimeter()
         keep0_all, groups = [], []
         for t in range(T):
             k0 = []
             for idx in range(bounds[t], bounds[t + 1]):
                 if alg.bbox[idx, 0] < 0:
                     continue
-                if len(cont[idx]) > 0:
-                    per = cont[idx][0]["perimeter"]
-                    if per > 0 and (4 * np.pi * int(alg.area[idx])) / (per ** 2) < 0.15:
-                        continue
+                per = per0[idx]
+                if per > 0 and (4 * np.pi * int(alg.area[idx])) / (per ** 2) < 0.15:
+                    continue
                 k0.append(idx)
             keep0_all.append(k0)
             cl = [per_tile_classes[t][i - bounds[t]] for i in k0]
@@ -551,7 +551,7 @@ class InferencePipeline:
         if not flat:
             return out
         finalp = allp[torch.tensor(flat, dtype=torch.long, device=dev)].contiguous()
-        recs = self.ops.contours(finalp, max_contours=256, um_pix=um_pix)
+        recs = cset.records(um_pix=um_pix, measure=True, select=flat)
         pos = 0
         for t in range(T):
             n = len(final_idx[t])

@@ -128,54 +128,100 @@ class MaskOps:
         return dst
 
     # -- contours + measurements ----------------------------------------------------------------
-    def contours(self, packed: torch.Tensor, max_contours: int = 64, max_points: Optional[int] = None,
-                 um_pix: float = 1.0, measure: bool = True):
-        """Per mask: external contours in OpenCV's order, with area, perimeter and the 12 measurement
-        values.  Returns a list (per mask) of lists of dicts with keys ``points`` (P, 2) int32,
-        ``area``, ``perimeter`` and (if ``measure``) ``values`` (12,) float64."""
+    def trace(self, packed: torch.Tensor, max_contours: int = 64, max_points: Optional[int] = None) -> "ContourSet":
+        """cv2.findContours(RETR_EXTERNAL, CHAIN_APPROX_SIMPLE) + contourArea + arcLength for every mask, once;
+        the returned set can be measured later for any subset of its masks without tracing again."""
         M, H, wpr = packed.shape
         W = wpr * 32
-        if M == 0:
-            return []
         area, bbox = self.area_bbox(packed)
         filled = self.fill_holes(packed, bbox)
         if max_points is None:
             max_points = int(min(max(4 * int(area.sum().item()) // 8 + 4096 * M, 1 << 16), 1 << 26))
         C = max_contours
-        count = torch.zeros((M,), dtype=torch.int32, device=self.device)
-        info = torch.zeros((M, C, 4), dtype=torch.int32, device=self.device)
-        red = torch.zeros((M, C, 2), dtype=torch.float64, device=self.device)
-        points = torch.empty((max_points, 2), dtype=torch.int32, device=self.device)
-        counters = torch.zeros((2,), dtype=torch.int32, device=self.device)
+        cs = ContourSet(self, M, C, max_points)
         _lib.check(self.lib.demia_mask_contours(_lib.ptr(packed), _lib.ptr(filled), _lib.ptr(bbox), M, H, W, C, max_points,
-                                                _lib.ptr(count), _lib.ptr(info), _lib.ptr(red), _lib.ptr(points),
-                                                _lib.ptr(counters), self._stream()), "demia_mask_contours")
-        vals = None
-        if measure:
-            wi = torch.empty((int(self.lib.demia_contour_work_ints(M, C, max_points)),), dtype=torch.int32, device=self.device)
-            wf = torch.empty((int(self.lib.demia_contour_work_floats(M, C, max_points)),), dtype=torch.float32, device=self.device)
-            wd = torch.empty((int(self.lib.demia_contour_work_doubles(M, C, max_points)),), dtype=torch.float64, device=self.device)
-            vals = torch.zeros((M, C, 12), dtype=torch.float64, device=self.device)
-            _lib.check(self.lib.demia_contour_measure(_lib.ptr(count), _lib.ptr(info), _lib.ptr(red), _lib.ptr(points), M, C,
-                                                      max_points, _lib.ptr(wi), _lib.ptr(wf), _lib.ptr(wd), float(um_pix), _lib.ptr(vals),
-                                                      self._stream()), "demia_contour_measure")
-        cnt = counters.cpu().numpy()
-        if cnt[1] != 0:
-            raise _lib.HipKernelError(f"contour extraction overflow (flags {int(cnt[1])}): raise max_contours / max_points")
-        count_h, info_h, red_h = count.cpu().numpy(), info.cpu().numpy(), red.cpu().numpy()
-        pts_h = points[: int(cnt[0])].cpu().numpy()
-        vals_h = vals.cpu().numpy() if vals is not None else None
+                                                _lib.ptr(cs.count), _lib.ptr(cs.info), _lib.ptr(cs.red), _lib.ptr(cs.points),
+                                                _lib.ptr(cs.counters), self._stream()), "demia_mask_contours")
+        return cs
+
+    def contours(self, packed: torch.Tensor, max_contours: int = 64, max_points: Optional[int] = None,
+                 um_pix: float = 1.0, measure: bool = True):
+        """Per mask: external contours in OpenCV's order, with area, perimeter and the 12 measurement
+        values.  Returns a list (per mask) of lists of dicts with keys ``points`` (P, 2) int32,
+        ``area``, ``perimeter`` and (if ``measure``) ``values`` (12,) float64."""
+        if int(packed.shape[0]) == 0:
+            return []
+        cs = self.trace(packed, max_contours, max_points)
+        return cs.records(um_pix=um_pix, measure=measure)
+
+
+class ContourSet:
+    """Device-resident result of one contour trace over M masks (see :meth:`MaskOps.trace`)."""
+
+    def __init__(self, ops: MaskOps, M: int, C: int, max_points: int):
+        dev = ops.device
+        self.ops, self.M, self.C, self.max_points = ops, M, C, max_points
+        self.count = torch.zeros((M,), dtype=torch.int32, device=dev)
+        self.info = torch.zeros((M, C, 4), dtype=torch.int32, device=dev)
+        self.red = torch.zeros((M, C, 2), dtype=torch.float64, device=dev)
+        self.points = torch.empty((max_points, 2), dtype=torch.int32, device=dev)
+        self.counters = torch.zeros((2,), dtype=torch.int32, device=dev)
+        self._host = None
+
+    def host(self):
+        if self._host is None:
+            cnt = self.counters.cpu().numpy()
+            if cnt[1] != 0:
+                raise _lib.HipKernelError(f"contour extraction overflow (flags {int(cnt[1])}): raise max_contours / max_points")
+            self._host = (self.count.cpu().numpy(), self.info.cpu().numpy(), self.red.cpu().numpy(), int(cnt[0]))
+        return self._host
+
+    def first_contour_perimeter(self) -> np.ndarray:
+        """Perimeter of ``contours[0]`` (OpenCV order: the contour with the greatest (start y, start x)) per mask,
+        -1 where a mask has no contour -- what ``deduplicate_masks_smart``'s compactness test reads."""
+        count, info, red, _ = self.host()
+        out = np.full(self.M, -1.0)
+        for m in range(self.M):
+            c = int(count[m])
+            if c:
+                k = np.lexsort((info[m, :c, 0], info[m, :c, 1]))[-1]
+                out[m] = red[m, k, 1]
+        return out
+
+    def measure(self, um_pix: float = 1.0, select: Optional[Sequence[int]] = None) -> np.ndarray:
+        """[M, C, 12] measurement values (only for the selected masks when ``select`` is given)."""
+        ops = self.ops
+        M, C, mp = self.M, self.C, self.max_points
+        sel_t = None
+        if select is not None:
+            flags = np.zeros(M, dtype=np.int32)
+            flags[np.asarray(list(select), dtype=np.int64)] = 1
+            sel_t = torch.from_numpy(flags).to(ops.device)
+        wi = torch.empty((int(ops.lib.demia_contour_work_ints(M, C, mp)),), dtype=torch.int32, device=ops.device)
+        wf = torch.empty((int(ops.lib.demia_contour_work_floats(M, C, mp)),), dtype=torch.float32, device=ops.device)
+        wd = torch.empty((int(ops.lib.demia_contour_work_doubles(M, C, mp)),), dtype=torch.float64, device=ops.device)
+        vals = torch.zeros((M, C, 12), dtype=torch.float64, device=ops.device)
+        _lib.check(ops.lib.demia_contour_measure(_lib.ptr(sel_t), _lib.ptr(self.count), _lib.ptr(self.info), _lib.ptr(self.red),
+                                                 _lib.ptr(self.points), M, C, mp, _lib.ptr(wi), _lib.ptr(wf), _lib.ptr(wd),
+                                                 float(um_pix), _lib.ptr(vals), ops._stream()), "demia_contour_measure")
+        return vals.cpu().numpy()
+
+    def records(self, um_pix: float = 1.0, measure: bool = True, select: Optional[Sequence[int]] = None, with_points: bool = True):
+        """Per (selected) mask the list of contour dicts in OpenCV's order (reverse raster order of the start)."""
+        vals = self.measure(um_pix, select) if measure else None
+        count, info, red, used = self.host()
+        pts = self.points[:used].cpu().numpy() if with_points else None
         out = []
-        for m in range(M):
+        for m in (range(self.M) if select is None else select):
             recs = []
-            for c in range(int(count_h[m])):
-                sx, sy, n, off = (int(v) for v in info_h[m, c])
-                rec = dict(start=(sx, sy), points=pts_h[off: off + n].copy(), area=float(red_h[m, c, 0]),
-                           perimeter=float(red_h[m, c, 1]))
-                if vals_h is not None:
-                    rec["values"] = vals_h[m, c].copy()
+            for c in range(int(count[m])):
+                sx, sy, n, off = (int(v) for v in info[m, c])
+                rec = dict(start=(sx, sy), area=float(red[m, c, 0]), perimeter=float(red[m, c, 1]))
+                if pts is not None:
+                    rec["points"] = pts[off: off + n].copy()
+                if vals is not None:
+                    rec["values"] = vals[m, c].copy()
                 recs.append(rec)
-            # cv2.findContours returns the contours in reverse discovery (raster) order
             recs.sort(key=lambda r: (r["start"][1], r["start"][0]), reverse=True)
             out.append(recs)
         return out

@@ -252,7 +252,8 @@ int64_t demia_contour_work_doubles(int M, int C, int max_points);
 int demia_mask_contours(const uint32_t* masks, const uint32_t* filled, const int32_t* bbox, int M, int H, int W, int C,
                         int max_points, int32_t* count, int32_t* info, double* red, int32_t* points,
                         int32_t* counters, void* stream);
-int demia_contour_measure(const int32_t* count, const int32_t* info, const double* red, const int32_t* points, int M,
+int demia_contour_measure(const int32_t* select /* [M] or NULL */, const int32_t* count, const int32_t* info,
+                          const double* red, const int32_t* points, int M,
                           int C, int max_points, int32_t* work_i, float* work_f, double* work_d, double um_pix,
                           double* out, void* stream);
 
