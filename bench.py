@@ -140,7 +140,7 @@ def main() -> None:
                 a, b = pipe.ops.area_bbox(packed)
                 hdr, pay = parallel.encode_instance_table(packed, scores, classes, units, b.cpu().numpy(), a.cpu().numpy())
             else:
-                hdr = torch.zeros((0, 8), dtype=torch.int32, device=dev)
+                hdr = torch.zeros((0, parallel.HDR), dtype=torch.int32, device=dev)
                 pay = torch.zeros((0,), dtype=torch.int32, device=dev)
             parallel.all_gather_instance_tables(hdr, pay)
         return n_inst, n_rows

@@ -28,6 +28,7 @@ import torch
 
 from ..data.datasets import DatasetCatalog, MetadataCatalog, read_dataset_info, register_datasets
 from ..data.models import choose_and_use_model, get_trained_model_paths
+from .. import parallel
 from ..maskset import MaskOps
 from ..utils.config import get_config
 from ..utils.logger_utils import log_memory_usage, system_logger
@@ -147,6 +148,9 @@ class InferencePipeline:
         self.class_specific_settings = inf_settings.get("class_specific_settings", {})
         self._cache: Dict[Tuple[int, str], List[_Detections]] = {}
         self.forward_calls = 0
+        import torch.distributed as dist
+        self.rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+        self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
 
     # ------------------------------------------------------------------ predictor plumbing
     def forward_async(self, model_idx: int, images: torch.Tensor):
@@ -303,19 +307,28 @@ class InferencePipeline:
                 return self._ensemble_class_pass(dets_per_model, target_class, small_classes, confidence_threshold, iou_threshold)
             return self._single_model_class_pass(dets_per_model[0], target_class, small_classes, confidence_threshold, iou_threshold)
 
-        full = [self._predict_batch(m, image_key + "|full", image_dev[None])[0] for m in model_ids]
-        full_masks, full_scores, full_classes = class_pass(full)
+        rank, world = self.rank, self.world
         tiles, offs = self._make_tiles(image_dev, tile_size, overlap_ratio)
         uh, uw = int(tile_size * upscale_factor), int(tile_size * upscale_factor)
-        if (uh, uw) != (tile_size, tile_size):
-            tiles = self.predictors[0].engine.resize_linear_u8(tiles, uh, uw)
         if uw % 32:
             raise ValueError("upscaled tile width must be a multiple of 32")
-        tile_dets = [self._predict_batch(m, f"{image_key}|tiles{tile_size}/{overlap_ratio}/{upscale_factor}", tiles) for m in model_ids]
-        tile_masks, tile_scores, tile_classes = [], [], []
+        # unit 0 = the full-image pass (rank 0), unit 1 + t = tile t (rank t % world): SURVEY.md section 8(e)
+        mine = parallel.shard_indices(len(offs), rank, world)
+        full_masks, full_scores, full_classes = None, [], []
+        if rank == 0:
+            full = [self._predict_batch(m, image_key + "|full", image_dev[None])[0] for m in model_ids]
+            full_masks, full_scores, full_classes = class_pass(full)
+        tile_masks, tile_scores, tile_classes, tile_units = [], [], [], []
+        if mine:
+            my_tiles = tiles[torch.tensor(mine, dtype=torch.long, device=self.dev)]
+            if (uh, uw) != (tile_size, tile_size):
+                my_tiles = self.predictors[0].engine.resize_linear_u8(my_tiles, uh, uw)
+            tile_dets = [self._predict_batch(m, f"{image_key}|tiles{tile_size}/{overlap_ratio}/{upscale_factor}/{rank}of{world}", my_tiles)
+                         for m in model_ids]
         edge = int(tile_size * overlap_ratio / 2)
-        for t, (x_off, y_off) in enumerate(offs):
-            tm, ts, tc = class_pass([d[t] for d in tile_dets])
+        for k, t in enumerate(mine):
+            x_off, y_off = offs[t]
+            tm, ts, tc = class_pass([d[k] for d in tile_dets])
             if tm is None or isinstance(tm, str) or tm.shape[0] == 0:
                 continue
             n = int(tm.shape[0])
@@ -333,6 +346,39 @@ class InferencePipeline:
             tile_masks.append(glob)
             tile_scores.extend(ts[i] for i in keep)
             tile_classes.extend(tc[i] for i in keep)
+            tile_units.extend([1 + t] * len(keep))
+        if world > 1:
+            # the ONE exchange of the path: every rank receives every rank's instance table, ordered by unit id
+            empty_full = isinstance(full_masks, str)
+            parts = ([full_masks] if (full_masks is not None and not empty_full and full_masks.shape[0]) else []) + tile_masks
+            sc = ([] if (full_masks is None or empty_full) else list(full_scores)) + list(tile_scores)
+            cl = ([] if (full_masks is None or empty_full) else list(full_classes)) + list(tile_classes)
+            un = [0] * (len(sc) - len(tile_scores)) + tile_units
+            local = torch.cat(parts, dim=0) if parts else None
+            if local is not None:
+                a, b = self.ops.area_bbox(local)
+                hdr, pay = parallel.encode_instance_table(local, sc, cl, un, b.cpu().numpy(), a.cpu().numpy())
+            else:
+                hdr = torch.zeros((0, parallel.HDR), dtype=torch.int32, device=self.dev)
+                pay = torch.zeros((0,), dtype=torch.int32, device=self.dev)
+            if rank == 0 and empty_full:   # N4 marker travels too: unit -1 row, no payload
+                mark = torch.zeros((1, parallel.HDR), dtype=torch.int32, device=self.dev)
+                mark[0, 0] = -1
+                mark[0, 4:8] = -1
+                hdr = torch.cat([mark, hdr], dim=0)
+            gh, gp = parallel.all_gather_instance_tables(hdr, pay)
+            packed_all, s_all, c_all, u_all = parallel.decode_instance_table(gh, gp, h, w, self.dev)
+            has_marker = bool(u_all) and u_all[0] == -1
+            if has_marker:
+                packed_all, s_all, c_all, u_all = packed_all[1:], s_all[1:], c_all[1:], u_all[1:]
+                if len(s_all):
+                    raise EmptyEnsembleTypeError("operands could not be broadcast together (empty ensemble result + tile masks)")
+                return None, [], []
+            if not ensemble:
+                s_all = [np.float32(v) for v in s_all]      # single-model scores are the predictor's float32 values
+            if len(s_all) == 0:
+                return None, [], []
+            return self.deduplicate_masks_smart(packed_all, s_all, c_all, 0.4)
         if isinstance(full_masks, str):        # N4: ndarray + list
             if tile_masks:
                 raise EmptyEnsembleTypeError("operands could not be broadcast together (empty ensemble result + tile masks)")
@@ -700,6 +746,8 @@ def run_inference(dataset_name, output_dir, visualize=True, threshold=0.65, draw
     unprocessed = set(images_name) - processed
     if unprocessed:
         system_logger.warning(f"Unprocessed images: {sorted(unprocessed)}")
+    if pipe.rank != 0:
+        return dedup_results     # every rank holds the same merged result; rank 0 alone writes the output files
     with open(os.path.join(output_dir, "R50_flip_results.csv"), "w", newline="") as f:
         wri = csv.writer(f)
         wri.writerow(["ImageId", "EncodedPixels"])

@@ -4,8 +4,8 @@ filters.  The reference is single-process (``models.py:
 translates an existing call pattern.
 
 Instance table (what crosses xGMI instead of N x H x W masks):
-  header  [n, 8] int32 : unit id (0 = full-image pass, 1 + t = tile t), class, score (f32 bits),
-                         bbox y0, x0, y1, x1 (global frame, inclusive; -1 for an empty mask), area
+  header  [n, 10] int32: unit id (0 = full-image pass, 1 + t = tile t), class, score (f64 bits, lo / hi word),
+                         bbox y0, x0, y1, x1 (global frame, inclusive; -1 for an empty mask), area, flags
   payload [sum] int32  : each mask's bit-packed words cropped to its bbox rows and word columns
 A 2048^2 tile with 100 instances is a few hundred KB at most; the collective is latency-bound, so it is
 a single ``all_gather`` of sizes followed by one padded ``all_gather`` (direct, one hop on the fully
@@ -22,6 +22,9 @@ import torch
 import torch.distributed as dist
 
 
+HDR = 10
+
+
 def shard_indices(n_units: int, rank: int, world: int) -> List[int]:
     """Unit i is owned by rank ``i % world`` (16 tiles on 8 GPUs -> 2 each)."""
     return list(range(rank, n_units, world))
@@ -34,17 +37,17 @@ def _crop_words(bbox_row) -> Tuple[int, int, int, int]:
 
 def encode_instance_table(packed: Optional[torch.Tensor], scores: Sequence[float], classes: Sequence[int], unit_ids: Sequence[int],
                           bbox: np.ndarray, area: np.ndarray) -> Tuple[torch.Tensor, torch.Tensor]:
-    """-> (header [n, 8] int32, payload [L] int32) on the masks' device."""
+    """-> (header [n, 10] int32, payload [L] int32) on the masks' device."""
     n = 0 if packed is None else int(packed.shape[0])
     dev = packed.device if packed is not None else torch.device("cpu")
-    hdr = np.zeros((n, 8), dtype=np.int32)
+    hdr = np.zeros((n, HDR), dtype=np.int32)
     chunks = []
     for i in range(n):
         hdr[i, 0] = int(unit_ids[i])
         hdr[i, 1] = int(classes[i])
-        hdr[i, 2] = np.float32(scores[i]).view(np.int32)
-        hdr[i, 3:7] = bbox[i]
-        hdr[i, 7] = int(area[i])
+        hdr[i, 2:4] = np.array([scores[i]], dtype=np.float64).view(np.int32)   # exact: ensemble scores are f64 products
+        hdr[i, 4:8] = bbox[i]
+        hdr[i, 8] = int(area[i])
         if bbox[i, 0] >= 0:
             r0, r1, c0, c1 = _crop_words(bbox[i])
             chunks.append(packed[i, r0:r1, c0:c1].reshape(-1))
@@ -61,13 +64,13 @@ def decode_instance_table(header: torch.Tensor, payload: torch.Tensor, H: int, W
     payload = payload.to(device)
     off = 0
     for i in range(n):
-        if hdr[i, 3] < 0:
+        if hdr[i, 4] < 0:
             continue
-        r0, r1, c0, c1 = _crop_words(hdr[i, 3:7])
+        r0, r1, c0, c1 = _crop_words(hdr[i, 4:8])
         cnt = (r1 - r0) * (c1 - c0)
         packed[i, r0:r1, c0:c1] = payload[off:off + cnt].view(r1 - r0, c1 - c0)
         off += cnt
-    scores = [float(np.int32(v).view(np.float32)) for v in hdr[:, 2]]
+    scores = [float(v) for v in np.ascontiguousarray(hdr[:, 2:4]).view(np.float64).reshape(-1)] if n else []
     return packed, scores, [int(v) for v in hdr[:, 1]], [int(v) for v in hdr[:, 0]]
 
 
@@ -86,24 +89,24 @@ def all_gather_instance_tables(header: torch.Tensor, payload: torch.Tensor, grou
     dist.all_gather(all_sizes, sizes, group=group)
     max_n = max(int(s[0]) for s in all_sizes)
     max_p = max(int(s[1]) for s in all_sizes)
-    buf = torch.zeros((max_n * 8 + max_p,), dtype=torch.int32, device=comm_dev)
+    buf = torch.zeros((max_n * HDR + max_p,), dtype=torch.int32, device=comm_dev)
     buf[: h.numel()] = h.reshape(-1)
-    buf[max_n * 8: max_n * 8 + p.numel()] = p
+    buf[max_n * HDR: max_n * HDR + p.numel()] = p
     gathered = [torch.zeros_like(buf) for _ in range(world)]
     dist.all_gather(gathered, buf, group=group)
     hs, ps = [], []
     for r in range(world):
         n_r, p_r = int(all_sizes[r][0]), int(all_sizes[r][1])
-        hs.append(gathered[r][: n_r * 8].view(n_r, 8))
-        ps.append(gathered[r][max_n * 8: max_n * 8 + p_r])
+        hs.append(gathered[r][: n_r * HDR].view(n_r, HDR))
+        ps.append(gathered[r][max_n * HDR: max_n * HDR + p_r])
     out_h, out_p = _merge_tables(hs, ps)
     return out_h.to(header.device), out_p.to(payload.device)
 
 
 def _payload_lengths(hdr: np.ndarray) -> np.ndarray:
     lens = np.zeros(hdr.shape[0], dtype=np.int64)
-    ok = hdr[:, 3] >= 0
-    lens[ok] = (hdr[ok, 5] - hdr[ok, 3] + 1) * ((hdr[ok, 6] >> 5) - (hdr[ok, 4] >> 5) + 1)
+    ok = hdr[:, 4] >= 0
+    lens[ok] = (hdr[ok, 6] - hdr[ok, 4] + 1) * ((hdr[ok, 7] >> 5) - (hdr[ok, 5] >> 5) + 1)
     return lens
 
 

@@ -63,6 +63,16 @@ def main(argv=None) -> int:
     if not args.dataset_name:
         system_logger.error("--dataset_name is required for --task inference")
         return 2
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        # one process per GPU (torchrun): tiles of each image are sharded over the ranks, rank 0 writes the outputs
+        import torch
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(os.environ.get("DEEPEMIA_DIST_BACKEND", "nccl"), device_id=torch.device(f"cuda:{local_rank}"))
     config = get_config()
     if not args.no_gpu_check:
         log_device_info()

@@ -28,7 +28,7 @@ def _make_unit(unit_id, h, w):
         y0, x0 = rng.integers(0, h - 8), rng.integers(0, w - 8)
         y1, x1 = rng.integers(y0 + 1, h + 1), rng.integers(x0 + 1, w + 1)
         masks[i, y0:y1, x0:x1] = rng.random((y1 - y0, x1 - x0)) > 0.4
-    scores = rng.uniform(0.3, 1.0, n).astype(np.float32)
+    scores = rng.uniform(0.3, 1.0, n) * 0.6   # float64 (ensemble scores are score * weight products)
     classes = rng.integers(0, 2, n)
     return masks, scores, classes
 

@@ -175,3 +175,55 @@ def test_batched_tile_pipeline_equals_tile_by_tile(gpu_device):
                 assert np.array_equal(u["points"], v["points"]) and u["area"] == v["area"]
                 assert np.array_equal(u["values"], v["values"])
     assert total > 50
+
+
+def _sharded_worker(rank, world, port, tmp, out):
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DEEPEMIA_LOG_DIR=str(tmp))
+    dist.init_process_group("gloo", rank=rank, world_size=world)   # both ranks share the one GPU of the test box
+    out[rank] = _run_tile_pipeline()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_tile_pipeline():
+    from deepemia_amd import synth
+    from deepemia_amd.engine import MaskRCNNEngine
+    from deepemia_amd.functions.inference import InferencePipeline
+    from deepemia_amd.predictor import Predictor
+
+    sd = synth.random_d2_state_dict(50, 2, seed=0, mask_bias=0.5, mask_gain=6.0)
+    pipe = InferencePipeline([Predictor(MaskRCNNEngine(sd, 50, 2, 0.3, "cuda:0", "f32"))], "t", {}, {})
+    img = torch.from_numpy(synth.em_tile(77, 1024)).to("cuda:0")
+    res = []
+    for cls, conf, thr in ((0, 0.3, 0.6), (1, 0.35, 0.5)):
+        m, s, c = pipe.tile_based_inference_pipeline([0], "img", img, cls, {1}, conf, 512, 0.25, 1.0, thr, True)
+        res.append((None if m is None else m.cpu().numpy(), [float(v) for v in s], list(c)))
+    return res, pipe.forward_calls
+
+
+def test_tiles_sharded_over_two_ranks_equal_single_process(gpu_device, tmp_path):
+    """config[2] shape: one image, its tiles sharded over 2 ranks (unit i -> rank i % 2), instance tables all-gathered,
+    every rank runs the same dedup -> identical to the single-process result on every rank."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    single, calls1 = _run_tile_pipeline()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_sharded_worker, args=(2, port, tmp_path, out), nprocs=2, join=True)
+    for r in range(2):
+        res, calls = out[r]
+        for (ma, sa, ca), (mb, sb, cb) in zip(res, single):
+            assert (ma is None) == (mb is None)
+            if ma is not None:
+                np.testing.assert_array_equal(ma, mb)
+            assert sa == sb and ca == cb
+    assert out[1][1] < calls1                      # rank 1 ran fewer forwards (no full-image pass, half the tiles)
+    assert sum(len(x[1]) for x in single) > 20
