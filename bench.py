@@ -176,6 +176,12 @@ def main() -> None:
         launches = len(events)
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         peak = PEAK_TFLOPS[args.precision]
+        # HBM bytes per conv launch from the PMC passes committed under profiles/ (collected with separate
+        # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this workload; FETCH_SIZE doubled per the gfx950 note)
+        traffic = None
+        tf = ROOT / "profiles" / f"r01_conv_{args.precision}_b{args.batch}_pmc_traffic.json"
+        if tf.exists() and args.depth == 101 and args.size == 2048:
+            traffic = json.loads(tf.read_text()).get("hbm_bytes_per_launch")
         line = {
             "metric": "EM tiles/s (2048x2048, R101-FPN)", "value": world * args.batch * args.steps / dt,
             "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -195,7 +201,8 @@ def main() -> None:
                          "launches_per_step": launches // max(args.steps, 1),
                          "avg_launch_us": conv_ms * 1e3 / max(launches, 1),
                          "algorithmic_gflop_per_launch": conv_flops / max(launches, 1) / 1e9,
-                         "share_of_step_time": conv_ms * 1e-3 / dt, "traffic": None},
+                         "share_of_step_time": conv_ms * 1e-3 / dt, "traffic": traffic,
+                         "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.depth, args.size, args.threshold, sd)
