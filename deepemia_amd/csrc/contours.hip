@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void contour_trace_kernel(const ContourP p) {
     __shared__ int ncand, ncont;
     __shared__ uint32_t region[TRACE_LDS_WORDS];
     const int m = blockIdx.x, tid = threadIdx.x;
-    const int wpr = p.W >> 5;
+    const int wpr = (p.W + 31) >> 5;
     const uint32_t* mk = p.masks + (long)m * p.H * wpr;
     const uint32_t* fl = p.filled + (long)m * p.H * wpr;
     const int y0 = p.bbox[m * 4 + 0], x0 = p.bbox[m * 4 + 1], y1 = p.bbox[m * 4 + 2], x1 = p.bbox[m * 4 + 3];
@@ -602,7 +602,7 @@ extern "C" int64_t demia_contour_work_doubles(int M, int C, int max_points) { re
 extern "C" int demia_mask_contours(const uint32_t* masks, const uint32_t* filled, const int32_t* bbox, int M, int H, int W, int C,
                                    int max_points, int32_t* count, int32_t* info, double* red, int32_t* points,
                                    int32_t* counters, void* stream) {
-    DEMIA_REQUIRE(masks && filled && bbox && count && info && red && points && counters && W % 32 == 0, "args");
+    DEMIA_REQUIRE(masks && filled && bbox && count && info && red && points && counters && W > 0, "args");
     DEMIA_REQUIRE((long)H * W < (1L << 31) && C > 0 && max_points > 0, "sizes");
     if (M == 0) return DEMIA_OK;
     hipError_t e = hipMemsetAsync(counters, 0, 2 * sizeof(int32_t), (hipStream_t)stream);

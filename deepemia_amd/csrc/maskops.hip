@@ -83,7 +83,7 @@ __global__ __launch_bounds__(1024) void fill_holes_kernel(const uint32_t* __rest
     __shared__ int changed;
     __shared__ uint32_t lds[2 * FILL_LDS_WORDS];
     const long m = blockIdx.x;
-    const int wpr = W >> 5;
+    const int wpr = (W + 31) >> 5;
     const uint32_t* src = in + m * (long)H * wpr;
     uint32_t* dst = out + m * (long)H * wpr;
     const int y0 = bbox[m * 4 + 0], x0 = bbox[m * 4 + 1], y1 = bbox[m * 4 + 2], x1 = bbox[m * 4 + 3];
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(1024) void fill_holes_kernel(const uint32_t* __rest
         else {
             seed = ~span_mask(wx, x0, x1);
             if (wx == 0) seed |= 1u;
-            if (wx == wpr - 1) seed |= 0x80000000u;
+            if (wx == wpr - 1) seed |= 0xFFFFFFFFu << ((W - 1) & 31);   // pixel W-1 and the padding bits beyond it
         }
         if (use_lds) Mreg[ly * stride + lx] = mk;
         Rreg[ly * stride + lx] = ~mk & seed;
@@ -124,25 +124,28 @@ __global__ __launch_bounds__(1024) void fill_holes_kernel(const uint32_t* __rest
     flood_bg_iterate(Mptr, Rreg, stride, rh, rw, 2 * (H + W), &changed);
     for (int i = tid; i < rh * rw; i += nt) {
         const int ly = i / rw, lx = i - ly * rw;
-        dst[(long)(ry0 + ly) * wpr + wx0 + lx] = ~Rreg[ly * stride + lx];
+        const uint32_t valid = (wx0 + lx == wpr - 1 && (W & 31)) ? ((1u << (W & 31)) - 1u) : 0xFFFFFFFFu;
+        dst[(long)(ry0 + ly) * wpr + wx0 + lx] = ~Rreg[ly * stride + lx] & valid;
     }
 }
 
 // ---- cross erosion / dilation, border = replicate ------------------------------------------------
 template <bool DILATE>
 __global__ void morph_cross_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, long nwords, int H, int W) {
-    const int wpr = W >> 5;
+    const int wpr = (W + 31) >> 5;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nwords; i += (long)gridDim.x * blockDim.x) {
         const int wx = (int)(i % wpr);
         const int y = (int)((i / wpr) % H);
         const uint32_t c = in[i];
         const uint32_t up = y > 0 ? in[i - wpr] : c;
         const uint32_t dn = y < H - 1 ? in[i + wpr] : c;
+        const int last = (W - 1) & 31;                                           // bit of pixel W-1 in the last word
         const uint32_t lbit = wx > 0 ? (in[i - 1] >> 31) : (c & 1u);            // pixel x-1 of bit 0
-        const uint32_t rbit = wx < wpr - 1 ? (in[i + 1] & 1u) : (c >> 31);      // pixel x+1 of bit 31
         const uint32_t left = (c << 1) | lbit;     // bit b = pixel b-1
-        const uint32_t right = (c >> 1) | (rbit << 31);
-        out[i] = DILATE ? (c | up | dn | left | right) : (c & up & dn & left & right);
+        uint32_t right, valid = 0xFFFFFFFFu;
+        if (wx < wpr - 1) right = (c >> 1) | ((in[i + 1] & 1u) << 31);
+        else { right = (c >> 1) | (((c >> last) & 1u) << last); valid = last == 31 ? 0xFFFFFFFFu : ((2u << last) - 1u); }
+        out[i] = (DILATE ? (c | up | dn | left | right) : (c & up & dn & left & right)) & valid;
     }
 }
 
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(1024) void components_gt1_kernel(const uint32_t* __
     __shared__ int first;
     __shared__ uint32_t lds[2 * FILL_LDS_WORDS];
     const long m = blockIdx.x;
-    const int wpr = W >> 5;
+    const int wpr = (W + 31) >> 5;
     const uint32_t* src = in + m * (long)H * wpr;
     const int y0 = bbox[m * 4 + 0], x0 = bbox[m * 4 + 1], y1 = bbox[m * 4 + 2], x1 = bbox[m * 4 + 3];
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -242,7 +245,7 @@ __global__ void column_counts_kernel(const uint32_t* __restrict__ masks, const i
     if (y0 < 0) return;
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= W || x < x0 || x > x1) return;
-    const int wpr = W >> 5, wx = x >> 5, b = x & 31;
+    const int wpr = (W + 31) >> 5, wx = x >> 5, b = x & 31;
     const uint32_t* src = masks + (long)m * H * wpr;
     int c = 0;
     for (int y = y0; y <= y1; ++y) c += (src[(long)y * wpr + wx] >> b) & 1u;
@@ -257,7 +260,7 @@ __global__ __launch_bounds__(256) void pair_intersections_kernel(const uint32_t*
     __shared__ int acc;
     const int p = blockIdx.x;
     const int i = pi[p], j = pj[p];
-    const int wpr = W >> 5;
+    const int wpr = (W + 31) >> 5;
     const int y0 = max(bbox_a[i * 4 + 0], bbox_b[j * 4 + 0]), y1 = min(bbox_a[i * 4 + 2], bbox_b[j * 4 + 2]);
     const int x0 = max(bbox_a[i * 4 + 1], bbox_b[j * 4 + 1]), x1 = min(bbox_a[i * 4 + 3], bbox_b[j * 4 + 3]);
     if (threadIdx.x == 0) acc = 0;
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(256) void pair_intersections_kernel(const uint32_t*
 // the mask is first resized to (tile_h, tile_w) with cv2's INTER_NEAREST rule.
 __global__ void place_tile_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, const int* __restrict__ x_off,
                                   const int* __restrict__ y_off, int T, int sh, int sw, int tile_h, int tile_w, int H, int W) {
-    const int wpr = W >> 5, swpr = sw >> 5;
+    const int wpr = (W + 31) >> 5, swpr = (sw + 31) >> 5;
     const long total = (long)T * H * wpr;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int wx = (int)(i % wpr);
@@ -295,6 +298,7 @@ __global__ void place_tile_kernel(const uint32_t* __restrict__ src, uint32_t* __
             const int sy = min((int)floor((double)ty * (1.0 / ((double)tile_h / (double)sh))), sh - 1);
             const uint32_t* srow = src + ((long)t * sh + sy) * swpr;
             for (int bb = 0; bb < 32; ++bb) {
+                if (wx * 32 + bb >= W) break;                      // padding bits of the last word stay 0
                 const int tx = wx * 32 + bb - x_off[t];
                 if (tx < 0 || tx >= tile_w) continue;
                 const int sx = min((int)floor((double)tx * (1.0 / ((double)tile_w / (double)sw))), sw - 1);
@@ -314,7 +318,7 @@ inline int grid_for(long total, int block) {
 
 extern "C" int demia_mask_fill_holes(const uint32_t* in, uint32_t* out, const int32_t* bbox, int64_t M, int H, int W,
                                      void* stream) {
-    DEMIA_REQUIRE(in && out && bbox && in != out && W % 32 == 0, "args");
+    DEMIA_REQUIRE(in && out && bbox && in != out && W > 0, "args");
     if (M == 0) return DEMIA_OK;
     hipLaunchKernelGGL(fill_holes_kernel, dim3((int)M), dim3(1024), 0, (hipStream_t)stream, in, out, bbox, H, W);
     DEMIA_CHECK_LAUNCH("fill_holes_kernel");
@@ -322,8 +326,8 @@ extern "C" int demia_mask_fill_holes(const uint32_t* in, uint32_t* out, const in
 }
 
 extern "C" int demia_mask_morph_cross(const uint32_t* in, uint32_t* out, int64_t M, int H, int W, int dilate, void* stream) {
-    DEMIA_REQUIRE(in && out && in != out && W % 32 == 0, "args");
-    const long n = (long)M * H * (W / 32);
+    DEMIA_REQUIRE(in && out && in != out && W > 0, "args");
+    const long n = (long)M * H * ((W + 31) / 32);
     if (n == 0) return DEMIA_OK;
     if (dilate)
         hipLaunchKernelGGL(morph_cross_kernel<true>, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, in, out, n, H, W);
@@ -334,8 +338,8 @@ extern "C" int demia_mask_morph_cross(const uint32_t* in, uint32_t* out, int64_t
 }
 
 extern "C" int demia_mask_overlap_prefix(uint32_t* masks, const int32_t* seg, int64_t M, int H, int W, void* stream) {
-    DEMIA_REQUIRE(masks && W % 32 == 0, "args");
-    const long wpm = (long)H * (W / 32);
+    DEMIA_REQUIRE(masks && W > 0, "args");
+    const long wpm = (long)H * ((W + 31) / 32);
     if (M == 0 || wpm == 0) return DEMIA_OK;
     hipLaunchKernelGGL(overlap_prefix_kernel, dim3(grid_for(wpm, 256)), dim3(256), 0, (hipStream_t)stream, masks, seg, (int)M, wpm);
     DEMIA_CHECK_LAUNCH("overlap_prefix_kernel");
@@ -344,7 +348,7 @@ extern "C" int demia_mask_overlap_prefix(uint32_t* masks, const int32_t* seg, in
 
 extern "C" int demia_mask_components_gt1(const uint32_t* in, uint32_t* scratch, const int32_t* bbox, int32_t* flag,
                                          int64_t M, int H, int W, void* stream) {
-    DEMIA_REQUIRE(in && scratch && bbox && flag && in != scratch && W % 32 == 0, "args");
+    DEMIA_REQUIRE(in && scratch && bbox && flag && in != scratch && W > 0, "args");
     if (M == 0) return DEMIA_OK;
     hipLaunchKernelGGL(components_gt1_kernel, dim3((int)M), dim3(1024), 0, (hipStream_t)stream, in, scratch, bbox, flag, H, W);
     DEMIA_CHECK_LAUNCH("components_gt1_kernel");
@@ -353,7 +357,7 @@ extern "C" int demia_mask_components_gt1(const uint32_t* in, uint32_t* scratch, 
 
 extern "C" int demia_mask_column_counts(const uint32_t* masks, const int32_t* seg, const int32_t* bbox, int64_t M, int H, int W,
                                         int32_t* counts, void* stream) {
-    DEMIA_REQUIRE(masks && counts && W % 32 == 0, "args");
+    DEMIA_REQUIRE(masks && counts && W > 0, "args");
     if (W == 0) return DEMIA_OK;
     DEMIA_REQUIRE(bbox, "bbox");
     if (M == 0) return DEMIA_OK;
@@ -367,7 +371,7 @@ extern "C" int demia_mask_column_counts(const uint32_t* masks, const int32_t* se
 extern "C" int demia_mask_pair_intersections(const uint32_t* a, const uint32_t* b, const int32_t* pi, const int32_t* pj,
                                              const int32_t* bbox_a, const int32_t* bbox_b, int32_t* out, int64_t P,
                                              int H, int W, void* stream) {
-    DEMIA_REQUIRE(a && b && pi && pj && bbox_a && bbox_b && out && W % 32 == 0, "args");
+    DEMIA_REQUIRE(a && b && pi && pj && bbox_a && bbox_b && out && W > 0, "args");
     if (P == 0) return DEMIA_OK;
     hipLaunchKernelGGL(pair_intersections_kernel, dim3((int)P), dim3(256), 0, (hipStream_t)stream, a, b, pi, pj, bbox_a, bbox_b,
                        out, H, W);
@@ -377,8 +381,8 @@ extern "C" int demia_mask_pair_intersections(const uint32_t* a, const uint32_t* 
 
 extern "C" int demia_mask_place_tiles(const uint32_t* src, uint32_t* dst, const int32_t* x_off, const int32_t* y_off, int64_t T,
                                       int src_h, int src_w, int tile_h, int tile_w, int H, int W, void* stream) {
-    DEMIA_REQUIRE(src && dst && x_off && y_off && W % 32 == 0 && src_w % 32 == 0, "args");
-    const long n = (long)T * H * (W / 32);
+    DEMIA_REQUIRE(src && dst && x_off && y_off && W > 0 && src_w > 0, "args");
+    const long n = (long)T * H * ((W + 31) / 32);
     if (n == 0) return DEMIA_OK;
     hipLaunchKernelGGL(place_tile_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, x_off, y_off,
                        (int)T, src_h, src_w, tile_h, tile_w, H, W);

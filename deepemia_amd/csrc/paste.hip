@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void paste_kernel(const PasteP p) {
     const int inst = blockIdx.y;  // n * D + i
     const int n = inst / p.D, i = inst - n * p.D;
     const int tid = threadIdx.x;
-    const int wpr = p.out_w >> 5;  // words per row
+    const int wpr = (p.out_w + 31) >> 5;  // words per row
     const int row0 = blockIdx.x * PASTE_ROWS;
     uint32_t* dst = p.packed + ((long)inst * p.out_h + row0) * wpr;
     const int nrows = min(PASTE_ROWS, p.out_h - row0);
@@ -113,18 +113,28 @@ __global__ __launch_bounds__(256) void paste_kernel(const PasteP p) {
     }
 }
 
-__global__ void unpack_kernel(const uint32_t* __restrict__ packed, uint8_t* __restrict__ out, long nwords) {
+__global__ void unpack_kernel(const uint32_t* __restrict__ packed, uint8_t* __restrict__ out, long nwords, int W) {
+    const int wpr = (W + 31) >> 5;
+    const bool fast = (W & 31) == 0;
     for (long w = blockIdx.x * (long)blockDim.x + threadIdx.x; w < nwords; w += (long)gridDim.x * blockDim.x) {
         const uint32_t b = packed[w];
-        uint32_t o[8];
+        if (fast) {
+            uint32_t o[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const uint32_t nib = (b >> (4 * q)) & 15u;
-            o[q] = (nib & 1u) | ((nib & 2u) << 7) | ((nib & 4u) << 14) | ((nib & 8u) << 21);
+            for (int q = 0; q < 8; ++q) {
+                const uint32_t nib = (b >> (4 * q)) & 15u;
+                o[q] = (nib & 1u) | ((nib & 2u) << 7) | ((nib & 4u) << 14) | ((nib & 8u) << 21);
+            }
+            uint4* d = reinterpret_cast<uint4*>(out + w * 32);
+            d[0] = make_uint4(o[0], o[1], o[2], o[3]);
+            d[1] = make_uint4(o[4], o[5], o[6], o[7]);
+        } else {   // rows are W bytes long: byte stores, the last word of a row is partial
+            const long row = w / wpr;
+            const int wx = (int)(w - row * wpr);
+            const int n = min(32, W - wx * 32);
+            uint8_t* d = out + row * W + wx * 32;
+            for (int q = 0; q < n; ++q) d[q] = (uint8_t)((b >> q) & 1u);
         }
-        uint4* d = reinterpret_cast<uint4*>(out + w * 32);
-        d[0] = make_uint4(o[0], o[1], o[2], o[3]);
-        d[1] = make_uint4(o[4], o[5], o[6], o[7]);
     }
 }
 
@@ -133,7 +143,7 @@ __global__ __launch_bounds__(1024) void area_bbox_kernel(const uint32_t* __restr
                                                          int* __restrict__ bbox, int H, int W) {
     __shared__ int s_area, s_y0, s_y1, s_x0, s_x1;
     const long m = blockIdx.x;
-    const int wpr = W >> 5;
+    const int wpr = (W + 31) >> 5;
     const uint32_t* src = packed + m * (long)H * wpr;
     if (threadIdx.x == 0) { s_area = 0; s_y0 = 1 << 30; s_x0 = 1 << 30; s_y1 = -1; s_x1 = -1; }
     __syncthreads();
@@ -172,7 +182,7 @@ __global__ __launch_bounds__(1024) void area_bbox_kernel(const uint32_t* __restr
 extern "C" int demia_paste_masks(const demia_paste_desc* d, void* stream) {
     DEMIA_REQUIRE(d && d->mask_prob && d->det_boxes && d->det_classes && d->det_count && d->out_boxes && d->valid &&
                       d->packed, "null pointer");
-    DEMIA_REQUIRE(d->out_w % 32 == 0 && d->out_w > 0 && d->out_h > 0, "out_w must be a multiple of 32");
+    DEMIA_REQUIRE(d->out_w > 0 && d->out_h > 0, "output size");
     DEMIA_REQUIRE(d->N * d->D <= 65535, "N*D <= 65535");
     PasteP p;
     p.mask_prob = d->mask_prob; p.ld = d->ld; p.det_boxes = d->det_boxes; p.det_classes = d->det_classes;
@@ -185,19 +195,19 @@ extern "C" int demia_paste_masks(const demia_paste_desc* d, void* stream) {
 }
 
 extern "C" int demia_unpack_masks(const uint32_t* packed, uint8_t* out_bool, int64_t M, int H, int W, void* stream) {
-    DEMIA_REQUIRE(packed && out_bool && W % 32 == 0, "args");
-    const long nwords = (long)M * H * (W / 32);
+    DEMIA_REQUIRE(packed && out_bool && W > 0, "args");
+    const long nwords = (long)M * H * ((W + 31) / 32);
     if (nwords == 0) return DEMIA_OK;
     long g = (nwords + 255) / 256;
     if (g > 32768) g = 32768;
-    hipLaunchKernelGGL(unpack_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, packed, out_bool, nwords);
+    hipLaunchKernelGGL(unpack_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, packed, out_bool, nwords, W);
     DEMIA_CHECK_LAUNCH("unpack_kernel");
     return DEMIA_OK;
 }
 
 extern "C" int demia_mask_area_bbox(const uint32_t* packed, int32_t* area, int32_t* bbox, int64_t M, int H, int W,
                                     void* stream) {
-    DEMIA_REQUIRE(packed && area && bbox && W % 32 == 0, "args");
+    DEMIA_REQUIRE(packed && area && bbox && W > 0, "args");
     if (M == 0) return DEMIA_OK;
     hipLaunchKernelGGL(area_bbox_kernel, dim3((int)M), dim3(1024), 0, (hipStream_t)stream, packed, area, bbox, H, W);
     DEMIA_CHECK_LAUNCH("area_bbox_kernel");

@@ -429,11 +429,9 @@ class MaskRCNNEngine:
 
     def paste(self, mask_prob, det_boxes, det_classes, det_count, newh, neww, out_h, out_w):
         b, D = det_boxes.shape[:2]
-        if out_w % 32 != 0:
-            raise ValueError("image width must be a multiple of 32 for bit-packed masks")
         out_boxes = torch.empty((b, D, 4), dtype=torch.float32, device=self.device)
         valid = torch.empty((b, D), dtype=torch.uint8, device=self.device)
-        packed = torch.empty((b, D, out_h, out_w // 32), dtype=torch.int32, device=self.device)
+        packed = torch.empty((b, D, out_h, (out_w + 31) // 32), dtype=torch.int32, device=self.device)
         d = _lib.PasteDesc(_lib.ptr(mask_prob), mask_prob.shape[-1], _lib.ptr(det_boxes), _lib.ptr(det_classes),
                            _lib.ptr(det_count), b, D, newh, neww, out_h, out_w, _lib.ptr(out_boxes), _lib.ptr(valid),
                            _lib.ptr(packed))

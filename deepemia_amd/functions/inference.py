@@ -298,8 +298,9 @@ class InferencePipeline:
                                       iou_threshold=0.7, edge_filter_enabled=True):
         """``inference.py:2299-2485`` for one class."""
         h, w = int(image_dev.shape[0]), int(image_dev.shape[1])
-        if w % 32 or tile_size % 32:
-            raise ValueError("image width and tile_size must be multiples of 32 (bit-packed masks)")
+        if tile_size % 32:
+            raise ValueError("tile_size must be a multiple of 32 (bit-packed tile masks)")
+        self.ops.set_frame_width(w)
         ensemble = len(model_ids) > 1
 
         def class_pass(dets_per_model):
@@ -538,6 +539,7 @@ class InferencePipeline:
             return self.process_tile_batch_unbatched(key, tiles, small_classes, class_thresholds, spatial_cfg, um_pix, model_ids)
         if dets is None:
             dets = self._predict_batch(model_ids[0], key, tiles)
+        self.ops.set_frame_width(int(tiles.shape[2]))
         T, dev = len(dets), self.dev
         per_tile_parts: List[List[torch.Tensor]] = [[] for _ in range(T)]
         per_tile_scores: List[list] = [[] for _ in range(T)]
@@ -779,6 +781,7 @@ def write_measurements(ops: MaskOps, dedup_results: Dict[str, dict], test_img_pa
             if packed is None or packed.shape[0] == 0:
                 continue
             h, wd = data["hw"]
+            ops.set_frame_width(wd)
             min_area = max(5, h * wd * 0.000005 * 0.05)
             recs = ops.contours(packed, max_contours=256, um_pix=um_pix)
             rows = []

@@ -24,6 +24,17 @@ class MaskOps:
             raise _lib.HipExtensionMissing("no HIP device visible: packed-mask ops have no CPU fallback")
         self.lib = _lib.load()
         self.device = torch.device(device)
+        self._frame_w = 0
+
+    def set_frame_width(self, W: int) -> None:
+        """True pixel width of the full-frame masks in flight.  Packed rows hold ceil(W / 32) words; kernels need
+        the true W for the right border (replicate rule of the morphology, image-frame seeds of the hole fill).
+        Tensors whose row length does not match ceil(W / 32) (tile-level masks) are taken as 32 * words wide."""
+        self._frame_w = int(W)
+
+    def _w(self, packed: torch.Tensor) -> int:
+        wpr = int(packed.shape[-1])
+        return self._frame_w if (self._frame_w and (self._frame_w + 31) // 32 == wpr) else wpr * 32
 
     def _stream(self) -> int:
         return int(torch.cuda.current_stream(self.device).cuda_stream)
@@ -33,10 +44,11 @@ class MaskOps:
         """(M, H, W) bool/uint8 host array -> packed device tensor (test / interop helper)."""
         m = np.ascontiguousarray(masks != 0)
         M, H, W = m.shape
+        wpr = (W + 31) // 32
         if W % 32:
-            raise ValueError("width must be a multiple of 32")
-        packed = np.packbits(m.reshape(M, H, W // 32, 32), axis=-1, bitorder="little").view(np.uint32)
-        return torch.from_numpy(packed.reshape(M, H, W // 32).view(np.int32)).to(self.device)
+            m = np.concatenate([m, np.zeros((M, H, wpr * 32 - W), dtype=bool)], axis=2)
+        packed = np.packbits(m.reshape(M, H, wpr, 32), axis=-1, bitorder="little").view(np.uint32)
+        return torch.from_numpy(packed.reshape(M, H, wpr).view(np.int32)).to(self.device)
 
     def to_dense(self, packed: torch.Tensor, W: int) -> np.ndarray:
         M, H, wpr = packed.shape
@@ -49,7 +61,7 @@ class MaskOps:
         M, H, wpr = packed.shape
         area = torch.empty((M,), dtype=torch.int32, device=self.device)
         bbox = torch.empty((M, 4), dtype=torch.int32, device=self.device)
-        _lib.check(self.lib.demia_mask_area_bbox(_lib.ptr(packed), _lib.ptr(area), _lib.ptr(bbox), M, H, wpr * 32,
+        _lib.check(self.lib.demia_mask_area_bbox(_lib.ptr(packed), _lib.ptr(area), _lib.ptr(bbox), M, H, self._w(packed),
                                                  self._stream()), "demia_mask_area_bbox")
         return area, bbox
 
@@ -57,10 +69,11 @@ class MaskOps:
         """Per-column pixel counts over all masks ([W]), or per segment ([n_seg, W]) when ``seg`` (int32,
         non-decreasing segment id per mask) is given."""
         M, H, wpr = packed.shape
-        shape = (wpr * 32,) if seg is None else (n_seg, wpr * 32)
+        W = self._w(packed)
+        shape = (W,) if seg is None else (n_seg, W)
         counts = torch.zeros(shape, dtype=torch.int32, device=self.device)
         _, bbox = self.area_bbox(packed)
-        _lib.check(self.lib.demia_mask_column_counts(_lib.ptr(packed), _lib.ptr(seg), _lib.ptr(bbox), M, H, wpr * 32,
+        _lib.check(self.lib.demia_mask_column_counts(_lib.ptr(packed), _lib.ptr(seg), _lib.ptr(bbox), M, H, W,
                                                      _lib.ptr(counts), self._stream()), "demia_mask_column_counts")
         return counts
 
@@ -74,7 +87,7 @@ class MaskOps:
         tj = torch.from_numpy(np.ascontiguousarray(pj, dtype=np.int32)).to(self.device)
         out = torch.empty((P,), dtype=torch.int32, device=self.device)
         _lib.check(self.lib.demia_mask_pair_intersections(_lib.ptr(a), _lib.ptr(b), _lib.ptr(ti), _lib.ptr(tj), _lib.ptr(bbox_a),
-                                                          _lib.ptr(bbox_b), _lib.ptr(out), P, H, wpr * 32, self._stream()),
+                                                          _lib.ptr(bbox_b), _lib.ptr(out), P, H, self._w(a), self._stream()),
                    "demia_mask_pair_intersections")
         return out.cpu().numpy().astype(np.int64)
 
@@ -84,14 +97,14 @@ class MaskOps:
         if bbox is None:
             _, bbox = self.area_bbox(packed)
         out = torch.empty_like(packed)
-        _lib.check(self.lib.demia_mask_fill_holes(_lib.ptr(packed), _lib.ptr(out), _lib.ptr(bbox), M, H, wpr * 32, self._stream()),
+        _lib.check(self.lib.demia_mask_fill_holes(_lib.ptr(packed), _lib.ptr(out), _lib.ptr(bbox), M, H, self._w(packed), self._stream()),
                    "demia_mask_fill_holes")
         return out
 
     def _morph(self, packed: torch.Tensor, dilate: int) -> torch.Tensor:
         M, H, wpr = packed.shape
         out = torch.empty_like(packed)
-        _lib.check(self.lib.demia_mask_morph_cross(_lib.ptr(packed), _lib.ptr(out), M, H, wpr * 32, dilate, self._stream()),
+        _lib.check(self.lib.demia_mask_morph_cross(_lib.ptr(packed), _lib.ptr(out), M, H, self._w(packed), dilate, self._stream()),
                    "demia_mask_morph_cross")
         return out
 
@@ -103,7 +116,7 @@ class MaskOps:
 
     def overlap_prefix_(self, packed: torch.Tensor, seg: Optional[torch.Tensor] = None) -> torch.Tensor:
         M, H, wpr = packed.shape
-        _lib.check(self.lib.demia_mask_overlap_prefix(_lib.ptr(packed), _lib.ptr(seg), M, H, wpr * 32, self._stream()),
+        _lib.check(self.lib.demia_mask_overlap_prefix(_lib.ptr(packed), _lib.ptr(seg), M, H, self._w(packed), self._stream()),
                    "demia_mask_overlap_prefix")
         return packed
 
@@ -114,13 +127,13 @@ class MaskOps:
         scratch = torch.empty_like(packed)
         flag = torch.empty((M,), dtype=torch.int32, device=self.device)
         _lib.check(self.lib.demia_mask_components_gt1(_lib.ptr(packed), _lib.ptr(scratch), _lib.ptr(bbox), _lib.ptr(flag), M, H,
-                                                      wpr * 32, self._stream()), "demia_mask_components_gt1")
+                                                      self._w(packed), self._stream()), "demia_mask_components_gt1")
         return flag
 
     def place_tiles(self, src: torch.Tensor, x_off: Sequence[int], y_off: Sequence[int], tile_h: int, tile_w: int,
                     H: int, W: int) -> torch.Tensor:
         T, sh, swpr = src.shape
-        dst = torch.empty((T, H, W // 32), dtype=torch.int32, device=self.device)
+        dst = torch.empty((T, H, (W + 31) // 32), dtype=torch.int32, device=self.device)
         xo = torch.tensor(list(x_off), dtype=torch.int32, device=self.device)
         yo = torch.tensor(list(y_off), dtype=torch.int32, device=self.device)
         _lib.check(self.lib.demia_mask_place_tiles(_lib.ptr(src), _lib.ptr(dst), _lib.ptr(xo), _lib.ptr(yo), T, sh, swpr * 32,
@@ -132,7 +145,7 @@ class MaskOps:
         """cv2.findContours(RETR_EXTERNAL, CHAIN_APPROX_SIMPLE) + contourArea + arcLength for every mask, once;
         the returned set can be measured later for any subset of its masks without tracing again."""
         M, H, wpr = packed.shape
-        W = wpr * 32
+        W = self._w(packed)
         area, bbox = self.area_bbox(packed)
         filled = self.fill_holes(packed, bbox)
         if max_points is None:

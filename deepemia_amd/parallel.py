@@ -60,7 +60,7 @@ def decode_instance_table(header: torch.Tensor, payload: torch.Tensor, H: int, W
     device = header.device if device is None else device
     hdr = header.cpu().numpy()
     n = hdr.shape[0]
-    packed = torch.zeros((n, H, W // 32), dtype=torch.int32, device=device)
+    packed = torch.zeros((n, H, (W + 31) // 32), dtype=torch.int32, device=device)
     payload = payload.to(device)
     off = 0
     for i in range(n):

@@ -182,8 +182,8 @@ int demia_box_detections(const demia_dets_desc* d, void* stream);
  *        of instance i lives at [(i*196 + y*14 + x), dy*2+dx, class]; already sigmoid-ed
  *   det_boxes [N, D, 4] f32 network-input coords, det_classes, det_count as above
  *   out_boxes [N, D, 4] f32 output-image coords (clipped); valid [N, D] u8 (nonempty)
- *   packed    [N, D, out_h, out_w/32] u32 : bit (x & 31) of word x>>5 = mask[y][x]
- * out_w must be a multiple of 32.                                                     */
+ *   packed    [N, D, out_h, ceil(out_w/32)] u32 : bit (x & 31) of word x>>5 = mask[y][x]; the padding bits of
+ *             a partial last word are always 0.  Every packed-mask entry point takes the TRUE width W.   */
 typedef struct demia_paste_desc {
     const float* mask_prob;
     int32_t ld;
@@ -203,7 +203,7 @@ int demia_unpack_masks(const uint32_t* packed, uint8_t* out_bool, int64_t M, int
 /* per-mask popcount ("np.sum(mask)", inference.py:1688, 2599) and tight bbox [M,4] = y0,x0,y1,x1 (inclusive; -1 if empty) */
 int demia_mask_area_bbox(const uint32_t* packed, int32_t* area, int32_t* bbox, int64_t M, int H, int W, void* stream);
 
-/* a9-a15: packed-mask morphology (all masks [M, H, W/32] u32, W % 32 == 0; in != out) ------------
+/* a9-a15: packed-mask morphology (all masks [M, H, ceil(W/32)] u32, W = true pixel width; in != out) -
  * Replace, on bit-packed device masks, what the reference does with scipy / scikit-image / numpy on
  * dense host arrays:
  *   fill_holes      scipy.ndimage.binary_fill_holes           (mask_utils.py:75; inference.py:193, 1780)

@@ -219,3 +219,49 @@ def test_full_size_mask_ops_properties(ops):
     recs = ops.contours(f)
     assert len(recs[0]) == 1 and len(recs[1]) == 1
     assert recs[1][0]["area"] == (2 * 400 - 2) * (2 * 200 - 2)
+
+
+@pytest.mark.parametrize("w", [100, 77, 33])
+def test_widths_not_multiple_of_32(ops, w):
+    """Real EM frames are not always 32-aligned: packed rows hold ceil(W/32) words and the kernels use the
+    true W for the right border (replicate rule, image-frame seeds)."""
+    from oracle import postproc_ref as P
+
+    h = 60
+    rng = np.random.default_rng(w)
+    yy, xx = np.mgrid[0:h, 0:w]
+    masks = []
+    for i in range(8):
+        cy, cx, r = rng.uniform(0, h), rng.uniform(w * 0.5, w), rng.uniform(6, 25)
+        m = ((yy - cy) ** 2 + (xx - cx) ** 2 <= r * r) & ((yy - cy) ** 2 + (xx - cx) ** 2 >= (0.45 * r) ** 2)
+        if i == 3:
+            m[:, w - 1] = True          # touches the right frame
+        if i == 4:
+            m = rng.random((h, w)) > 0.5
+        masks.append(m)
+    masks = np.stack(masks)
+    ops.set_frame_width(w)
+    try:
+        p = ops.from_dense(masks)
+        assert p.shape[2] == (w + 31) // 32
+        np.testing.assert_array_equal(ops.to_dense(p, w), masks)
+        fill, er, di = ops.to_dense(ops.fill_holes(p), w), ops.to_dense(ops.erode(p), w), ops.to_dense(ops.dilate(p), w)
+        flags = ops.components_gt1(p).cpu().numpy()
+        area, bbox = ops.area_bbox(p)
+        recs = ops.contours(p, max_contours=2048)
+        for i in range(len(masks)):
+            np.testing.assert_array_equal(fill[i], P.fill_holes(masks[i]), err_msg=f"fill {i}")
+            np.testing.assert_array_equal(er[i], P.erode_cross(masks[i]), err_msg=f"erode {i}")
+            np.testing.assert_array_equal(di[i], P.dilate_cross(masks[i]), err_msg=f"dilate {i}")
+            assert int(flags[i]) == int(P.n_components8(masks[i]) > 1)
+            assert int(area[i]) == int(masks[i].sum())
+            ref = P.find_external_contours(masks[i])
+            assert len(ref) == len(recs[i])
+            for rec, c in zip(recs[i], ref):
+                np.testing.assert_array_equal(rec["points"], c)
+        # padding bits of the last word stay zero after every op
+        for t in (ops.fill_holes(p), ops.dilate(p), ops.erode(p)):
+            if w % 32:
+                assert int((t[:, :, -1] >> (w % 32)).abs().sum()) == 0
+    finally:
+        ops.set_frame_width(0)

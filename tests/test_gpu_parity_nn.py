@@ -332,3 +332,20 @@ def test_bf16_features_within_tolerance(env):
         assert float((a - b).abs().max() / b.abs().max()) < 5e-2, k
     out = eng.forward(x)
     assert int(out.count[0]) == 100
+
+
+def test_non_square_image_width_not_multiple_of_32(env):
+    """600 x 700 input: resize to 800 x 933 (pad 800 x 960), masks pasted at 600 x 700 (22 words per row)."""
+    from deepemia_amd.predictor import Predictor
+
+    R, synth = env["R"], env["synth"]
+    img = synth.em_tile(5, 700)[:600]
+    ref = R.predict(img, env["sd"], 50, THR)
+    inst = Predictor(env["eng"])(img)["instances"].to("cpu")
+    n = ref["scores"].shape[0]
+    assert len(inst) == n and n > 10
+    np.testing.assert_array_equal(inst.pred_classes.numpy(), ref["pred_classes"].numpy())
+    m, r = inst.pred_masks, ref["pred_masks"]
+    assert tuple(m.shape) == (n, 600, 700)
+    iou = (m & r).sum((1, 2)).float() / (m | r).sum((1, 2)).float().clamp(min=1)
+    assert float(iou.min()) >= 0.999
