@@ -85,6 +85,91 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 
 constexpr int ROWB = 144;  // bytes per LDS tile row: 128 B of K + 16 B pad
 
+// Epilogue shared by the conv kernels: accumulators -> LDS (f32) -> scale/bias/residual/activation on 16-byte rows.
+template <typename TO, int BM, int BN, int TM, int TN>
+__device__ __forceinline__ void conv_epilogue(const ConvP& p, char* smem, f32x16 (&acc)[TM][TN], int a_row0, int b_row0, int m0, int n0) {
+    constexpr int EROW = BN * 4 + 16;          // epilogue LDS row (f32) + pad
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    __syncthreads();
+    // ---- epilogue: accumulators -> LDS (f32) -> 16-byte rows --------------------------
+    // C layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    {
+        float* e = reinterpret_cast<float*>(smem);
+        constexpr int EF = EROW / 4;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = a_row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const int col = b_row0 + j * 32 + (lane & 31);
+                    e[row * EF + col] = acc[i][j][r];
+                }
+    }
+    __syncthreads();
+    {
+        constexpr int G = BN / 4;          // 4-channel groups per row
+        constexpr int RPP = 256 / G;       // rows per pass
+        const int g = tid % G;
+        const int r0 = tid / G;
+        const int co = n0 + g * 4;
+        TO* __restrict__ out = reinterpret_cast<TO*>(p.out);
+        const TO* __restrict__ res = reinterpret_cast<const TO*>(p.residual);
+        if (co < p.Cout) {
+            float sc[4], bs[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool ok = (co + q) < p.Cout;
+                sc[q] = (p.scale && ok) ? p.scale[co + q] : 1.0f;
+                bs[q] = (p.bias && ok) ? p.bias[co + q] : 0.0f;
+            }
+            const char* e = smem;
+            for (int r = r0; r < BM; r += RPP) {
+                const int m = m0 + r;
+                if (m >= p.M) break;
+                const float4 a4 = *reinterpret_cast<const float4*>(e + r * EROW + g * 16);
+                float v[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = v[q] * sc[q] + bs[q];
+                if (p.res_mode != DEMIA_RES_NONE) {
+                    long ridx;
+                    if (p.res_mode == DEMIA_RES_SAME) {
+                        ridx = (long)m * p.Cout + co;
+                    } else {
+                        const int n = m / p.HoWo;
+                        const int rem = m - n * p.HoWo;
+                        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+                        const int Hr = (p.Ho + 1) >> 1, Wr = (p.Wo + 1) >> 1;
+                        ridx = (((long)n * Hr + (ho >> 1)) * Wr + (wo >> 1)) * p.Cout + co;
+                    }
+                    if (p.vec_ok) {
+                        float rv[4];
+                        load4<TO>(res + ridx, rv);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] += rv[q];
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (co + q < p.Cout) v[q] += to_f32<TO>(res[ridx + q]);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = apply_act(v[q], p.act);
+                TO* o = out + (long)m * p.out_ld + co;
+                if (p.vec_ok) {
+                    store4<TO>(o, v);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (co + q < p.Cout) o[q] = from_f32<TO>(v[q]);
+                }
+            }
+        }
+    }
+}
+
 template <typename T, typename TO, int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
     constexpr int BM = WM * TM * 32;
@@ -209,82 +294,185 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
         __syncthreads();
     }
 
-    // ---- epilogue: accumulators -> LDS (f32) -> 16-byte rows --------------------------
-    // C layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-    {
-        float* e = reinterpret_cast<float*>(smem);
-        constexpr int EF = EROW / 4;
+    conv_epilogue<TO, BM, BN, TM, TN>(p, smem, acc, a_row0, b_row0, m0, n0);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// f32 convolution on the bf16 matrix pipe ("f32x3"): every f32 operand is split into three bf16 planes
+//   x = x1 + x2 + x3,  x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2)      (3 x 8 = 24 mantissa bits)
+// and a*b is taken as the six products with i + j <= 4 (a1b1, a1b2, a2b1, a1b3, a2b2, a3b1), each exact in the
+// f32 accumulator of v_mfma_f32_32x32x16_bf16; the dropped terms are <= 3 * 2^-24 |ab|, the size of one f32
+// rounding.  Six bf16 MFMAs (6 x 32 cycles per 32x32x16) replace eight f32 MFMAs (8 x 64 cycles), so the matrix
+// pipe does the same f32 dot product 2.7x faster.  Activations stay f32 in HBM (nothing else changes): the A tile
+// is split in registers on its way to LDS; weights are split once on the host ([3][CoutPad][K] bf16).
+// K-step = 32 elements; LDS rows are 64 B + 16 B pad (80 B: conflict-free ds_read_b128); 2 stages x 3 planes.
+constexpr int ROWS3 = 80;
+
+__device__ __forceinline__ void split3(float x, bf16_t& h, bf16_t& m, bf16_t& l) {
+    h = (bf16_t)x;
+    const float r1 = x - (float)h;
+    m = (bf16_t)r1;
+    const float r2 = r1 - (float)m;
+    l = (bf16_t)r2;
+}
+
+__device__ __forceinline__ f32x16 mma_bf16(const uint4& a, const uint4& b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&a), *reinterpret_cast<const bf16x8*>(&b), c, 0, 0, 0);
+}
+
+template <typename TO, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256) void conv_igemm_split_kernel(const ConvP p) {
+    constexpr int BM = WM * TM * 32;
+    constexpr int BN = WN * TN * 32;
+    constexpr int BK = 32;
+    constexpr int AV = BM / 32;                 // f32 vectors (4 elements) of A per thread per K-step
+    constexpr int BVT = 3 * BN / 64;            // 16-B bf16 vectors (8 elements) of the B planes per thread per K-step
+    constexpr int PLANE_A = BM * ROWS3, PLANE_B = BN * ROWS3;
+    static_assert((3 * BN) % 64 == 0, "BN must be a multiple of 64 / 3");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int swz = xcd_remap(blockIdx.x, p.nwg);
+    const int tile_n = swz % p.ntn, tile_m = swz / p.ntn;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const float* __restrict__ in = reinterpret_cast<const float*>(p.in);
+    const bf16_t* __restrict__ wt = reinterpret_cast<const bf16_t*>(p.w);
+
+    const int chunk = tid & 7, lrow = tid >> 3;
+    long a_base[AV];
+    int a_hi0[AV], a_wi0[AV];
+    bool a_vm[AV];
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = a_row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    const int col = b_row0 + j * 32 + (lane & 31);
-                    e[row * EF + col] = acc[i][j][r];
-                }
+    for (int i = 0; i < AV; ++i) {
+        const int m = m0 + lrow + 32 * i;
+        a_vm[i] = m < p.M;
+        const int mm = a_vm[i] ? m : 0;
+        const int n = mm / p.HoWo;
+        const int rem = mm - n * p.HoWo;
+        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+        a_hi0[i] = ho * p.stride - p.pad;
+        a_wi0[i] = wo * p.stride - p.pad;
+        a_base[i] = (((long)n * p.H + a_hi0[i]) * p.W + a_wi0[i]) * p.Cin + chunk * 4;
     }
-    __syncthreads();
-    {
-        constexpr int G = BN / 4;          // 4-channel groups per row
-        constexpr int RPP = 256 / G;       // rows per pass
-        const int g = tid % G;
-        const int r0 = tid / G;
-        const int co = n0 + g * 4;
-        TO* __restrict__ out = reinterpret_cast<TO*>(p.out);
-        const TO* __restrict__ res = reinterpret_cast<const TO*>(p.residual);
-        if (co < p.Cout) {
-            float sc[4], bs[4];
+    const long Ktot = (long)p.KH * p.KW * p.Cin;
+    const long plane_stride = (long)p.CoutPad * Ktot;
+    long b_off[BVT];
+    int b_lds[BVT];
+    bool b_vm[BVT];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const bool ok = (co + q) < p.Cout;
-                sc[q] = (p.scale && ok) ? p.scale[co + q] : 1.0f;
-                bs[q] = (p.bias && ok) ? p.bias[co + q] : 0.0f;
-            }
-            const char* e = smem;
-            for (int r = r0; r < BM; r += RPP) {
-                const int m = m0 + r;
-                if (m >= p.M) break;
-                const float4 a4 = *reinterpret_cast<const float4*>(e + r * EROW + g * 16);
-                float v[4] = {a4.x, a4.y, a4.z, a4.w};
+    for (int j = 0; j < BVT; ++j) {
+        const int v = tid + 256 * j;
+        const int plane = v / (BN * 4), rem = v - plane * (BN * 4);
+        const int row = rem >> 2, c8 = rem & 3;
+        const int co = n0 + row;
+        b_vm[j] = co < p.CoutPad;
+        b_off[j] = plane * plane_stride + (long)(b_vm[j] ? co : 0) * Ktot + c8 * 8;
+        b_lds[j] = 3 * PLANE_A + plane * PLANE_B + row * ROWS3 + c8 * 16;
+    }
+
+    // ONE LDS stage (61 KiB for 128x128) so that TWO workgroups share a CU: while one is in its barrier / split /
+    // store phase the other one's MFMAs keep the matrix pipe busy (a K-step is only 48 MFMAs, ~1.5k cycles, far
+    // too short to hide an HBM round trip behind a single wave per SIMD).  The next tile waits in registers.
+    uint4 ra[AV], rb[BVT];
+    int kh = 0, kw = 0, c0 = 0;
+    auto load_step = [&]() {
+        const long tap = ((long)kh * p.W + kw) * p.Cin + c0;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = v[q] * sc[q] + bs[q];
-                if (p.res_mode != DEMIA_RES_NONE) {
-                    long ridx;
-                    if (p.res_mode == DEMIA_RES_SAME) {
-                        ridx = (long)m * p.Cout + co;
-                    } else {
-                        const int n = m / p.HoWo;
-                        const int rem = m - n * p.HoWo;
-                        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-                        const int Hr = (p.Ho + 1) >> 1, Wr = (p.Wo + 1) >> 1;
-                        ridx = (((long)n * Hr + (ho >> 1)) * Wr + (wo >> 1)) * p.Cout + co;
-                    }
-                    if (p.vec_ok) {
-                        float rv[4];
-                        load4<TO>(res + ridx, rv);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) v[q] += rv[q];
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            if (co + q < p.Cout) v[q] += to_f32<TO>(res[ridx + q]);
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = apply_act(v[q], p.act);
-                TO* o = out + (long)m * p.out_ld + co;
-                if (p.vec_ok) {
-                    store4<TO>(o, v);
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (co + q < p.Cout) o[q] = from_f32<TO>(v[q]);
-                }
-            }
+        for (int i = 0; i < AV; ++i) {
+            const int hi = a_hi0[i] + kh, wi = a_wi0[i] + kw;
+            const bool ok = a_vm[i] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            ra[i] = ok ? *reinterpret_cast<const uint4*>(in + a_base[i] + tap) : make_uint4(0, 0, 0, 0);
         }
+        const long kof = ((long)kh * p.KW + kw) * p.Cin + c0;
+#pragma unroll
+        for (int j = 0; j < BVT; ++j)
+            rb[j] = b_vm[j] ? *reinterpret_cast<const uint4*>(wt + b_off[j] + kof) : make_uint4(0, 0, 0, 0);
+        c0 += BK;
+        if (c0 >= p.Cin) { c0 = 0; if (++kw == p.KW) { kw = 0; ++kh; } }
+    };
+    auto store_step = [&]() {
+#pragma unroll
+        for (int i = 0; i < AV; ++i) {
+            const float* f = reinterpret_cast<const float*>(&ra[i]);
+            bf16x4 h, m, l;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { bf16_t a, b, c; split3(f[q], a, b, c); h[q] = a; m[q] = b; l[q] = c; }
+            char* dst = smem + (lrow + 32 * i) * ROWS3 + chunk * 8;
+            *reinterpret_cast<bf16x4*>(dst) = h;
+            *reinterpret_cast<bf16x4*>(dst + PLANE_A) = m;
+            *reinterpret_cast<bf16x4*>(dst + 2 * PLANE_A) = l;
+        }
+#pragma unroll
+        for (int j = 0; j < BVT; ++j) *reinterpret_cast<uint4*>(smem + b_lds[j]) = rb[j];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int frag_off = (lane & 31) * ROWS3 + (lane >> 5) * 16;
+    const int a_row0 = wm * TM * 32, b_row0 = wn * TN * 32;
+    const char* sA = smem + a_row0 * ROWS3 + frag_off;
+    const char* sB = smem + 3 * PLANE_A + b_row0 * ROWS3 + frag_off;
+
+    load_step();
+    store_step();
+    __syncthreads();
+    for (int s = 0; s < p.ksteps; ++s) {
+        const bool more = (s + 1) < p.ksteps;
+        if (more) load_step();
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            uint4 fa[3][TM], fb[3][TN];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[q][i] = *reinterpret_cast<const uint4*>(sA + q * PLANE_A + i * 32 * ROWS3 + kk * 32);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[q][j] = *reinterpret_cast<const uint4*>(sB + q * PLANE_B + j * 32 * ROWS3 + kk * 32);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    f32x16 c = acc[i][j];
+                    c = mma_bf16(fa[0][i], fb[2][j], c);   // smallest terms first
+                    c = mma_bf16(fa[1][i], fb[1][j], c);
+                    c = mma_bf16(fa[2][i], fb[0][j], c);
+                    c = mma_bf16(fa[0][i], fb[1][j], c);
+                    c = mma_bf16(fa[1][i], fb[0][j], c);
+                    c = mma_bf16(fa[0][i], fb[0][j], c);
+                    acc[i][j] = c;
+                }
+        }
+        __syncthreads();                 // every wave is done reading this K-step
+        if (more) store_step();
+        __syncthreads();
     }
+    conv_epilogue<TO, BM, BN, TM, TN>(p, smem, acc, a_row0, b_row0, m0, n0);
+}
+
+template <typename TO, int WM, int WN, int TM, int TN>
+int launch_split_cfg(ConvP p, hipStream_t st) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int stage = 3 * (BM + BN) * ROWS3, epi = BM * (BN * 4 + 16);
+    constexpr int smem = stage > epi ? stage : epi;      // one tile stage, re-used by the epilogue
+    p.ntn = cdiv(p.CoutPad, BN);
+    p.nwg = p.ntn * cdiv(p.M, BM);
+    auto k = conv_igemm_split_kernel<TO, WM, WN, TM, TN>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k, dim3(p.nwg), dim3(256), smem, st, p);
+    DEMIA_CHECK_LAUNCH("conv_igemm_split_kernel");
+    return DEMIA_OK;
 }
 
 template <typename T, typename TO, int WM, int WN, int TM, int TN>
@@ -322,9 +510,10 @@ int launch_typed(ConvP p, int bn, hipStream_t st) {
 
 extern "C" int demia_conv2d_nhwc(const demia_conv_desc* d, void* stream) {
     DEMIA_REQUIRE(d && d->in && d->w && d->out, "null pointer");
-    DEMIA_REQUIRE(d->dtype == DEMIA_F32 || d->dtype == DEMIA_BF16, "dtype");
+    DEMIA_REQUIRE(d->dtype == DEMIA_F32 || d->dtype == DEMIA_BF16 || d->dtype == DEMIA_F32X3, "dtype");
     DEMIA_REQUIRE(d->out_dtype == DEMIA_F32 || d->out_dtype == DEMIA_BF16, "out_dtype");
     const int bk = d->dtype == DEMIA_BF16 ? 64 : 32;
+    DEMIA_REQUIRE(d->dtype != DEMIA_F32X3 || (d->CoutPad % 64 == 0 && d->out_dtype == DEMIA_F32), "f32x3 needs CoutPad % 64 == 0, f32 output");
     DEMIA_REQUIRE(d->Cin > 0 && d->Cin % bk == 0, "Cin must be a multiple of 64 (bf16) / 32 (f32)");
     DEMIA_REQUIRE(d->CoutPad >= d->Cout && d->CoutPad % 32 == 0, "CoutPad");
     DEMIA_REQUIRE(d->KH > 0 && d->KW > 0 && d->stride > 0 && d->pad >= 0, "kernel geometry");
@@ -349,6 +538,12 @@ extern "C" int demia_conv2d_nhwc(const demia_conv_desc* d, void* stream) {
     int bn = d->tile_hint;
     if (bn != 128 && bn != 64 && bn != 32) bn = d->CoutPad >= 128 ? 128 : (d->CoutPad >= 64 ? 64 : 32);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (d->dtype == DEMIA_F32X3) {
+        if (d->CoutPad % 128 != 0) return launch_split_cfg<float, 4, 1, 1, 2>(p, st);            // 128 x 64
+        const long blocks128 = (long)cdiv(p.M, 128) * cdiv(p.CoutPad, 128);
+        if (blocks128 < 1300) return launch_split_cfg<float, 2, 2, 1, 2>(p, st);                  // 64 x 128
+        return launch_split_cfg<float, 2, 2, 2, 2>(p, st);                                        // 128 x 128
+    }
     if (d->dtype == DEMIA_BF16) {
         if (d->out_dtype == DEMIA_BF16) return launch_typed<bf16_t, bf16_t>(p, bn, st);
         return launch_typed<bf16_t, float>(p, bn, st);

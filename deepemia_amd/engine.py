@@ -26,7 +26,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, BF16, F32, RES_NONE, RES_SAME, RES_UP2
+from ._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, BF16, F32, F32X3, RES_NONE, RES_SAME, RES_UP2
 
 RES_BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}
 PIXEL_MEAN = (103.530, 116.280, 123.675)
@@ -113,6 +113,17 @@ def cv_linear_tables(in_size: int, out_size: int, vertical: bool = False):
     return np.ascontiguousarray(ofs), np.ascontiguousarray(coef)
 
 
+def split3_bf16(w: torch.Tensor) -> torch.Tensor:
+    """x = x1 + x2 + x3 with x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2) (round to nearest even, as the
+    device cast does): the three planes carry the full 24-bit significand of an f32 value."""
+    w = w.to(torch.float32)
+    h = w.to(torch.bfloat16)
+    r1 = w - h.to(torch.float32)
+    m = r1.to(torch.bfloat16)
+    l = (r1 - m.to(torch.float32)).to(torch.bfloat16)
+    return torch.stack([h, m, l], dim=0)
+
+
 def cell_anchor_table() -> np.ndarray:
     out = np.zeros((5, 3, 4), dtype=np.float32)
     for l, size in enumerate(ANCHOR_SIZES):
@@ -136,6 +147,7 @@ class ConvLayer:
     kw: int
     stride: int
     pad: int
+    w3: Optional[torch.Tensor] = None   # f32x3 mode: the three bf16 planes of w, [3, CoutPad, KH, KW, Cin]
 
 
 @dataclass
@@ -164,6 +176,8 @@ class MaskRCNNEngine:
         self.score_thresh = float(score_thresh)
         self.device = torch.device(device)
         self.precision = precision
+        if precision not in ("f32", "f32x3", "bf16"):
+            raise ValueError("precision must be 'f32' (exact-f32 MFMA), 'f32x3' (f32 on the bf16 pipe, 3-way split) or 'bf16'")
         self.dt = BF16 if precision == "bf16" else F32
         self.tdt = torch.bfloat16 if precision == "bf16" else torch.float32
         self._tables: Dict[Tuple[int, int], dict] = {}
@@ -197,9 +211,12 @@ class MaskRCNNEngine:
         elif bias:
             b = self._get(sd, prefix + ".bias") if bias_t is None else bias_t
         dev = self.device
+        w3 = None
+        if self.precision == "f32x3" and cout_pad % 64 == 0 and cin % 32 == 0:
+            w3 = split3_bf16(wp).to(dev).contiguous()
         return ConvLayer(wp.to(dev, self.tdt).contiguous(),
                          None if scale is None else scale.to(dev).contiguous(),
-                         None if b is None else b.to(dev).contiguous(), cin, cout, cout_pad, kh, kw, stride, pad)
+                         None if b is None else b.to(dev).contiguous(), cin, cout, cout_pad, kh, kw, stride, pad, w3)
 
     def _pack(self, sd):
         bu = "backbone.bottom_up."
@@ -271,9 +288,10 @@ class MaskRCNNEngine:
         ld = out_ld if out_ld > 0 else L.cout
         if out is None:
             out = torch.empty((n, ho, wo, ld), dtype=odt, device=self.device)
-        d = _lib.ConvDesc(_lib.ptr(x), _lib.ptr(L.w), _lib.ptr(L.scale), _lib.ptr(L.bias), _lib.ptr(residual),
+        use3 = L.w3 is not None and odt == torch.float32
+        d = _lib.ConvDesc(_lib.ptr(x), _lib.ptr(L.w3 if use3 else L.w), _lib.ptr(L.scale), _lib.ptr(L.bias), _lib.ptr(residual),
                           _lib.ptr(out), n, h, w, cin, ho, wo, L.cout, L.cout_pad, L.kh, L.kw, L.stride, L.pad,
-                          self.dt, BF16 if odt == torch.bfloat16 else F32, act, res_mode, ld, tile_hint)
+                          F32X3 if use3 else self.dt, BF16 if odt == torch.bfloat16 else F32, act, res_mode, ld, tile_hint)
         ev = self.conv_events
         if ev is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

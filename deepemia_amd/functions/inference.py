@@ -756,7 +756,7 @@ def run_inference(dataset_name, output_dir, visualize=True, threshold=0.65, draw
         for a, b in zip(Img_ID, EncodedPixels):
             wri.writerow([a, b])
 
-    write_measurements(pipe.ops, dedup_results, inpath, output_dir, metadata, dataset_name, draw_scalebar)
+    write_measurements(pipe.ops, dedup_results, inpath, output_dir, metadata, dataset_name, draw_scalebar, visualize)
     with open(os.path.join(output_dir, "class_color_legend.txt"), "w") as f:
         f.write("Class Color Legend (BGR)\n")
         for i, cname in enumerate(metadata.thing_classes):
@@ -764,8 +764,37 @@ def run_inference(dataset_name, output_dir, visualize=True, threshold=0.65, draw
     return dedup_results
 
 
+def write_predictions_png(path: str, image_bgr: np.ndarray, dense_masks: np.ndarray, classes: Sequence[int], contours, thing_classes) -> None:
+    """``<img>_predictions.png`` (``inference.py:1080-1145``): per mask a 50 % colour overlay (``addWeighted(vis, 1, colour, .5)``),
+    its external contours in the class colour, instance number and class name at the centroid.  Output formatting only --
+    drawn with Pillow (OpenCV's Hershey font / line rasteriser are not reproduced)."""
+    from PIL import Image, ImageDraw
+
+    vis = image_bgr.astype(np.float32)
+    for m, cls in zip(dense_masks, classes):
+        color = np.asarray(CLASS_COLORS[int(cls) % len(CLASS_COLORS)], dtype=np.float32)
+        vis[m] = np.clip(np.rint(vis[m] + 0.5 * color), 0, 255)
+    im = Image.fromarray(vis.astype(np.uint8)[:, :, ::-1].copy())       # BGR -> RGB for Pillow
+    draw = ImageDraw.Draw(im)
+    for i, (m, cls, recs) in enumerate(zip(dense_masks, classes, contours)):
+        b, g, r = CLASS_COLORS[int(cls) % len(CLASS_COLORS)]
+        for rec in recs:
+            pts = [tuple(int(v) for v in p) for p in rec["points"]]
+            if len(pts) > 1:
+                draw.line(pts + [pts[0]], fill=(r, g, b), width=1)
+            elif pts:
+                draw.point(pts, fill=(r, g, b))
+        ys, xs = np.nonzero(m)
+        if len(ys):
+            cx, cy = int(xs.sum() / len(xs)), int(ys.sum() / len(ys))
+            cname = thing_classes[int(cls)] if int(cls) < len(thing_classes) else f"class_{int(cls)}"
+            draw.text((cx, cy - 18), f"{i + 1}", fill=(255, 255, 255))
+            draw.text((cx, cy + 6), cname, fill=(255, 255, 255))
+    im.save(path)
+
+
 def write_measurements(ops: MaskOps, dedup_results: Dict[str, dict], test_img_path: str, output_dir: str, metadata,
-                       dataset_name: str, draw_scalebar: bool = False) -> str:
+                       dataset_name: str, draw_scalebar: bool = False, visualize: bool = False) -> str:
     """Measurement phase (``inference.py:983-1291``): one CSV row per external contour that passes
     the area gate, 20 columns, ``None`` -> empty field, floats through ``csv.writer``."""
     csv_filename = os.path.join(output_dir, "measurements_results.csv")
@@ -784,6 +813,11 @@ def write_measurements(ops: MaskOps, dedup_results: Dict[str, dict], test_img_pa
             ops.set_frame_width(wd)
             min_area = max(5, h * wd * 0.000005 * 0.05)
             recs = ops.contours(packed, max_contours=256, um_pix=um_pix)
+            if visualize:
+                im = imread_bgr(os.path.join(test_img_path, test_img))
+                if im is not None:
+                    write_predictions_png(os.path.join(output_dir, f"{test_img}_predictions.png"), im, ops.to_dense(packed, wd),
+                                          classes, recs, metadata.thing_classes)
             rows = []
             for instance_id, (cls, contours) in enumerate(zip(classes, recs), 1):
                 cls = int(cls)

@@ -34,6 +34,7 @@ extern "C" {
 
 #define DEMIA_F32 0
 #define DEMIA_BF16 1
+#define DEMIA_F32X3 2   /* conv only: f32 activations, weights pre-split into 3 bf16 planes [3, CoutPad, KH*KW*Cin] */
 
 #define DEMIA_ACT_NONE 0
 #define DEMIA_ACT_RELU 1
@@ -57,7 +58,9 @@ const char* demia_build_arch(void);   /* "gfx950" */
  *   scale/bias [Cout] f32 or NULL    y = acc * scale + bias   (FrozenBN folded / conv bias)
  *   residual  NULL or out-shaped (RES_SAME) / half-res (RES_UP2), dtype `out_dtype`
  *   out       [N, Ho, Wo, Cout]      dtype `out_dtype`
- * Cin must be a multiple of 64 (bf16) / 32 (f32).  */
+ * Cin must be a multiple of 64 (bf16) / 32 (f32, f32x3).  dtype DEMIA_F32X3 computes the f32 product on the bf16
+ * matrix pipe from three-way split operands (six bf16 MFMAs per f32 FMA tile, error ~ one f32 rounding): `in` is
+ * f32, `w` holds the three bf16 planes of the f32 weights, CoutPad % 64 == 0, output f32.  */
 typedef struct demia_conv_desc {
     const void* in;
     const void* w;

@@ -77,10 +77,12 @@ CONV_CASES = [
     (256, 15, 1, 1, 0, 13, 13, 2, False, 0),
     (256, 256, 3, 1, 1, 14, 14, 5, True, 0),
     (512, 256, 1, 1, 0, 50, 50, 1, False, 2),
+    (64, 256, 3, 1, 1, 300, 300, 1, True, 1),      # > 1300 blocks: the 128 x 128 tile of the split kernel
+    (128, 192, 3, 2, 1, 61, 47, 2, True, 0),       # CoutPad % 128 != 0: the 128 x 64 tile
 ]
 
 
-@pytest.mark.parametrize("prec", ["f32", "bf16"])
+@pytest.mark.parametrize("prec", ["f32", "f32x3", "bf16"])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_igemm_vs_torch(env, case, prec):
     from deepemia_amd import engine as E
@@ -88,7 +90,7 @@ def test_conv_igemm_vs_torch(env, case, prec):
 
     cin, cout, k, stride, pad, h, w, n, relu, res = case
     g = torch.Generator().manual_seed(cin * 131 + cout * 7 + k)
-    eng = env["eng"] if prec == "f32" else E.MaskRCNNEngine.__new__(E.MaskRCNNEngine)
+    eng = env["eng"] if prec != "bf16" else E.MaskRCNNEngine.__new__(E.MaskRCNNEngine)
     if prec == "bf16":
         eng.__dict__.update(env["eng"].__dict__)
         eng.dt, eng.tdt, eng.precision = E.BF16, torch.bfloat16, "bf16"
@@ -114,6 +116,12 @@ def test_conv_igemm_vs_torch(env, case, prec):
     wp[:cout] = wt.permute(0, 2, 3, 1)
     dev = env["dev"]
     L = E.ConvLayer(wp.to(dev, eng.tdt), scale.to(dev), bias.to(dev), cin, cout, cout_pad, k, k, stride, pad)
+    if prec == "f32x3":
+        # f32 operands on the bf16 matrix pipe (3-way split, 6 products): same tolerance as the exact-f32 kernel;
+        # shapes the split kernel does not take stay on the f32 kernel, exactly as the engine packs them
+        if cout_pad % 64 or cin % 32:
+            pytest.skip("shape stays on the exact-f32 kernel")
+        L.w3 = E.split3_bf16(wp).to(dev).contiguous()
     rdev = None if residual is None else nhwc(residual).to(dev, eng.tdt)
     if prec == "bf16" and residual is not None:
         # the reference must see the rounded residual as well
@@ -122,11 +130,11 @@ def test_conv_igemm_vs_torch(env, case, prec):
         y = y + (rr if res == 1 else F.interpolate(rr, scale_factor=2.0, mode="nearest")[:, :, :ho, :wo])
         y = F.relu(y) if relu else y
     # the residual is read in the OUTPUT dtype (ABI contract), so a bf16 residual means bf16 output
-    odt = torch.float32 if (prec == "f32" or residual is None) else torch.bfloat16
+    odt = torch.float32 if (prec != "bf16" or residual is None) else torch.bfloat16
     out = eng.conv(nhwc(x).to(dev, eng.tdt), L, act=ACT_RELU if relu else ACT_NONE, residual=rdev,
                    res_mode=(RES_NONE, RES_SAME, RES_UP2)[res], out_dtype=odt)
     got = out.float().cpu().permute(0, 3, 1, 2)
-    tol = 2e-5 if prec == "f32" else 3e-2
+    tol = 2e-5 if prec != "bf16" else 3e-2
     err = float((got - y).abs().max() / y.abs().max())
     assert err <= tol, err
 

@@ -60,7 +60,7 @@ def _run_cli(monkeypatch, cfgdir, root):
     monkeypatch.setenv("DEEPEMIA_OFFLINE", "1")
     monkeypatch.chdir(root)
     C.reset_cache()
-    assert cli.main(["--task", "inference", "--dataset_name", DATASET, "--threshold", "0.3", "--no-gpu-check"]) == 0
+    assert cli.main(["--task", "inference", "--dataset_name", DATASET, "--threshold", "0.3", "--no-gpu-check", "--visualize"]) == 0
     C.reset_cache()
 
 
@@ -109,6 +109,9 @@ def _compare(split, images, ref_rows, ref_masks):
     assert rle[0] == ["ImageId", "EncodedPixels"]
     assert len(rle) - 1 == sum(len(v) for v in ref_masks.values())
     assert (split / "class_color_legend.txt").exists()
+    for name, img in images.items():                       # --visualize: one overlay per image, same size, not the input
+        vis = np.asarray(Image.open(split / f"{name}_predictions.png"))
+        assert vis.shape == img.shape and (vis != img[:, :, ::-1]).any()
 
 
 @pytest.mark.parametrize("case", ["single_r50_blobby_upscale2", "ensemble_r50_r101_upscale1"])
