@@ -16,6 +16,8 @@ LIB_PATH = _HERE / "csrc" / "libdeepemia_hip.so"
 F32, BF16, F32X3 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 RES_NONE, RES_SAME, RES_UP2 = 0, 1, 2
+# stage codes of demia_mask_program (DEMIA_MOP_*)
+MOP = {"fill": 1, "dilate": 2, "erode": 3, "drop_multi": 4, "flag_multi": 5, "gate": 6}
 
 
 class HipExtensionMissing(RuntimeError):
@@ -71,7 +73,7 @@ class PasteDesc(C.Structure):
         ("mask_prob", C.c_void_p), ("ld", C.c_int32), ("det_boxes", C.c_void_p), ("det_classes", C.c_void_p),
         ("det_count", C.c_void_p), ("N", C.c_int32), ("D", C.c_int32), ("img_h", C.c_int32), ("img_w", C.c_int32),
         ("out_h", C.c_int32), ("out_w", C.c_int32), ("out_boxes", C.c_void_p), ("valid", C.c_void_p),
-        ("packed", C.c_void_p),
+        ("packed", C.c_void_p), ("out_bbox", C.c_void_p),
     ]
 
 
@@ -98,12 +100,10 @@ EXPORTS = {
     "demia_box_detections": (C.c_int, [C.POINTER(DetsDesc), C.c_void_p]),
     "demia_paste_masks": (C.c_int, [C.POINTER(PasteDesc), C.c_void_p]),
     "demia_unpack_masks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
-    "demia_mask_area_bbox": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
-    "demia_mask_fill_holes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
-    "demia_mask_morph_cross": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
-    "demia_mask_overlap_prefix": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
-    "demia_mask_components_gt1": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
-                                             C.c_void_p]),
+    "demia_mask_area_bbox": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+    "demia_mask_program": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int64, C.c_int, C.c_int,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "demia_mask_overlap_prefix": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "demia_mask_column_counts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "demia_mask_pair_intersections": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                  C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),

@@ -16,22 +16,38 @@
 // point count), pass B writes the SIMPLE points at an atomically reserved offset.
 // Compiled with -ffp-contract=off: the f32 calipers follow OpenCV's operation order.
 #include "common.h"
+#include "maskregion.h"
 
 namespace {
 
-__constant__ int c_dx[8] = {1, 1, 0, -1, -1, -1, 0, 1};
-__constant__ int c_dy[8] = {0, -1, -1, -1, 0, 1, 1, 1};
+// Direction codes of OpenCV's tracer: 0 E, 1 NE, 2 N, 3 NW, 4 W, 5 SW, 6 S, 7 SE (y grows downwards).
+// dx + 1 / dy + 1 packed 2 bits per code -- no table in memory on the critical path of the walk.
+__device__ __forceinline__ int dir_dx(int s) { return (int)((0x901Au >> (2 * s)) & 3u) - 1; }
+__device__ __forceinline__ int dir_dy(int s) { return (int)((0xA901u >> (2 * s)) & 3u) - 1; }
 
-// Bit image of one mask restricted to its bbox region [ry0, ry0+rh) x word columns [wx0, wx0+rw): everything
+// Bit image of one mask restricted to its region [ry0, ry0+rh) x word columns [wx0, wx0+rw): everything
 // outside the region is background by construction, so probes there return 0 without touching memory.
 // `p` points at the region's first word (LDS copy when it fits, else the mask in HBM/L2), `stride` = words per row.
 struct BitImg {
     const uint32_t* p;
     int H, W, stride, ry0, wx0, rh, rw;
-    __device__ __forceinline__ int get(int x, int y) const {
-        const int ly = y - ry0, lx = (x >> 5) - wx0;
-        if (x < 0 || (unsigned)ly >= (unsigned)rh || (unsigned)lx >= (unsigned)rw) return 0;
-        return (p[ly * stride + lx] >> (x & 31)) & 1u;
+    // pixels x-1, x, x+1 of row y as bits 0..2
+    __device__ __forceinline__ uint32_t row3(int x, int y) const {
+        const int ly = y - ry0;
+        if ((unsigned)ly >= (unsigned)rh) return 0u;
+        const int k = (x - 1) >> 5;                       // word of pixel x-1 (arithmetic shift: -1 for x = 0)
+        const int lk = k - wx0;
+        const uint32_t* row = p + ly * stride;
+        const uint32_t lo = (unsigned)lk < (unsigned)rw ? row[lk] : 0u;
+        const uint32_t hi = (unsigned)(lk + 1) < (unsigned)rw ? row[lk + 1] : 0u;
+        const unsigned long long both = (unsigned long long)lo | ((unsigned long long)hi << 32);
+        return (uint32_t)(both >> ((x - 1) - 32 * k)) & 7u;
+    }
+    // the 8 neighbours of (x, y): bit s = pixel at (x + dx[s], y + dy[s])
+    __device__ __forceinline__ uint32_t nbr8(int x, int y) const {
+        const uint32_t n = row3(x, y - 1), c = row3(x, y), d = row3(x, y + 1);
+        return ((c >> 2) & 1u) | (((n >> 2) & 1u) << 1) | (((n >> 1) & 1u) << 2) | ((n & 1u) << 3) |
+               ((c & 1u) << 4) | ((d & 1u) << 5) | (((d >> 1) & 1u) << 6) | (((d >> 2) & 1u) << 7);
     }
 };
 
@@ -42,37 +58,32 @@ struct TraceResult {
     double perimeter;
 };
 
-template <bool EMIT>
-__device__ TraceResult trace_border(const BitImg& im, int sx, int sy, int* __restrict__ pts /* EMIT only */) {
+// Suzuki-Abe border following from the start pixel (sx, sy), as cv::findContours walks an outer border.
+// Points of CHAIN_APPROX_SIMPLE are counted always and written to pts[2*i], pts[2*i+1] while i < cap.
+__device__ TraceResult trace_border(const BitImg& im, int sx, int sy, int* pts, int cap) {
     TraceResult r;
     r.valid = 1; r.npts = 0; r.area2 = 0; r.perimeter = 0.0;
-    int s = 4, s_end = 4;
-    int nx, ny;
-    do {
-        s = (s - 1) & 7;
-        nx = sx + c_dx[s]; ny = sy + c_dy[s];
-    } while (im.get(nx, ny) == 0 && s != s_end);
-    if (s == s_end) {  // single pixel
-        if (EMIT) { pts[0] = sx; pts[1] = sy; }
+    uint32_t n8 = im.nbr8(sx, sy);
+    int s = -1;
+    for (int k = 3; k > -4; --k)                          // 3, 2, 1, 0, 7, 6, 5: first neighbour found clockwise from W
+        if ((n8 >> (k & 7)) & 1u) { s = k & 7; break; }
+    if (s < 0) {  // single pixel
+        if (cap > 0) { pts[0] = sx; pts[1] = sy; }
         r.npts = 1;
         return r;
     }
-    const int i1x = nx, i1y = ny;
+    const int i1x = sx + dir_dx(s), i1y = sy + dir_dy(s);
     int x = sx, y = sy;
     int prev_s = s ^ 4;
     int fx = 0, fy = 0, lx = 0, ly = 0;  // first / last emitted point
-    const long max_steps = 4L * ((long)im.H * im.W + 4);
+    const long max_steps = 4L * ((long)im.rh * im.rw * 32 + 4);
     for (long step = 0; step < max_steps; ++step) {
-        s_end = s;
-        int qx, qy;
-        for (;;) {
-            ++s;
-            qx = x + c_dx[s & 7]; qy = y + c_dy[s & 7];
-            if (im.get(qx, qy)) break;
-        }
-        s &= 7;
+        // first set neighbour in the order s+1, s+2, ... (counter-clockwise)
+        const uint32_t rot = ((n8 | (n8 << 8)) >> ((s + 1) & 7)) & 0xFFu;
+        s = (s + 1 + (__ffs((int)rot) - 1)) & 7;
+        const int qx = x + dir_dx(s), qy = y + dir_dy(s);
         if (s != prev_s) {
-            if (EMIT) { pts[2 * r.npts] = x; pts[2 * r.npts + 1] = y; }
+            if (r.npts < cap) { pts[2 * r.npts] = x; pts[2 * r.npts + 1] = y; }
             if (r.npts == 0) { fx = x; fy = y; }
             else {
                 const float ddx = (float)(x - lx), ddy = (float)(y - ly);
@@ -88,6 +99,7 @@ __device__ TraceResult trace_border(const BitImg& im, int sx, int sy, int* __res
         x = qx; y = qy;
         if (done) break;
         s = (s + 4) & 7;
+        n8 = im.nbr8(x, y);
     }
     if (r.npts > 1) {
         const float ddx = (float)(fx - lx), ddy = (float)(fy - ly);
@@ -96,12 +108,12 @@ __device__ TraceResult trace_border(const BitImg& im, int sx, int sy, int* __res
     return r;
 }
 
-constexpr int CAND_MAX = 4096;
-constexpr int TRACE_LDS_WORDS = 12288;   // 48 KiB region image (e.g. 384 rows x 1024 px)
+constexpr int CAND_MAX = 3072;
+constexpr int TRACE_WORDS = 8192;        // LDS words per region buffer (mask bits; outside flood, later the point buffer)
 
 struct ContourP {
     const uint32_t* masks;
-    const uint32_t* filled;
+    uint32_t* scratch;
     const int* bbox;
     int M, H, W, C;          // C = max contours per mask
     int max_points;
@@ -112,48 +124,74 @@ struct ContourP {
     int* counters;           // [0] = points used, [1] = error flags
 };
 
+// One workgroup per mask.  (1) region (+1 ring) -> LDS, (2) flood the outside background (what RETR_EXTERNAL
+// needs to tell an outer border from a component sitting in a hole), (3) list the start candidates, (4) one lane
+// per candidate walks its border; the raster-first candidate is a valid start by construction, so its lane
+// writes the points straight into an LDS buffer and the whole block copies them out -- the common one-contour mask
+// is walked exactly once.  Other valid starts (further components) are walked a second time to emit.
 __global__ __launch_bounds__(256) void contour_trace_kernel(const ContourP p) {
-    __shared__ int cand[CAND_MAX];
-    __shared__ int ncand, ncont;
-    __shared__ uint32_t region[TRACE_LDS_WORDS];
-    const int m = blockIdx.x, tid = threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t* regA = smem;                              // TRACE_WORDS
+    uint32_t* regB = smem + TRACE_WORDS;                // TRACE_WORDS: outside flood, then point buffer
+    int* cand = reinterpret_cast<int*>(smem + 2 * TRACE_WORDS);   // CAND_MAX
+    __shared__ int ncand, ncont, s_changed, first_cand, first_off, first_npts;
+    const int m = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const int wpr = (p.W + 31) >> 5;
-    const uint32_t* mk = p.masks + (long)m * p.H * wpr;
-    const uint32_t* fl = p.filled + (long)m * p.H * wpr;
     const int y0 = p.bbox[m * 4 + 0], x0 = p.bbox[m * 4 + 1], y1 = p.bbox[m * 4 + 2], x1 = p.bbox[m * 4 + 3];
-    if (tid == 0) { ncand = 0; ncont = 0; }
-    BitImg im{mk, p.H, p.W, wpr, 0, 0, 0, 0};
-    if (y0 >= 0) {
-        const int wx0 = x0 >> 5, rw = (x1 >> 5) - wx0 + 1, rh = y1 - y0 + 1;
-        const bool use_lds = rh * rw <= TRACE_LDS_WORDS;
-        if (use_lds)
-            for (int i = tid; i < rh * rw; i += blockDim.x) region[i] = mk[(long)(y0 + i / rw) * wpr + wx0 + i % rw];
-        im = BitImg{use_lds ? region : mk + (long)y0 * wpr + wx0, p.H, p.W, use_lds ? rw : wpr, y0, wx0, rh, rw};
+    if (y0 < 0) { if (tid == 0) p.count[m] = 0; return; }
+    if (tid == 0) { ncand = 0; ncont = 0; first_cand = 0x7FFFFFFF; first_npts = 0; }
+    mreg::Reg g;
+    g.H = p.H; g.W = p.W; g.wpr = wpr;
+    mreg::region_of(y0, x0, y1, x1, 1, p.H, p.W, g.ry0, g.wx0, g.rh, g.rw);
+    const int n = g.rh * g.rw;
+    const bool use_lds = n <= TRACE_WORDS;
+    const uint32_t* home = p.masks + (long)m * p.H * wpr + (long)g.ry0 * wpr + g.wx0;
+    if (use_lds) {
+        g.A = regA; g.B = regB; g.stride = g.rw;
+        for (int i = tid; i < n; i += nt) regA[i] = home[(long)(i / g.rw) * wpr + i % g.rw];
+    } else {
+        g.A = const_cast<uint32_t*>(home); g.B = p.scratch + (long)m * p.H * wpr + (long)g.ry0 * wpr + g.wx0; g.stride = wpr;
     }
     __syncthreads();
-    if (y0 >= 0) {
-        const int wx0 = x0 >> 5, rw = (x1 >> 5) - wx0 + 1, rh = y1 - y0 + 1;
-        for (int i = tid; i < rh * rw; i += blockDim.x) {
-            const int y = y0 + i / rw, wx = wx0 + i % rw;
-            const long o = (long)y * wpr + wx;
-            const uint32_t mm = mk[o];
-            if (!mm) continue;
-            const uint32_t ml = (mm << 1) | (wx > 0 ? mk[o - 1] >> 31 : 0u);
-            const uint32_t f = fl[o];
-            const uint32_t fleft = (f << 1) | (wx > 0 ? fl[o - 1] >> 31 : 0u);
-            uint32_t u = 0u, ul = 0u, ur = 0u;
-            if (y > 0) {
-                u = mk[o - wpr];
-                ul = (u << 1) | (wx > 0 ? mk[o - wpr - 1] >> 31 : 0u);
-                ur = (u >> 1) | (wx < wpr - 1 ? mk[o - wpr + 1] << 31 : 0u);
-            }
-            uint32_t c = mm & ~ml & ~fleft & ~u & ~ul & ~ur;
-            while (c) {
-                const int b = __ffs((int)c) - 1;
-                c &= c - 1u;
-                const int slot = atomicAdd(&ncand, 1);
-                if (slot < CAND_MAX) cand[slot] = y * p.W + wx * 32 + b;
-            }
+    // ---- outside background R (4-connected from beyond the bbox / the image frame), as in mreg::fill_holes ----
+    for (int i = tid; i < n; i += nt) {
+        const int ly = i / g.rw, lx = i - ly * g.rw;
+        const int y = g.ry0 + ly, wx = g.wx0 + lx;
+        const uint32_t mk = g.A[ly * g.stride + lx];
+        uint32_t seed;
+        if (y < y0 || y > y1 || y == 0 || y == p.H - 1) seed = 0xFFFFFFFFu;
+        else {
+            seed = ~mreg::span_mask(wx, x0, x1);
+            if (wx == 0) seed |= 1u;
+            if (wx == wpr - 1) seed |= 0xFFFFFFFFu << ((p.W - 1) & 31);
+        }
+        g.B[ly * g.stride + lx] = ~mk & seed;
+    }
+    __syncthreads();
+    mreg::flood<false>(g.A, 0xFFFFFFFFu, g.B, g.stride, g.rh, g.rw, &s_changed);
+    // ---- candidates: W, NW, N, NE background and the W pixel is OUTSIDE background (or off the frame) ------
+    for (int i = tid; i < n; i += nt) {
+        const int ly = i / g.rw, lx = i - ly * g.rw;
+        const int y = g.ry0 + ly, wx = g.wx0 + lx;
+        const int o = ly * g.stride + lx;
+        const uint32_t mm = g.A[o];
+        if (!mm) continue;
+        const uint32_t ml = (mm << 1) | (lx > 0 ? g.A[o - 1] >> 31 : 0u);
+        const uint32_t out_l = (g.B[o] << 1) | (lx > 0 ? g.B[o - 1] >> 31 : (wx == 0 ? 1u : 0u));
+        uint32_t u = 0u, ul = 0u, ur = 0u;
+        if (ly > 0) {
+            u = g.A[o - g.stride];
+            ul = (u << 1) | (lx > 0 ? g.A[o - g.stride - 1] >> 31 : 0u);
+            ur = (u >> 1) | (lx < g.rw - 1 ? g.A[o - g.stride + 1] << 31 : 0u);
+        }
+        uint32_t c = mm & ~ml & out_l & ~u & ~ul & ~ur;
+        while (c) {
+            const int b = __ffs((int)c) - 1;
+            c &= c - 1u;
+            const int slot = atomicAdd(&ncand, 1);
+            const int code = y * p.W + wx * 32 + b;
+            if (slot < CAND_MAX) cand[slot] = code;
+            atomicMin(&first_cand, code);
         }
     }
     __syncthreads();
@@ -161,9 +199,14 @@ __global__ __launch_bounds__(256) void contour_trace_kernel(const ContourP p) {
         if (tid == 0) { atomicOr(&p.counters[1], 1); p.count[m] = 0; }
         return;
     }
-    for (int c = tid; c < ncand; c += blockDim.x) {
-        const int sy = cand[c] / p.W, sx = cand[c] - sy * p.W;
-        const TraceResult r = trace_border<false>(im, sx, sy, nullptr);
+    const BitImg im{g.A, p.H, p.W, g.stride, g.ry0, g.wx0, g.rh, g.rw};
+    int* lpts = reinterpret_cast<int*>(regB);             // the flood result is no longer needed
+    const int lcap = use_lds ? TRACE_WORDS / 2 : 0;       // (in HBM mode regB is not ours: always walk twice)
+    for (int c = tid; c < ncand; c += nt) {
+        const int code = cand[c];
+        const int sy = code / p.W, sx = code - sy * p.W;
+        const bool is_first = code == first_cand;
+        const TraceResult r = trace_border(im, sx, sy, lpts, is_first ? lcap : 0);
         if (!r.valid) continue;
         const int slot = atomicAdd(&ncont, 1);
         if (slot >= p.C) { atomicOr(&p.counters[1], 2); continue; }
@@ -176,9 +219,11 @@ __global__ __launch_bounds__(256) void contour_trace_kernel(const ContourP p) {
         rd[0] = (double)(r.area2 < 0 ? -r.area2 : r.area2) * 0.5;
         rd[1] = r.perimeter;
         if (off + r.npts + 4 > p.max_points) { atomicOr(&p.counters[1], 4); inf[2] = 0; continue; }
-        trace_border<true>(im, sx, sy, p.points + 2L * off);
+        if (is_first && r.npts <= lcap) { first_off = off; first_npts = r.npts; }   // copied out by the whole block below
+        else trace_border(im, sx, sy, p.points + 2L * off, r.npts);
     }
     __syncthreads();
+    for (int i = tid; i < 2 * first_npts; i += nt) p.points[2L * first_off + i] = lpts[i];
     if (tid == 0) p.count[m] = ncont < p.C ? ncont : p.C;
 }
 
@@ -599,16 +644,22 @@ extern "C" int64_t demia_contour_work_ints(int M, int C, int max_points) { retur
 extern "C" int64_t demia_contour_work_floats(int M, int C, int max_points) { return 5L * max_points + 16L * M * C + 16; }
 extern "C" int64_t demia_contour_work_doubles(int M, int C, int max_points) { return 5L * max_points + 8L * M * C + 16; }
 
-extern "C" int demia_mask_contours(const uint32_t* masks, const uint32_t* filled, const int32_t* bbox, int M, int H, int W, int C,
+extern "C" int demia_mask_contours(const uint32_t* masks, uint32_t* scratch, const int32_t* bbox, int M, int H, int W, int C,
                                    int max_points, int32_t* count, int32_t* info, double* red, int32_t* points,
                                    int32_t* counters, void* stream) {
-    DEMIA_REQUIRE(masks && filled && bbox && count && info && red && points && counters && W > 0, "args");
+    DEMIA_REQUIRE(masks && scratch && bbox && count && info && red && points && counters && W > 0, "args");
     DEMIA_REQUIRE((long)H * W < (1L << 31) && C > 0 && max_points > 0, "sizes");
     if (M == 0) return DEMIA_OK;
     hipError_t e = hipMemsetAsync(counters, 0, 2 * sizeof(int32_t), (hipStream_t)stream);
     if (e != hipSuccess) { demia_set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return DEMIA_ELAUNCH; }
-    ContourP p{masks, filled, bbox, M, H, W, C, max_points, count, info, red, points, counters};
-    hipLaunchKernelGGL(contour_trace_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, p);
+    constexpr int smem = (2 * TRACE_WORDS + CAND_MAX) * 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(contour_trace_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_done = true;
+    }
+    ContourP p{masks, scratch, bbox, M, H, W, C, max_points, count, info, red, points, counters};
+    hipLaunchKernelGGL(contour_trace_kernel, dim3(M), dim3(256), smem, (hipStream_t)stream, p);
     DEMIA_CHECK_LAUNCH("contour_trace_kernel");
     return DEMIA_OK;
 }

@@ -10,142 +10,123 @@
 //   pair counts    np.count_nonzero(m1 & m2)                  inference.py:431, 2710; spatial_constraints.py:143,186
 //   place tile     cv2.resize(INTER_NEAREST) + paste at (x, y) offset, edge test   inference.py:2399-2420, 2522-2549
 //
-// Layout: [M, H, W/32] u32, bit (x & 31) of word (x >> 5).  Flood fills work on the mask's
-// bounding box only (holes and components cannot leave it) with a Kogge-Stone occluded fill
-// inside each word, so one iteration moves a front a whole word horizontally and one row
-// vertically; one workgroup per mask iterates to a fixed point.
+// Layout: [M, H, ceil(W/32)] u32, bit (x & 31) of word (x >> 5).  Fill / erode / dilate / component test run as
+// stage PROGRAMS on the mask's bounding-box region, in place, one workgroup per mask (maskregion.h): the frame
+// outside the box is never touched.  Every kernel that takes a bbox accepts a superset of the tight box.
 #include "common.h"
+#include "maskregion.h"
 
 namespace {
 
-__device__ __forceinline__ uint32_t fill_up(uint32_t g, uint32_t p) {  // towards higher bits, through p
-    g |= p & (g << 1); p &= p << 1;
-    g |= p & (g << 2); p &= p << 2;
-    g |= p & (g << 4); p &= p << 4;
-    g |= p & (g << 8); p &= p << 8;
-    g |= p & (g << 16);
-    return g;
-}
-__device__ __forceinline__ uint32_t fill_down(uint32_t g, uint32_t p) {
-    g |= p & (g >> 1); p &= p >> 1;
-    g |= p & (g >> 2); p &= p >> 2;
-    g |= p & (g >> 4); p &= p >> 4;
-    g |= p & (g >> 8); p &= p >> 8;
-    g |= p & (g >> 16);
-    return g;
-}
+constexpr int REG_WORDS = 8192;       // LDS words per region buffer (two buffers = 64 KiB: e.g. 512 rows x 512 px)
 
-// bits of word wx (pixels wx*32 .. wx*32+31) that lie in [x0, x1]
-__device__ __forceinline__ uint32_t span_mask(int wx, int x0, int x1) {
-    const int lo = max(x0 - wx * 32, 0), hi = min(x1 - wx * 32, 31);
-    if (lo > hi) return 0u;
-    const uint32_t upto_hi = hi == 31 ? 0xFFFFFFFFu : ((1u << (hi + 1)) - 1u);
-    return upto_hi & ~((1u << lo) - 1u);
-}
+// ---- per-mask stage programs on the bbox region, in place ----------------------------------------------------
+// program = up to 8 stage codes, 4 bits each, executed low nibble first (DEMIA_MOP_*).  The region (bbox grown by
+// one pixel per dilation + 1) is staged in LDS; the result is written back into the mask and its area / tight
+// bbox are reduced on the way out, so a chain such as fill -> dilate -> erode costs one launch and touches
+// ~1 KiB per mask instead of streaming the 512 KiB frame three times.
+struct ProgP {
+    uint32_t* masks;
+    uint32_t* scratch;
+    const int* bbox;
+    const uint8_t* active;
+    uint32_t program;
+    int H, W;
+    int* area;
+    int* bbox_out;
+    int* flag;
+};
 
-// ---- fill holes: block per mask --------------------------------------------------------------
-// R = background reachable from outside (4-connected).  The bbox region (+1 ring) of the mask and of R is
-// staged in LDS when it fits (2 x 8192 words = 64 KiB: e.g. 256 rows x 1024 px), so the fixed-point iteration
-// runs at LDS latency; larger regions iterate in place in HBM/L2.
-constexpr int FILL_LDS_WORDS = 8192;
-
-__device__ void flood_bg_iterate(const uint32_t* __restrict__ M, uint32_t* R, int stride, int rh, int rw, int max_iter, int* changed) {
-    const int tid = threadIdx.x, nt = blockDim.x;
-    for (int iter = 0; iter < max_iter; ++iter) {
-        if (tid == 0) *changed = 0;
-        __syncthreads();
-        bool ch = false;
-        for (int i = tid; i < rh * rw; i += nt) {
-            const int ly = i / rw, lx = i - ly * rw;
-            const int o = ly * stride + lx;
-            const uint32_t bg = ~M[o];
-            const uint32_t r = R[o];
-            uint32_t n = r;
-            if (ly > 0) n |= R[o - stride];
-            if (ly < rh - 1) n |= R[o + stride];
-            uint32_t lr = (r << 1) | (r >> 1);
-            if (lx > 0) lr |= R[o - 1] >> 31;
-            if (lx < rw - 1) lr |= R[o + 1] << 31;
-            uint32_t c = (n | lr) & bg;
-            c = fill_up(c, bg);
-            c = fill_down(c, bg);
-            if (c != r) { R[o] = c; ch = true; }
-        }
-        if (ch) *changed = 1;
-        __syncthreads();
-        if (!*changed) break;
-        __syncthreads();
-    }
-}
-
-__global__ __launch_bounds__(1024) void fill_holes_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
-                                                          const int* __restrict__ bbox, int H, int W) {
-    __shared__ int changed;
-    __shared__ uint32_t lds[2 * FILL_LDS_WORDS];
+__global__ __launch_bounds__(512) void mask_program_kernel(const ProgP p) {
+    __shared__ uint32_t lds[2 * REG_WORDS];
+    __shared__ int s_changed, s_first, s_area, s_y0, s_y1, s_x0, s_x1;
     const long m = blockIdx.x;
-    const int wpr = (W + 31) >> 5;
-    const uint32_t* src = in + m * (long)H * wpr;
-    uint32_t* dst = out + m * (long)H * wpr;
-    const int y0 = bbox[m * 4 + 0], x0 = bbox[m * 4 + 1], y1 = bbox[m * 4 + 2], x1 = bbox[m * 4 + 3];
     const int tid = threadIdx.x, nt = blockDim.x;
-    if (y0 < 0) {  // empty mask
-        for (int i = tid; i < H * wpr; i += nt) dst[i] = 0u;
+    const int wpr = (p.W + 31) >> 5;
+    int cy0 = p.bbox[m * 4 + 0], cx0 = p.bbox[m * 4 + 1], cy1 = p.bbox[m * 4 + 2], cx1 = p.bbox[m * 4 + 3];
+    if (cy0 < 0) {                      // empty mask stays empty under every stage
+        if (tid == 0) {
+            if (p.area) p.area[m] = 0;
+            if (p.bbox_out) { p.bbox_out[m * 4 + 0] = -1; p.bbox_out[m * 4 + 1] = -1; p.bbox_out[m * 4 + 2] = -1; p.bbox_out[m * 4 + 3] = -1; }
+            if (p.flag) p.flag[m] = 0;
+        }
         return;
     }
-    const int ry0 = max(y0 - 1, 0), ry1 = min(y1 + 1, H - 1);
-    const int wx0 = max((x0 - 1) >> 5, 0), wx1 = min((x1 + 1) >> 5, wpr - 1);
-    const int rw = wx1 - wx0 + 1, rh = ry1 - ry0 + 1;
-    const bool use_lds = rh * rw <= FILL_LDS_WORDS;
-    // everything outside the bbox rows/words is copied (no holes there)
-    for (int i = tid; i < H * wpr; i += nt) {
-        const int y = i / wpr, wx = i - y * wpr;
-        if (y < ry0 || y > ry1 || wx < wx0 || wx > wx1) dst[i] = src[i];
-    }
-    uint32_t* Mreg = use_lds ? lds : nullptr;
-    uint32_t* Rreg = use_lds ? lds + FILL_LDS_WORDS : dst + (long)ry0 * wpr + wx0;
-    const int stride = use_lds ? rw : wpr;
-    // seeds: background outside the tight bbox, or on the image frame
-    for (int i = tid; i < rh * rw; i += nt) {
-        const int ly = i / rw, lx = i - ly * rw;
-        const int y = ry0 + ly, wx = wx0 + lx;
-        const uint32_t mk = src[(long)y * wpr + wx];
-        uint32_t seed;
-        if (y < y0 || y > y1 || y == 0 || y == H - 1) seed = 0xFFFFFFFFu;
-        else {
-            seed = ~span_mask(wx, x0, x1);
-            if (wx == 0) seed |= 1u;
-            if (wx == wpr - 1) seed |= 0xFFFFFFFFu << ((W - 1) & 31);   // pixel W-1 and the padding bits beyond it
-        }
-        if (use_lds) Mreg[ly * stride + lx] = mk;
-        Rreg[ly * stride + lx] = ~mk & seed;
+    int ndil = 0;
+    for (uint32_t q = p.program; q; q >>= 4) ndil += (q & 15u) == DEMIA_MOP_DILATE;
+    mreg::Reg g;
+    g.H = p.H; g.W = p.W; g.wpr = wpr;
+    mreg::region_of(cy0, cx0, cy1, cx1, ndil + 1, p.H, p.W, g.ry0, g.wx0, g.rh, g.rw);
+    const int n = g.rh * g.rw;
+    const bool use_lds = n <= REG_WORDS;
+    uint32_t* home = p.masks + m * (long)p.H * wpr + (long)g.ry0 * wpr + g.wx0;
+    if (use_lds) {
+        g.A = lds; g.B = lds + REG_WORDS; g.stride = g.rw;
+        for (int i = tid; i < n; i += nt) g.A[i] = home[(long)(i / g.rw) * wpr + i % g.rw];
+    } else {
+        g.A = home; g.B = p.scratch + m * (long)p.H * wpr + (long)g.ry0 * wpr + g.wx0; g.stride = wpr;
     }
     __syncthreads();
-    const uint32_t* Mptr = use_lds ? Mreg : src + (long)ry0 * wpr + wx0;
-    flood_bg_iterate(Mptr, Rreg, stride, rh, rw, 2 * (H + W), &changed);
-    for (int i = tid; i < rh * rw; i += nt) {
-        const int ly = i / rw, lx = i - ly * rw;
-        const uint32_t valid = (wx0 + lx == wpr - 1 && (W & 31)) ? ((1u << (W & 31)) - 1u) : 0xFFFFFFFFu;
-        dst[(long)(ry0 + ly) * wpr + wx0 + lx] = ~Rreg[ly * stride + lx] & valid;
+    int flagged = 0;
+    for (uint32_t q = p.program; q; q >>= 4) {
+        const uint32_t op = q & 15u;
+        if (op == DEMIA_MOP_FILL) {
+            mreg::fill_holes(g, cy0, cx0, cy1, cx1, &s_changed);
+        } else if (op == DEMIA_MOP_DILATE || op == DEMIA_MOP_ERODE) {
+            if (op == DEMIA_MOP_DILATE) {
+                mreg::morph_cross<true>(g);
+                cy0 = max(cy0 - 1, 0); cx0 = max(cx0 - 1, 0); cy1 = min(cy1 + 1, p.H - 1); cx1 = min(cx1 + 1, p.W - 1);
+            } else {
+                mreg::morph_cross<false>(g);
+            }
+            uint32_t* t = g.A; g.A = g.B; g.B = t;
+        } else if (op == DEMIA_MOP_DROP_MULTI || op == DEMIA_MOP_FLAG_MULTI) {
+            const bool multi = mreg::more_than_one_component(g, &s_first, &s_changed);
+            flagged |= multi;
+            if (multi && op == DEMIA_MOP_DROP_MULTI) {
+                for (int i = tid; i < n; i += nt) g.A[(i / g.rw) * g.stride + i % g.rw] = 0u;
+                __syncthreads();
+            }
+        } else if (op == DEMIA_MOP_GATE) {
+            if (!(p.active && p.active[m])) break;
+        }
     }
-}
-
-// ---- cross erosion / dilation, border = replicate ------------------------------------------------
-template <bool DILATE>
-__global__ void morph_cross_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, long nwords, int H, int W) {
-    const int wpr = (W + 31) >> 5;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nwords; i += (long)gridDim.x * blockDim.x) {
-        const int wx = (int)(i % wpr);
-        const int y = (int)((i / wpr) % H);
-        const uint32_t c = in[i];
-        const uint32_t up = y > 0 ? in[i - wpr] : c;
-        const uint32_t dn = y < H - 1 ? in[i + wpr] : c;
-        const int last = (W - 1) & 31;                                           // bit of pixel W-1 in the last word
-        const uint32_t lbit = wx > 0 ? (in[i - 1] >> 31) : (c & 1u);            // pixel x-1 of bit 0
-        const uint32_t left = (c << 1) | lbit;     // bit b = pixel b-1
-        uint32_t right, valid = 0xFFFFFFFFu;
-        if (wx < wpr - 1) right = (c >> 1) | ((in[i + 1] & 1u) << 31);
-        else { right = (c >> 1) | (((c >> last) & 1u) << last); valid = last == 31 ? 0xFFFFFFFFu : ((2u << last) - 1u); }
-        out[i] = (DILATE ? (c | up | dn | left | right) : (c & up & dn & left & right)) & valid;
+    // ---- write back + area / tight bbox -------------------------------------------------------------------
+    if (tid == 0) { s_area = 0; s_y0 = 1 << 30; s_x0 = 1 << 30; s_y1 = -1; s_x1 = -1; }
+    __syncthreads();
+    int a = 0, y0 = 1 << 30, y1 = -1, x0 = 1 << 30, x1 = -1;
+    const bool copy = g.A != home;
+    for (int i = tid; i < n; i += nt) {
+        const int ly = i / g.rw, lx = i - ly * g.rw;
+        const uint32_t b = g.A[ly * g.stride + lx];
+        if (copy) home[(long)ly * wpr + lx] = b;
+        if (b) {
+            const int y = g.ry0 + ly, xb = (g.wx0 + lx) << 5;
+            a += __popc(b);
+            y0 = min(y0, y); y1 = max(y1, y);
+            x0 = min(x0, xb + __ffs((int)b) - 1);
+            x1 = max(x1, xb + 31 - __clz((int)b));
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_down(a, o, 64);
+        y0 = min(y0, __shfl_down(y0, o, 64)); x0 = min(x0, __shfl_down(x0, o, 64));
+        y1 = max(y1, __shfl_down(y1, o, 64)); x1 = max(x1, __shfl_down(x1, o, 64));
+    }
+    if ((tid & 63) == 0 && a) {
+        atomicAdd(&s_area, a);
+        atomicMin(&s_y0, y0); atomicMin(&s_x0, x0);
+        atomicMax(&s_y1, y1); atomicMax(&s_x1, x1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const bool e = s_area == 0;
+        if (p.area) p.area[m] = s_area;
+        if (p.bbox_out) {
+            p.bbox_out[m * 4 + 0] = e ? -1 : s_y0; p.bbox_out[m * 4 + 1] = e ? -1 : s_x0;
+            p.bbox_out[m * 4 + 2] = e ? -1 : s_y1; p.bbox_out[m * 4 + 3] = e ? -1 : s_x1;
+        }
+        if (p.flag) p.flag[m] = flagged;
     }
 }
 
@@ -165,74 +146,56 @@ __global__ void overlap_prefix_kernel(uint32_t* __restrict__ masks, const int* _
     }
 }
 
-// ---- more than one 8-connected component?  block per mask, `scratch` same shape as the masks -----
-// Flood the component of the first set pixel (8-connected) and compare with the mask; the bbox region
-// is staged in LDS when it fits, `scratch` is only touched by the out-of-LDS fallback.
-__global__ __launch_bounds__(1024) void components_gt1_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ scratch,
-                                                              const int* __restrict__ bbox, int* __restrict__ flag,
-                                                              int H, int W) {
-    __shared__ int changed;
-    __shared__ int first;
-    __shared__ uint32_t lds[2 * FILL_LDS_WORDS];
-    const long m = blockIdx.x;
-    const int wpr = (W + 31) >> 5;
-    const uint32_t* src = in + m * (long)H * wpr;
+// The same with bounding boxes (supersets allowed): one block per mask m clears, inside m's box, the pixels of
+// every earlier mask j of its segment whose box meets it.  Blocks race on purpose: block j may already have
+// removed from mask j what even earlier masks cover, but those pixels are still in the union of the earlier masks
+// that block m reads (each pixel stays in the first mask that has it), so m loses exactly the same pixels.
+__global__ __launch_bounds__(256) void overlap_prefix_bbox_kernel(uint32_t* masks, const int* __restrict__ seg,
+                                                                  const int* __restrict__ bbox, int H, int W) {
+    __shared__ int sb[256 * 4];
+    __shared__ int sj[256];
+    __shared__ int s_cnt, s_more;
+    const int m = blockIdx.x, tid = threadIdx.x;
     const int y0 = bbox[m * 4 + 0], x0 = bbox[m * 4 + 1], y1 = bbox[m * 4 + 2], x1 = bbox[m * 4 + 3];
-    const int tid = threadIdx.x, nt = blockDim.x;
-    if (y0 < 0) { if (tid == 0) flag[m] = 0; return; }
-    const int wx0 = x0 >> 5, wx1 = x1 >> 5;
-    const int rw = wx1 - wx0 + 1, rh = y1 - y0 + 1;
-    const bool use_lds = rh * rw <= FILL_LDS_WORDS;
-    const int stride = use_lds ? rw : wpr;
-    uint32_t* R = use_lds ? lds + FILL_LDS_WORDS : scratch + m * (long)H * wpr + (long)y0 * wpr + wx0;
-    const uint32_t* Mk = use_lds ? lds : src + (long)y0 * wpr + wx0;
-    if (tid == 0) first = 0x7FFFFFFF;
-    __syncthreads();
-    for (int i = tid; i < rw; i += nt)
-        if (src[(long)y0 * wpr + wx0 + i]) atomicMin(&first, i);
-    __syncthreads();
-    for (int i = tid; i < rh * rw; i += nt) {
-        const int ly = i / rw, lx = i - ly * rw;
-        const uint32_t mk = src[(long)(y0 + ly) * wpr + wx0 + lx];
-        if (use_lds) lds[ly * stride + lx] = mk;
-        R[ly * stride + lx] = (ly == 0 && lx == first) ? (mk & (0u - mk)) : 0u;
-    }
-    __syncthreads();
-    for (int iter = 0; iter < 2 * (H + W); ++iter) {
-        if (tid == 0) changed = 0;
+    if (y0 < 0) return;
+    const int wpr = (W + 31) >> 5;
+    const int s = seg ? seg[m] : 0;
+    uint32_t* mine = masks + (long)m * H * wpr;
+    const int wx0 = x0 >> 5, rw = (x1 >> 5) - wx0 + 1, rh = y1 - y0 + 1;
+    for (int jbase = m - 1; jbase >= 0; jbase -= 256) {
+        if (tid == 0) { s_cnt = 0; s_more = 1; }
         __syncthreads();
-        bool ch = false;
-        for (int i = tid; i < rh * rw; i += nt) {
-            const int ly = i / rw, lx = i - ly * rw;
-            const int o = ly * stride + lx;
-            const uint32_t fg = Mk[o];
-            const uint32_t r = R[o];
-            uint32_t v = r, lcar = 0u, rcar = 0u;
-            if (lx > 0) lcar = R[o - 1];
-            if (lx < rw - 1) rcar = R[o + 1];
-            if (ly > 0) { v |= R[o - stride]; if (lx > 0) lcar |= R[o - stride - 1]; if (lx < rw - 1) rcar |= R[o - stride + 1]; }
-            if (ly < rh - 1) { v |= R[o + stride]; if (lx > 0) lcar |= R[o + stride - 1]; if (lx < rw - 1) rcar |= R[o + stride + 1]; }
-            uint32_t c = v | (v << 1) | (v >> 1) | (lcar >> 31) | (rcar << 31);
-            c &= fg;
-            c = fill_up(c, fg);
-            c = fill_down(c, fg);
-            if (c != r) { R[o] = c; ch = true; }
+        const int j = jbase - tid;                       // earlier masks, 256 at a time
+        if (j >= 0) {
+            if (seg && seg[j] != s) s_more = 0;          // the segment starts inside this chunk
+            else {
+                const int jy0 = bbox[j * 4 + 0], jx0 = bbox[j * 4 + 1], jy1 = bbox[j * 4 + 2], jx1 = bbox[j * 4 + 3];
+                if (jy0 >= 0 && jy0 <= y1 && jy1 >= y0 && jx0 <= x1 && jx1 >= x0) {
+                    const int k = atomicAdd(&s_cnt, 1);
+                    sb[k * 4 + 0] = jy0; sb[k * 4 + 1] = jx0; sb[k * 4 + 2] = jy1; sb[k * 4 + 3] = jx1;
+                    sj[k] = j;
+                }
+            }
         }
-        if (ch) changed = 1;
         __syncthreads();
-        if (!changed) break;
+        const int cnt = s_cnt;
+        // every word of m's box belongs to ONE thread for the whole kernel: no read-modify-write race inside the block
+        for (int t = tid; t < rh * rw; t += 256) {
+            const int y = y0 + t / rw, wx = wx0 + t % rw;
+            const long o = (long)y * wpr + wx;
+            uint32_t c = mine[o];
+            if (!c) continue;
+            const uint32_t c_in = c;
+            for (int k = 0; k < cnt; ++k) {
+                if (y < sb[k * 4 + 0] || y > sb[k * 4 + 2] || wx * 32 + 31 < sb[k * 4 + 1] || wx * 32 > sb[k * 4 + 3]) continue;
+                c &= ~masks[(long)sj[k] * H * wpr + o];
+            }
+            if (c != c_in) mine[o] = c;
+        }
+        const int more = s_more;
         __syncthreads();
+        if (!more) break;
     }
-    if (tid == 0) changed = 0;
-    __syncthreads();
-    bool diff = false;
-    for (int i = tid; i < rh * rw; i += nt) {
-        const int ly = i / rw, lx = i - ly * rw;
-        if (R[ly * stride + lx] != Mk[ly * stride + lx]) diff = true;
-    }
-    if (diff) changed = 1;
-    __syncthreads();
-    if (tid == 0) flag[m] = changed;
 }
 
 // ---- per-column pixel counts over all masks of a call (counts must be zeroed by the caller) ------
@@ -316,42 +279,29 @@ inline int grid_for(long total, int block) {
 
 }  // namespace
 
-extern "C" int demia_mask_fill_holes(const uint32_t* in, uint32_t* out, const int32_t* bbox, int64_t M, int H, int W,
-                                     void* stream) {
-    DEMIA_REQUIRE(in && out && bbox && in != out && W > 0, "args");
+extern "C" int demia_mask_program(uint32_t* masks, uint32_t* scratch, const int32_t* bbox, const uint8_t* active, uint32_t program,
+                                  int64_t M, int H, int W, int32_t* area, int32_t* bbox_out, int32_t* flag, void* stream) {
+    DEMIA_REQUIRE(masks && scratch && bbox && masks != scratch && W > 0 && H > 0, "args");
+    for (uint32_t q = program; q; q >>= 4) DEMIA_REQUIRE((q & 15u) <= DEMIA_MOP_GATE, "unknown stage code");
     if (M == 0) return DEMIA_OK;
-    hipLaunchKernelGGL(fill_holes_kernel, dim3((int)M), dim3(1024), 0, (hipStream_t)stream, in, out, bbox, H, W);
-    DEMIA_CHECK_LAUNCH("fill_holes_kernel");
+    ProgP p{masks, scratch, bbox, active, program, H, W, area, bbox_out, flag};
+    hipLaunchKernelGGL(mask_program_kernel, dim3((int)M), dim3(512), 0, (hipStream_t)stream, p);
+    DEMIA_CHECK_LAUNCH("mask_program_kernel");
     return DEMIA_OK;
 }
 
-extern "C" int demia_mask_morph_cross(const uint32_t* in, uint32_t* out, int64_t M, int H, int W, int dilate, void* stream) {
-    DEMIA_REQUIRE(in && out && in != out && W > 0, "args");
-    const long n = (long)M * H * ((W + 31) / 32);
-    if (n == 0) return DEMIA_OK;
-    if (dilate)
-        hipLaunchKernelGGL(morph_cross_kernel<true>, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, in, out, n, H, W);
-    else
-        hipLaunchKernelGGL(morph_cross_kernel<false>, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, in, out, n, H, W);
-    DEMIA_CHECK_LAUNCH("morph_cross_kernel");
-    return DEMIA_OK;
-}
-
-extern "C" int demia_mask_overlap_prefix(uint32_t* masks, const int32_t* seg, int64_t M, int H, int W, void* stream) {
+extern "C" int demia_mask_overlap_prefix(uint32_t* masks, const int32_t* seg, const int32_t* bbox, int64_t M, int H, int W,
+                                         void* stream) {
     DEMIA_REQUIRE(masks && W > 0, "args");
     const long wpm = (long)H * ((W + 31) / 32);
     if (M == 0 || wpm == 0) return DEMIA_OK;
+    if (bbox) {
+        hipLaunchKernelGGL(overlap_prefix_bbox_kernel, dim3((int)M), dim3(256), 0, (hipStream_t)stream, masks, seg, bbox, H, W);
+        DEMIA_CHECK_LAUNCH("overlap_prefix_bbox_kernel");
+        return DEMIA_OK;
+    }
     hipLaunchKernelGGL(overlap_prefix_kernel, dim3(grid_for(wpm, 256)), dim3(256), 0, (hipStream_t)stream, masks, seg, (int)M, wpm);
     DEMIA_CHECK_LAUNCH("overlap_prefix_kernel");
-    return DEMIA_OK;
-}
-
-extern "C" int demia_mask_components_gt1(const uint32_t* in, uint32_t* scratch, const int32_t* bbox, int32_t* flag,
-                                         int64_t M, int H, int W, void* stream) {
-    DEMIA_REQUIRE(in && scratch && bbox && flag && in != scratch && W > 0, "args");
-    if (M == 0) return DEMIA_OK;
-    hipLaunchKernelGGL(components_gt1_kernel, dim3((int)M), dim3(1024), 0, (hipStream_t)stream, in, scratch, bbox, flag, H, W);
-    DEMIA_CHECK_LAUNCH("components_gt1_kernel");
     return DEMIA_OK;
 }
 

@@ -23,6 +23,7 @@ struct PasteP {
     float* out_boxes;
     uint8_t* valid;
     uint32_t* packed;
+    int* out_bbox;
 };
 
 constexpr int PASTE_ROWS = 8;
@@ -56,6 +57,14 @@ __global__ __launch_bounds__(256) void paste_kernel(const PasteP p) {
         if (blockIdx.x == 0) {
             reinterpret_cast<float4*>(p.out_boxes)[inst] = b;
             p.valid[inst] = (uint8_t)ok;
+            if (p.out_bbox) {     // the pixels the paste can set: y0, x0, y1, x1 inclusive (-1: none)
+                int4 h = make_int4(-1, -1, -1, -1);
+                if (ok) {
+                    h.x = max((int)floorf(b.y) - 1, 0); h.y = max((int)floorf(b.x) - 1, 0);
+                    h.z = min((int)ceilf(b.w) + 1, p.out_h) - 1; h.w = min((int)ceilf(b.z) + 1, p.out_w) - 1;
+                }
+                reinterpret_cast<int4*>(p.out_bbox)[inst] = h;
+            }
         }
     }
     __syncthreads();
@@ -138,20 +147,31 @@ __global__ void unpack_kernel(const uint32_t* __restrict__ packed, uint8_t* __re
     }
 }
 
-// one block per mask: popcount + tight bbox (y0, x0, y1, x1 inclusive; -1 when empty)
-__global__ __launch_bounds__(1024) void area_bbox_kernel(const uint32_t* __restrict__ packed, int* __restrict__ area,
-                                                         int* __restrict__ bbox, int H, int W) {
+// one block per mask: popcount + tight bbox (y0, x0, y1, x1 inclusive; -1 when empty).  hint (optional): a box
+// known to contain every set pixel (e.g. the paste box) -- only that region is read.
+__global__ __launch_bounds__(1024) void area_bbox_kernel(const uint32_t* __restrict__ packed, const int* __restrict__ hint,
+                                                         int* __restrict__ area, int* __restrict__ bbox, int H, int W) {
     __shared__ int s_area, s_y0, s_y1, s_x0, s_x1;
     const long m = blockIdx.x;
     const int wpr = (W + 31) >> 5;
     const uint32_t* src = packed + m * (long)H * wpr;
     if (threadIdx.x == 0) { s_area = 0; s_y0 = 1 << 30; s_x0 = 1 << 30; s_y1 = -1; s_x1 = -1; }
     __syncthreads();
+    int ry0 = 0, rh = H, wx0 = 0, rw = wpr;
+    if (hint) {
+        const int hy0 = hint[m * 4 + 0], hx0 = hint[m * 4 + 1], hy1 = hint[m * 4 + 2], hx1 = hint[m * 4 + 3];
+        if (hy0 < 0) rh = 0;
+        else {
+            ry0 = max(hy0, 0); rh = min(hy1, H - 1) - ry0 + 1;
+            wx0 = max(hx0, 0) >> 5; rw = (min(hx1, W - 1) >> 5) - wx0 + 1;
+        }
+    }
     int a = 0, y0 = 1 << 30, y1 = -1, x0 = 1 << 30, x1 = -1;
-    for (int w = threadIdx.x; w < H * wpr; w += blockDim.x) {
-        const uint32_t b = src[w];
+    for (int i = threadIdx.x; i < rh * rw; i += blockDim.x) {
+        const int ly = i / rw, lx = i - ly * rw;
+        const uint32_t b = src[(long)(ry0 + ly) * wpr + wx0 + lx];
         if (b) {
-            const int y = w / wpr, xb = (w - y * wpr) << 5;
+            const int y = ry0 + ly, xb = (wx0 + lx) << 5;
             a += __popc(b);
             y0 = min(y0, y); y1 = max(y1, y);
             x0 = min(x0, xb + __ffs((int)b) - 1);
@@ -163,7 +183,7 @@ __global__ __launch_bounds__(1024) void area_bbox_kernel(const uint32_t* __restr
         y0 = min(y0, __shfl_down(y0, o, 64)); x0 = min(x0, __shfl_down(x0, o, 64));
         y1 = max(y1, __shfl_down(y1, o, 64)); x1 = max(x1, __shfl_down(x1, o, 64));
     }
-    if ((threadIdx.x & 63) == 0) {
+    if ((threadIdx.x & 63) == 0 && a) {
         atomicAdd(&s_area, a);
         atomicMin(&s_y0, y0); atomicMin(&s_x0, x0);
         atomicMax(&s_y1, y1); atomicMax(&s_x1, x1);
@@ -188,6 +208,7 @@ extern "C" int demia_paste_masks(const demia_paste_desc* d, void* stream) {
     p.mask_prob = d->mask_prob; p.ld = d->ld; p.det_boxes = d->det_boxes; p.det_classes = d->det_classes;
     p.det_count = d->det_count; p.N = d->N; p.D = d->D; p.img_h = d->img_h; p.img_w = d->img_w;
     p.out_h = d->out_h; p.out_w = d->out_w; p.out_boxes = d->out_boxes; p.valid = d->valid; p.packed = d->packed;
+    p.out_bbox = d->out_bbox;
     if (d->N * d->D == 0) return DEMIA_OK;
     hipLaunchKernelGGL(paste_kernel, dim3(cdiv(d->out_h, PASTE_ROWS), d->N * d->D), dim3(256), 0, (hipStream_t)stream, p);
     DEMIA_CHECK_LAUNCH("paste_kernel");
@@ -205,11 +226,11 @@ extern "C" int demia_unpack_masks(const uint32_t* packed, uint8_t* out_bool, int
     return DEMIA_OK;
 }
 
-extern "C" int demia_mask_area_bbox(const uint32_t* packed, int32_t* area, int32_t* bbox, int64_t M, int H, int W,
+extern "C" int demia_mask_area_bbox(const uint32_t* packed, const int32_t* hint, int32_t* area, int32_t* bbox, int64_t M, int H, int W,
                                     void* stream) {
     DEMIA_REQUIRE(packed && area && bbox && W > 0, "args");
     if (M == 0) return DEMIA_OK;
-    hipLaunchKernelGGL(area_bbox_kernel, dim3((int)M), dim3(1024), 0, (hipStream_t)stream, packed, area, bbox, H, W);
+    hipLaunchKernelGGL(area_bbox_kernel, dim3((int)M), dim3(hint ? 256 : 1024), 0, (hipStream_t)stream, packed, hint, area, bbox, H, W);
     DEMIA_CHECK_LAUNCH("area_bbox_kernel");
     return DEMIA_OK;
 }

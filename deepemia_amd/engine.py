@@ -161,6 +161,7 @@ class RawDetections:
     packed: torch.Tensor     # [B, D, H, W/32] i32 (bit-packed masks)
     height: int
     width: int
+    bbox: Optional[torch.Tensor] = None   # [B, D, 4] i32: the box each paste could write (superset of the tight mask bbox)
 
 
 class MaskRCNNEngine:
@@ -450,11 +451,12 @@ class MaskRCNNEngine:
         out_boxes = torch.empty((b, D, 4), dtype=torch.float32, device=self.device)
         valid = torch.empty((b, D), dtype=torch.uint8, device=self.device)
         packed = torch.empty((b, D, out_h, (out_w + 31) // 32), dtype=torch.int32, device=self.device)
+        bbox = torch.empty((b, D, 4), dtype=torch.int32, device=self.device)
         d = _lib.PasteDesc(_lib.ptr(mask_prob), mask_prob.shape[-1], _lib.ptr(det_boxes), _lib.ptr(det_classes),
                            _lib.ptr(det_count), b, D, newh, neww, out_h, out_w, _lib.ptr(out_boxes), _lib.ptr(valid),
-                           _lib.ptr(packed))
+                           _lib.ptr(packed), _lib.ptr(bbox))
         _lib.check(self.lib.demia_paste_masks(C.byref(d), self._stream()), "demia_paste_masks")
-        return out_boxes, valid, packed
+        return out_boxes, valid, packed, bbox
 
     # ------------------------------------------------------------------ whole forward
     @torch.no_grad()
@@ -471,8 +473,8 @@ class MaskRCNNEngine:
         det_boxes, det_scores, det_classes, det_count = self.detections(logits, props, pcount, newh, neww)
         mpooled = self.roi_align(feats, det_boxes, det_count, 14)
         mask_prob = self.mask_head(mpooled)
-        out_boxes, valid, packed = self.paste(mask_prob, det_boxes, det_classes, det_count, newh, neww, h, w)
-        res = RawDetections(out_boxes, det_scores, det_classes, valid, det_count, packed, h, w)
+        out_boxes, valid, packed, bbox = self.paste(mask_prob, det_boxes, det_classes, det_count, newh, neww, h, w)
+        res = RawDetections(out_boxes, det_scores, det_classes, valid, det_count, packed, h, w, bbox)
         if keep_intermediates:
             res.dbg = dict(xin=xin, feats=feats, props=props, pscores=pscores, pcount=pcount, pooled=pooled,
                            logits=logits, det_boxes=det_boxes, mpooled=mpooled, mask_prob=mask_prob,
@@ -486,10 +488,10 @@ class MaskRCNNEngine:
         _lib.check(self.lib.demia_unpack_masks(_lib.ptr(packed), _lib.ptr(out), m, h, w, self._stream()), "demia_unpack_masks")
         return out
 
-    def area_bbox(self, packed: torch.Tensor, h: int, w: int):
+    def area_bbox(self, packed: torch.Tensor, h: int, w: int, hint: Optional[torch.Tensor] = None):
         m = packed.shape[0]
         area = torch.empty((m,), dtype=torch.int32, device=self.device)
         bbox = torch.empty((m, 4), dtype=torch.int32, device=self.device)
-        _lib.check(self.lib.demia_mask_area_bbox(_lib.ptr(packed), _lib.ptr(area), _lib.ptr(bbox), m, h, w, self._stream()),
+        _lib.check(self.lib.demia_mask_area_bbox(_lib.ptr(packed), _lib.ptr(hint), _lib.ptr(area), _lib.ptr(bbox), m, h, w, self._stream()),
                    "demia_mask_area_bbox")
         return area, bbox

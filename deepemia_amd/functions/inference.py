@@ -124,8 +124,10 @@ def determine_small_classes(class_avg_sizes: Dict[int, float], threshold_percent
 class _Detections:
     """One predictor call's result, device-resident (masks packed) + small host tables."""
 
-    def __init__(self, packed: torch.Tensor, scores: np.ndarray, classes: np.ndarray, hw: Tuple[int, int]):
+    def __init__(self, packed: torch.Tensor, scores: np.ndarray, classes: np.ndarray, hw: Tuple[int, int],
+                 bbox: Optional[torch.Tensor] = None):
         self.packed, self.scores, self.classes, self.hw = packed, scores, classes, hw
+        self.bbox = bbox      # [n, 4] int32 on the device: the paste boxes (supersets of the tight mask boxes) or None
 
 
 class EmptyEnsembleTypeError(ValueError):
@@ -178,8 +180,12 @@ class InferencePipeline:
             for b in range(raw.count.shape[0]):
                 n = int(counts[b])
                 sel = np.nonzero(valid[b, :n])[0]
-                packed = raw.packed[b, :n] if len(sel) == n else raw.packed[b, torch.from_numpy(sel).to(self.dev)]
-                out.append(_Detections(packed, scores[b, :n][sel], classes[b, :n][sel], (h, w)))
+                if len(sel) == n:
+                    packed, bbox = raw.packed[b, :n], (None if raw.bbox is None else raw.bbox[b, :n])
+                else:
+                    si = torch.from_numpy(sel).to(self.dev)
+                    packed, bbox = raw.packed[b, si], (None if raw.bbox is None else raw.bbox[b, si])
+                out.append(_Detections(packed, scores[b, :n][sel], classes[b, :n][sel], (h, w), bbox))
         return out
 
     def _predict_batch(self, model_idx: int, key: str, images: torch.Tensor) -> List[_Detections]:
@@ -207,11 +213,13 @@ class InferencePipeline:
         if len(sel) == 0:
             return None, [], []
         scores = det.scores[sel]
-        masks = det.packed[torch.from_numpy(sel).to(self.dev)].contiguous()
+        si = torch.from_numpy(sel).to(self.dev)
+        masks = det.packed[si].contiguous()
+        hint = None if det.bbox is None else det.bbox[si].contiguous()
         is_small = target_class in small_classes
         ccfg = self.class_specific_settings.get(f"class_{target_class}", {})
         min_size = ccfg.get("min_size", 5 if is_small else 25)
-        processed = postprocess_masks_device(self.ops, masks, scores, min_crys_size=min_size)
+        processed = postprocess_masks_device(self.ops, masks, scores, min_crys_size=min_size, bbox=hint)
         if processed is None or processed.shape[0] == 0:
             return None, [], []
         if processed.shape[0] > 2 and self.parallel_mask_processing:
@@ -232,8 +240,10 @@ class InferencePipeline:
             sel = np.nonzero((det.classes == target_class) & (det.scores >= conf_threshold))[0]
             if len(sel) == 0:
                 continue
-            masks = det.packed[torch.from_numpy(sel).to(self.dev)].contiguous()
-            kept_masks, kept_idx = postprocess_masks_universal_device(self.ops, masks, hw, is_small)
+            si = torch.from_numpy(sel).to(self.dev)
+            masks = det.packed[si].contiguous()
+            hint = None if det.bbox is None else det.bbox[si].contiguous()
+            kept_masks, kept_idx = postprocess_masks_universal_device(self.ops, masks, hw, is_small, bbox=hint)
             if len(kept_idx) == 0:
                 continue
             all_masks.append(kept_masks)
@@ -426,23 +436,29 @@ class InferencePipeline:
         other kernel is per mask anyway.  Returns per tile (index tensor into the returned big tensor, scores)."""
         T = len(dets)
         dev = self.dev
-        sels, parts = [], []
+        sels, parts, hints = [], [], []
         for det in dets:
             sel = np.nonzero(det.classes == target_class)[0]
             sel = sel[det.scores[sel] >= conf]
             sels.append(sel)
             if len(sel):
-                parts.append(det.packed[torch.from_numpy(sel).to(dev)])
+                si = torch.from_numpy(sel).to(dev)
+                parts.append(det.packed[si])
+                hints.append(None if det.bbox is None else det.bbox[si])
         lens = [len(x) for x in sels]
         empty = [([], []) for _ in range(T)]
         if sum(lens) == 0:
-            return None, empty
-        packed = torch.cat(parts, dim=0)
+            return None, empty, None
+        packed = torch.cat(parts, dim=0)          # our own copy: every stage below works on it in place
+        if any(h is None for h in hints):
+            _, bbox = self.ops.area_bbox(packed)
+        else:
+            bbox = torch.cat(hints, dim=0).contiguous()
         is_small = target_class in small_classes
         min_size = self.class_specific_settings.get(f"class_{target_class}", {}).get("min_size", 5 if is_small else 25)
         seg_np = np.repeat(np.arange(T, dtype=np.int32), lens)
         seg = torch.from_numpy(seg_np).to(dev)
-        ncols = (self.ops.column_counts(packed, seg, T) > min_size).sum(dim=1).cpu().numpy()
+        ncols = (self.ops.column_counts(packed, seg, T, bbox=bbox) > min_size).sum(dim=1).cpu().numpy()
         keep_idx, new_lens, start = [], [0] * T, 0
         for t in range(T):
             n = lens[t]
@@ -456,23 +472,24 @@ class InferencePipeline:
                 new_lens[t] = n_keep
             start += n
         if sum(new_lens) == 0:
-            return None, empty
+            return None, empty, None
         if len(keep_idx) != packed.shape[0]:
-            packed = packed[torch.tensor(keep_idx, dtype=torch.long, device=dev)].contiguous()
+            ki = torch.tensor(keep_idx, dtype=torch.long, device=dev)
+            packed, bbox = packed[ki].contiguous(), bbox[ki].contiguous()
             seg_np = np.repeat(np.arange(T, dtype=np.int32), new_lens)
             seg = torch.from_numpy(seg_np).to(dev)
-        closed = self.ops.erode(self.ops.dilate(self.ops.fill_holes(packed)))
-        self.ops.overlap_prefix_(closed, seg)
-        closed[self.ops.components_gt1(closed).bool()] = 0
+        # a9: fill holes -> closing, then the score-ordered overlap removal, then the component test; a11 (calls with
+        # more than two masks): fill -> erosion -> dilation.  Two region programs + one overlap launch, all in place.
+        _, bbox, _ = self.ops.program_(packed, ["fill", "dilate", "erode"], bbox)
+        self.ops.overlap_prefix_(packed, seg, bbox)
         if self.parallel_mask_processing:
-            big = np.nonzero(np.asarray(new_lens)[seg_np] > 2)[0]
-            if len(big) == closed.shape[0]:
-                closed = process_masks_device(self.ops, closed)
-            elif len(big):
-                bi = torch.from_numpy(big).to(dev)
-                closed[bi] = process_masks_device(self.ops, closed[bi].contiguous())
+            active = torch.from_numpy((np.asarray(new_lens)[seg_np] > 2).astype(np.uint8)).to(dev)
+            area, bbox, _ = self.ops.program_(packed, ["drop_multi", "gate", "fill", "erode", "dilate"], bbox, active)
+        else:
+            area, bbox, _ = self.ops.program_(packed, ["drop_multi"], bbox)
+        closed = packed
         thr = 0.5 if is_small else iou_threshold
-        alg = DeviceMaskAlgebra(self.ops, closed)
+        alg = DeviceMaskAlgebra(self.ops, closed, area=area, bbox=bbox)
         bounds = np.concatenate(([0], np.cumsum(new_lens)))
         alg.prefetch_overlapping_pairs([list(range(bounds[t], bounds[t + 1])) for t in range(T) if new_lens[t] > 1])
         out = []
@@ -480,7 +497,7 @@ class InferencePipeline:
             kept = self._greedy_keep(alg, range(bounds[t], bounds[t + 1]), thr)
             sc = dets[t].scores[sels[t]] if lens[t] else []
             out.append((kept, [sc[i - bounds[t]] for i in kept]))
-        return closed, out
+        return closed, out, alg
 
     @staticmethod
     def _dedup_smart_order(alg: DeviceMaskAlgebra, k0: Sequence[int], scores, classes, bb, iou_threshold: float) -> List[int]:
@@ -544,8 +561,10 @@ class InferencePipeline:
         per_tile_parts: List[List[torch.Tensor]] = [[] for _ in range(T)]
         per_tile_scores: List[list] = [[] for _ in range(T)]
         per_tile_classes: List[list] = [[] for _ in range(T)]
+        per_tile_area: List[list] = [[] for _ in range(T)]
+        per_tile_bbox: List[list] = [[] for _ in range(T)]
         for cls, (conf, iou_thr) in class_thresholds.items():
-            big, res = self._single_class_pass_batched(dets, cls, small_classes, conf, iou_thr)
+            big, res, calg = self._single_class_pass_batched(dets, cls, small_classes, conf, iou_thr)
             if big is None:
                 continue
             for t, (kept, sc) in enumerate(res):
@@ -553,6 +572,8 @@ class InferencePipeline:
                     per_tile_parts[t].append(big[torch.tensor(kept, dtype=torch.long, device=dev)])
                     per_tile_scores[t].extend(sc)
                     per_tile_classes[t].extend([cls] * len(kept))
+                    per_tile_area[t].append(calg.area[kept])           # already reduced by the class pass
+                    per_tile_bbox[t].append(calg.bbox[kept])
         # ---- cross-class dedup (a14) for all tiles: one contour launch, one pair-count launch -------------------
         lens = [sum(int(p.shape[0]) for p in per_tile_parts[t]) for t in range(T)]
         out = [(None, [], [], []) for _ in range(T)]
@@ -560,8 +581,11 @@ class InferencePipeline:
             return out
         allp = torch.cat([p for t in range(T) for p in per_tile_parts[t]], dim=0)
         bounds = np.concatenate(([0], np.cumsum(lens)))
-        alg = DeviceMaskAlgebra(self.ops, allp)
-        cset = self.ops.trace(allp, max_contours=256)       # traced ONCE: reused for the final measurements
+        area_all = np.concatenate([a for t in range(T) for a in per_tile_area[t]])
+        bbox_all = np.concatenate([b for t in range(T) for b in per_tile_bbox[t]])
+        alg = DeviceMaskAlgebra(self.ops, allp, area=area_all, bbox=bbox_all)
+        # traced ONCE: reused for the final measurements
+        cset = self.ops.trace(allp, max_contours=256, bbox=alg._bbox_dev, total_area=int(area_all.sum()))
         per0 = cset.first_contour_perimeter()
         keep0_all, groups = [], []
         for t in range(T):
@@ -590,8 +614,7 @@ class InferencePipeline:
             gl = [k0[i] for i in keep]
             sc, cl = [scores[i] for i in keep], [classes[i] for i in keep]
             if gl and spatial_cfg is not None and spatial_cfg.get("enabled", False):
-                sub = allp[torch.tensor(gl, dtype=torch.long, device=dev)].contiguous()
-                kk = apply_spatial_constraints_indices(DeviceMaskAlgebra(self.ops, sub), sc, cl, spatial_cfg)
+                kk = apply_spatial_constraints_indices(alg.view(gl), sc, cl, spatial_cfg)
                 gl, sc, cl = [gl[i] for i in kk], [sc[i] for i in kk], [cl[i] for i in kk]
             final_idx.append(gl)
             out[t] = (None, sc, cl, [])

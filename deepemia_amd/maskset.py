@@ -57,22 +57,26 @@ class MaskOps:
         return out.cpu().numpy()
 
     # -- reductions -----------------------------------------------------------------------------
-    def area_bbox(self, packed: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    def area_bbox(self, packed: torch.Tensor, hint: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Pixel count and tight bbox per mask.  ``hint`` ([M, 4] int32 boxes known to contain the masks, e.g. the
+        paste boxes) restricts the scan to those regions instead of the whole frame."""
         M, H, wpr = packed.shape
         area = torch.empty((M,), dtype=torch.int32, device=self.device)
         bbox = torch.empty((M, 4), dtype=torch.int32, device=self.device)
-        _lib.check(self.lib.demia_mask_area_bbox(_lib.ptr(packed), _lib.ptr(area), _lib.ptr(bbox), M, H, self._w(packed),
-                                                 self._stream()), "demia_mask_area_bbox")
+        _lib.check(self.lib.demia_mask_area_bbox(_lib.ptr(packed), _lib.ptr(hint), _lib.ptr(area), _lib.ptr(bbox), M, H,
+                                                 self._w(packed), self._stream()), "demia_mask_area_bbox")
         return area, bbox
 
-    def column_counts(self, packed: torch.Tensor, seg: Optional[torch.Tensor] = None, n_seg: int = 1) -> torch.Tensor:
+    def column_counts(self, packed: torch.Tensor, seg: Optional[torch.Tensor] = None, n_seg: int = 1,
+                      bbox: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Per-column pixel counts over all masks ([W]), or per segment ([n_seg, W]) when ``seg`` (int32,
         non-decreasing segment id per mask) is given."""
         M, H, wpr = packed.shape
         W = self._w(packed)
         shape = (W,) if seg is None else (n_seg, W)
         counts = torch.zeros(shape, dtype=torch.int32, device=self.device)
-        _, bbox = self.area_bbox(packed)
+        if bbox is None:
+            _, bbox = self.area_bbox(packed)
         _lib.check(self.lib.demia_mask_column_counts(_lib.ptr(packed), _lib.ptr(seg), _lib.ptr(bbox), M, H, W,
                                                      _lib.ptr(counts), self._stream()), "demia_mask_column_counts")
         return counts
@@ -92,43 +96,53 @@ class MaskOps:
         return out.cpu().numpy().astype(np.int64)
 
     # -- morphology -----------------------------------------------------------------------------
-    def fill_holes(self, packed: torch.Tensor, bbox: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def program_(self, packed: torch.Tensor, stages: Sequence[str], bbox: Optional[torch.Tensor] = None,
+                 active: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """Run per-mask stages IN PLACE on the bbox region of every mask (``demia_mask_program``): ``stages`` from
+        ``fill``, ``dilate``, ``erode``, ``drop_multi``, ``flag_multi``, ``gate`` (masks with ``active[m] == 0`` stop
+        there).  ``bbox`` may be any superset of the tight boxes.  Returns (area, tight bbox, multi-component flag) of
+        the result."""
         M, H, wpr = packed.shape
+        assert len(stages) <= 8 and packed.is_contiguous()
+        prog = 0
+        for i, st in enumerate(stages):
+            prog |= _lib.MOP[st] << (4 * i)
         if bbox is None:
             _, bbox = self.area_bbox(packed)
-        out = torch.empty_like(packed)
-        _lib.check(self.lib.demia_mask_fill_holes(_lib.ptr(packed), _lib.ptr(out), _lib.ptr(bbox), M, H, self._w(packed), self._stream()),
-                   "demia_mask_fill_holes")
+        area = torch.empty((M,), dtype=torch.int32, device=self.device)
+        bbox_out = torch.empty((M, 4), dtype=torch.int32, device=self.device)
+        flag = torch.empty((M,), dtype=torch.int32, device=self.device)
+        scratch = torch.empty_like(packed)       # only touched by regions that do not fit in LDS
+        _lib.check(self.lib.demia_mask_program(_lib.ptr(packed), _lib.ptr(scratch), _lib.ptr(bbox), _lib.ptr(active), prog, M, H,
+                                               self._w(packed), _lib.ptr(area), _lib.ptr(bbox_out), _lib.ptr(flag),
+                                               self._stream()), "demia_mask_program")
+        return area, bbox_out, flag
+
+    def fill_holes(self, packed: torch.Tensor, bbox: Optional[torch.Tensor] = None) -> torch.Tensor:
+        out = packed.clone()
+        self.program_(out, ["fill"], bbox)
         return out
 
-    def _morph(self, packed: torch.Tensor, dilate: int) -> torch.Tensor:
-        M, H, wpr = packed.shape
-        out = torch.empty_like(packed)
-        _lib.check(self.lib.demia_mask_morph_cross(_lib.ptr(packed), _lib.ptr(out), M, H, self._w(packed), dilate, self._stream()),
-                   "demia_mask_morph_cross")
+    def erode(self, packed: torch.Tensor, bbox: Optional[torch.Tensor] = None) -> torch.Tensor:
+        out = packed.clone()
+        self.program_(out, ["erode"], bbox)
         return out
 
-    def erode(self, packed: torch.Tensor) -> torch.Tensor:
-        return self._morph(packed, 0)
+    def dilate(self, packed: torch.Tensor, bbox: Optional[torch.Tensor] = None) -> torch.Tensor:
+        out = packed.clone()
+        self.program_(out, ["dilate"], bbox)
+        return out
 
-    def dilate(self, packed: torch.Tensor) -> torch.Tensor:
-        return self._morph(packed, 1)
-
-    def overlap_prefix_(self, packed: torch.Tensor, seg: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def overlap_prefix_(self, packed: torch.Tensor, seg: Optional[torch.Tensor] = None,
+                        bbox: Optional[torch.Tensor] = None) -> torch.Tensor:
         M, H, wpr = packed.shape
-        _lib.check(self.lib.demia_mask_overlap_prefix(_lib.ptr(packed), _lib.ptr(seg), M, H, self._w(packed), self._stream()),
-                   "demia_mask_overlap_prefix")
+        _lib.check(self.lib.demia_mask_overlap_prefix(_lib.ptr(packed), _lib.ptr(seg), _lib.ptr(bbox), M, H, self._w(packed),
+                                                      self._stream()), "demia_mask_overlap_prefix")
         return packed
 
     def components_gt1(self, packed: torch.Tensor, bbox: Optional[torch.Tensor] = None) -> torch.Tensor:
-        M, H, wpr = packed.shape
-        if bbox is None:
-            _, bbox = self.area_bbox(packed)
-        scratch = torch.empty_like(packed)
-        flag = torch.empty((M,), dtype=torch.int32, device=self.device)
-        _lib.check(self.lib.demia_mask_components_gt1(_lib.ptr(packed), _lib.ptr(scratch), _lib.ptr(bbox), _lib.ptr(flag), M, H,
-                                                      self._w(packed), self._stream()), "demia_mask_components_gt1")
-        return flag
+        """``label(mask).max() > 1`` per mask (the masks are not changed)."""
+        return self.program_(packed, ["flag_multi"], bbox)[2]
 
     def place_tiles(self, src: torch.Tensor, x_off: Sequence[int], y_off: Sequence[int], tile_h: int, tile_w: int,
                     H: int, W: int) -> torch.Tensor:
@@ -141,18 +155,22 @@ class MaskOps:
         return dst
 
     # -- contours + measurements ----------------------------------------------------------------
-    def trace(self, packed: torch.Tensor, max_contours: int = 64, max_points: Optional[int] = None) -> "ContourSet":
+    def trace(self, packed: torch.Tensor, max_contours: int = 64, max_points: Optional[int] = None,
+              bbox: Optional[torch.Tensor] = None, total_area: Optional[int] = None) -> "ContourSet":
         """cv2.findContours(RETR_EXTERNAL, CHAIN_APPROX_SIMPLE) + contourArea + arcLength for every mask, once;
-        the returned set can be measured later for any subset of its masks without tracing again."""
+        the returned set can be measured later for any subset of its masks without tracing again.  ``bbox`` (any
+        superset of the tight boxes) and ``total_area`` (sizes the point pool) save a reduction when known."""
         M, H, wpr = packed.shape
         W = self._w(packed)
-        area, bbox = self.area_bbox(packed)
-        filled = self.fill_holes(packed, bbox)
+        if bbox is None or (max_points is None and total_area is None):
+            area, bbox = self.area_bbox(packed, bbox)
+            total_area = int(area.sum().item())
         if max_points is None:
-            max_points = int(min(max(4 * int(area.sum().item()) // 8 + 4096 * M, 1 << 16), 1 << 26))
+            max_points = int(min(max(4 * int(total_area) // 8 + 4096 * M, 1 << 16), 1 << 26))
         C = max_contours
         cs = ContourSet(self, M, C, max_points)
-        _lib.check(self.lib.demia_mask_contours(_lib.ptr(packed), _lib.ptr(filled), _lib.ptr(bbox), M, H, W, C, max_points,
+        scratch = torch.empty_like(packed)       # only touched by regions that do not fit in LDS
+        _lib.check(self.lib.demia_mask_contours(_lib.ptr(packed), _lib.ptr(scratch), _lib.ptr(bbox), M, H, W, C, max_points,
                                                 _lib.ptr(cs.count), _lib.ptr(cs.info), _lib.ptr(cs.red), _lib.ptr(cs.points),
                                                 _lib.ptr(cs.counters), self._stream()), "demia_mask_contours")
         return cs

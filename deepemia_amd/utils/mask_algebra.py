@@ -19,15 +19,22 @@ def _overlap(b1, b2) -> bool:
 
 
 class DeviceMaskAlgebra:
-    def __init__(self, ops, packed: torch.Tensor):
+    def __init__(self, ops, packed: torch.Tensor, area=None, bbox=None):
+        """``area`` / ``bbox`` (device tensors or host arrays): the exact pixel counts and tight boxes when an earlier
+        kernel has already reduced them (``MaskOps.program_`` does) -- otherwise one ``demia_mask_area_bbox`` launch."""
         self.ops = ops
         self.packed = packed
         self.n = int(packed.shape[0])
         if self.n:
-            a, b = ops.area_bbox(packed)
-            self._bbox_dev = b
-            self.area = a.cpu().numpy().astype(np.int64)
-            self.bbox = b.cpu().numpy().astype(np.int64)
+            if area is None or bbox is None:
+                area, bbox = ops.area_bbox(packed)
+            if isinstance(bbox, torch.Tensor):
+                self._bbox_dev = bbox
+                self.bbox = bbox.cpu().numpy().astype(np.int64)
+            else:
+                self.bbox = np.asarray(bbox, dtype=np.int64).reshape(-1, 4)
+                self._bbox_dev = torch.from_numpy(self.bbox.astype(np.int32)).to(packed.device)
+            self.area = (area.cpu().numpy() if isinstance(area, torch.Tensor) else np.asarray(area)).astype(np.int64)
         else:
             self._bbox_dev = torch.zeros((0, 4), dtype=torch.int32, device=packed.device)
             self.area = np.zeros((0,), dtype=np.int64)
@@ -46,6 +53,10 @@ class DeviceMaskAlgebra:
             np.fill_diagonal(self.known, True)
         else:
             self.known = np.zeros((0, 0), dtype=bool)
+
+    def view(self, indices: Sequence[int]) -> "AlgebraView":
+        """The same answers for a subset of the masks, renumbered 0..len(indices)-1 (no copy, no launch)."""
+        return AlgebraView(self, indices)
 
     def bbox_of(self, i: int) -> Optional[Tuple[int, int, int, int]]:
         """(y_min, x_min, y_max, x_max) or None for an empty mask (spatial_constraints.py:70-89)."""
@@ -109,3 +120,44 @@ class DeviceMaskAlgebra:
 
     def union(self, i: int, j: int) -> int:
         return int(self.area[i]) + int(self.area[j]) - self.inter(i, j)
+
+
+class AlgebraView:
+    """Index-translated window on a :class:`DeviceMaskAlgebra` (what the spatial-constraint pass needs of it)."""
+
+    def __init__(self, base: DeviceMaskAlgebra, indices: Sequence[int]):
+        self.base = base
+        self.idx = np.asarray(list(indices), dtype=np.int64)
+        self.n = len(self.idx)
+        self.area = base.area[self.idx]
+        self.bbox = base.bbox[self.idx]
+
+    def bbox_of(self, i: int):
+        return self.base.bbox_of(int(self.idx[i]))
+
+    def inter(self, i: int, j: int) -> int:
+        return self.base.inter(int(self.idx[i]), int(self.idx[j]))
+
+    def union(self, i: int, j: int) -> int:
+        return self.base.union(int(self.idx[i]), int(self.idx[j]))
+
+    def prefetch_overlapping_pairs(self, groups: Optional[Iterable[Sequence[int]]] = None) -> None:
+        groups = [list(range(self.n))] if groups is None else groups
+        self.base.prefetch_overlapping_pairs([[int(self.idx[i]) for i in g] for g in groups])
+
+    def intersections(self, pi: Sequence[int], pj: Sequence[int]) -> np.ndarray:
+        return self.base.intersections(self.idx[np.asarray(pi, dtype=np.int64)], self.idx[np.asarray(pj, dtype=np.int64)])
+
+    @property
+    def _cache(self):
+        return _TranslatedKeys(self.base._cache, self.idx)
+
+
+class _TranslatedKeys:
+    """``(i, j) in view._cache`` in the view's numbering."""
+
+    def __init__(self, cache, idx):
+        self.cache, self.idx = cache, idx
+
+    def __contains__(self, key) -> bool:
+        return (int(self.idx[key[0]]), int(self.idx[key[1]])) in self.cache

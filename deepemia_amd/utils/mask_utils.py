@@ -24,8 +24,8 @@ def rle_encoding(x: np.ndarray) -> List[int]:
     return out.tolist()
 
 
-def postprocess_masks_device(ops, packed: torch.Tensor, scores: np.ndarray, min_crys_size: Optional[int] = None
-                             ) -> Optional[torch.Tensor]:
+def postprocess_masks_device(ops, packed: torch.Tensor, scores: np.ndarray, min_crys_size: Optional[int] = None,
+                             bbox: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """``postprocess_masks`` (``mask_utils.py:38-84``) on packed device masks, quirks included.
 
     * ``np.sum(ori_mask, axis=(0, 1))`` is a per-COLUMN count over all masks; if fewer columns
@@ -34,6 +34,7 @@ def postprocess_masks_device(ops, packed: torch.Tensor, scores: np.ndarray, min_
     * per mask, in score order: fill holes -> closing (dilation then erosion, 3x3 cross) -> remove
       every pixel an earlier (closed) mask covers -> zero the mask if it has more than one
       8-connected component (the zeroed mask is still returned).
+    ``packed`` is CONSUMED (the stages run in place on it).  ``bbox``: boxes containing the masks, if known.
     Returns ``[N', H, W/32]`` or ``None`` for the reference's ``[]``."""
     if min_crys_size is None:
         min_crys_size = DefaultThresholds.MIN_CRYSTAL_SIZE
@@ -41,36 +42,35 @@ def postprocess_masks_device(ops, packed: torch.Tensor, scores: np.ndarray, min_
     scores = np.asarray(scores)
     if n == 0 or bool(scores.all()) < 0.5:
         return None
-    n_cols = int((ops.column_counts(packed) > min_crys_size).sum().item())
+    if bbox is None:
+        _, bbox = ops.area_bbox(packed)
+    n_cols = int((ops.column_counts(packed, bbox=bbox) > min_crys_size).sum().item())
     if n_cols < n:
         if n_cols == 0:
             return None
-        packed = packed[:n_cols].contiguous()
-    filled = ops.fill_holes(packed)
-    closed = ops.erode(ops.dilate(filled))
-    ops.overlap_prefix_(closed)
-    multi = ops.components_gt1(closed)
-    closed[multi.bool()] = 0
-    return closed
+        packed, bbox = packed[:n_cols].contiguous(), bbox[:n_cols].contiguous()
+    _, bbox, _ = ops.program_(packed, ["fill", "dilate", "erode"], bbox)
+    ops.overlap_prefix_(packed, None, bbox)
+    ops.program_(packed, ["drop_multi"], bbox)
+    return packed
 
 
 def process_masks_device(ops, packed: torch.Tensor) -> torch.Tensor:
-    """``process_masks_parallel`` (``inference.py:170-213``): fill holes -> erosion -> dilation."""
-    return ops.dilate(ops.erode(ops.fill_holes(packed)))
+    """``process_masks_parallel`` (``inference.py:170-213``): fill holes -> erosion -> dilation (in place)."""
+    ops.program_(packed, ["fill", "erode", "dilate"])
+    return packed
 
 
-def postprocess_masks_universal_device(ops, packed: torch.Tensor, image_hw, is_small_class: bool, min_crys_size=None):
-    """``postprocess_masks_universal`` (``inference.py:1739-1813``): returns (packed_kept, kept_indices)."""
+def postprocess_masks_universal_device(ops, packed: torch.Tensor, image_hw, is_small_class: bool, min_crys_size=None,
+                                       bbox: Optional[torch.Tensor] = None):
+    """``postprocess_masks_universal`` (``inference.py:1739-1813``): returns (packed_kept, kept_indices);
+    ``packed`` is consumed."""
     n = int(packed.shape[0])
     if n == 0:
         return packed, []
     area_img = image_hw[0] * image_hw[1]
     if min_crys_size is None:
         min_crys_size = max(3, int(area_img * 0.000005)) if is_small_class else max(25, int(area_img * 0.0001))
-    filled = ops.fill_holes(packed)
-    final = ops.erode(filled)
-    if not is_small_class:
-        final = ops.dilate(final)
-    area, _ = ops.area_bbox(final)
+    area, _, _ = ops.program_(packed, ["fill", "erode"] if is_small_class else ["fill", "erode", "dilate"], bbox)
     keep = (area >= min_crys_size).nonzero().flatten()
-    return final[keep].contiguous(), keep.cpu().tolist()
+    return packed[keep].contiguous(), keep.cpu().tolist()

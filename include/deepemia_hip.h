@@ -199,36 +199,50 @@ typedef struct demia_paste_desc {
     float* out_boxes;
     uint8_t* valid;
     uint32_t* packed;
+    int32_t* out_bbox;        /* optional [N, D, 4] i32: y0, x0, y1, x1 (inclusive) of the pixels the paste can set,
+                                 -1 for invalid instances -- the bbox hint of the packed-mask entry points */
 } demia_paste_desc;
 int demia_paste_masks(const demia_paste_desc* d, void* stream);
 /* packed bits -> Detectron2's (M, H, W) bool bytes (pred_masks drop-in layout) */
 int demia_unpack_masks(const uint32_t* packed, uint8_t* out_bool, int64_t M, int H, int W, void* stream);
-/* per-mask popcount ("np.sum(mask)", inference.py:1688, 2599) and tight bbox [M,4] = y0,x0,y1,x1 (inclusive; -1 if empty) */
-int demia_mask_area_bbox(const uint32_t* packed, int32_t* area, int32_t* bbox, int64_t M, int H, int W, void* stream);
+/* per-mask popcount ("np.sum(mask)", inference.py:1688, 2599) and tight bbox [M,4] = y0,x0,y1,x1 (inclusive; -1 if empty).
+ * hint (optional, [M,4]): a box known to contain every set pixel of the mask; only that region is read. */
+int demia_mask_area_bbox(const uint32_t* packed, const int32_t* hint, int32_t* area, int32_t* bbox, int64_t M, int H, int W,
+                         void* stream);
 
-/* a9-a15: packed-mask morphology (all masks [M, H, ceil(W/32)] u32, W = true pixel width; in != out) -
+/* a9-a15: packed-mask morphology (all masks [M, H, ceil(W/32)] u32, W = true pixel width) ---------------
  * Replace, on bit-packed device masks, what the reference does with scipy / scikit-image / numpy on
- * dense host arrays:
- *   fill_holes      scipy.ndimage.binary_fill_holes           (mask_utils.py:75; inference.py:193, 1780)
- *   morph_cross     skimage erosion / dilation, 3x3 cross, 'reflect' border
- *                                                             (mask_utils.py:76; inference.py:196-198, 1786-1796)
+ * dense host arrays.  demia_mask_program runs a sequence of per-mask stages IN PLACE on the bbox region
+ * of every mask (one workgroup per mask, region staged in LDS; the frame outside the box is not touched):
+ *   DEMIA_MOP_FILL        scipy.ndimage.binary_fill_holes        (mask_utils.py:75; inference.py:193, 1780)
+ *   DEMIA_MOP_DILATE /    skimage dilation / erosion, 3x3 cross, 'reflect' border
+ *   DEMIA_MOP_ERODE                                              (mask_utils.py:76; inference.py:196-198, 1786-1796)
+ *   DEMIA_MOP_DROP_MULTI  if skimage.measure.label(mask).max() > 1 (8-connected): mask[:] = 0
+ *                                                                (mask_utils.py:79-81)
+ *   DEMIA_MOP_FLAG_MULTI  the same test without changing the mask
+ *   DEMIA_MOP_GATE        masks with active[m] == 0 (or active == NULL) stop here (inference.py:1443: the
+ *                         fill -> erosion -> dilation of process_masks_parallel only runs for calls with > 2 masks)
+ * program = up to 8 stage codes, 4 bits each, low nibble first, 0 ends it.
+ *   bbox     [M, 4] i32 y0, x0, y1, x1 inclusive, -1 for empty masks; a SUPERSET of the tight box is fine
+ *            (demia_mask_area_bbox, demia_paste_desc.out_bbox, or bbox_out of an earlier program)
+ *   scratch  same shape as masks; only regions larger than 64 KiB of LDS use it
+ *   area / bbox_out / flag (each optional): popcount and tight bbox of the result; flag = a *_MULTI stage fired.
+ * Other entry points:
  *   overlap_prefix  overlap += mask; mask[overlap > 1] = 0 over the masks of one call, in order
- *                                                             (mask_utils.py:77-78)
- *   components_gt1  skimage.measure.label(mask).max() > 1, 8-connected (mask_utils.py:79-81)
+ *                                                             (mask_utils.py:77-78); bbox optional (supersets ok)
  *   column_counts   np.sum(masks, axis=(0, 1)) (per-column pixel counts; `counts` pre-zeroed)
  *                                                             (mask_utils.py:62)
  *   pair_intersections  np.count_nonzero(a[pi[p]] & b[pj[p]]) (inference.py:431, 2710;
  *                                                              spatial_constraints.py:143, 186)
  *   place_tiles     cv2.resize(mask, (tile_w, tile_h), INTER_NEAREST) + paste into a zero (H, W)
  *                   frame at (x_off, y_off)                   (inference.py:2399-2420)
- * bbox = [M, 4] i32 (y0, x0, y1, x1) inclusive, -1 for empty masks (demia_mask_area_bbox).
  * seg (overlap_prefix, column_counts): NULL, or a non-decreasing segment id per mask so that the masks of
  * many (tile, class) calls share ONE launch; column_counts then fills counts[S, W] (pre-zeroed).   */
-int demia_mask_fill_holes(const uint32_t* in, uint32_t* out, const int32_t* bbox, int64_t M, int H, int W, void* stream);
-int demia_mask_morph_cross(const uint32_t* in, uint32_t* out, int64_t M, int H, int W, int dilate, void* stream);
-int demia_mask_overlap_prefix(uint32_t* masks, const int32_t* seg, int64_t M, int H, int W, void* stream);
-int demia_mask_components_gt1(const uint32_t* in, uint32_t* scratch, const int32_t* bbox, int32_t* flag,
-                              int64_t M, int H, int W, void* stream);
+enum { DEMIA_MOP_END = 0, DEMIA_MOP_FILL = 1, DEMIA_MOP_DILATE = 2, DEMIA_MOP_ERODE = 3, DEMIA_MOP_DROP_MULTI = 4,
+       DEMIA_MOP_FLAG_MULTI = 5, DEMIA_MOP_GATE = 6 };
+int demia_mask_program(uint32_t* masks, uint32_t* scratch, const int32_t* bbox, const uint8_t* active, uint32_t program,
+                       int64_t M, int H, int W, int32_t* area, int32_t* bbox_out, int32_t* flag, void* stream);
+int demia_mask_overlap_prefix(uint32_t* masks, const int32_t* seg, const int32_t* bbox, int64_t M, int H, int W, void* stream);
 int demia_mask_column_counts(const uint32_t* masks, const int32_t* seg, const int32_t* bbox, int64_t M, int H, int W,
                              int32_t* counts, void* stream);
 int demia_mask_pair_intersections(const uint32_t* a, const uint32_t* b, const int32_t* pi, const int32_t* pj,
@@ -240,8 +254,9 @@ int demia_mask_place_tiles(const uint32_t* src, uint32_t* dst, const int32_t* x_
 /* a17/a18: contours and morphometrics ---------------------------------------------------------
  * demia_mask_contours = cv2.findContours(mask, RETR_EXTERNAL, CHAIN_APPROX_SIMPLE) per mask
  * (inference.py:1164, 2605) + cv2.contourArea + cv2.arcLength(closed) (inference.py:1175, 2607;
- * measurements.py:134-135).  `filled` = demia_mask_fill_holes(masks) (used to skip components
- * nested in holes, as RETR_EXTERNAL does).
+ * measurements.py:134-135).  Components nested in holes are skipped as RETR_EXTERNAL does (the
+ * kernel floods the outside background of the bbox region itself).  bbox may be a superset of the tight box;
+ * scratch (same shape as masks) is only used by regions larger than the LDS buffers.
  *   count [M]; info [M, C, 4] = start x, start y, n points, offset into `points`;
  *   red [M, C, 2] f64 = area, perimeter; points [max_points, 2] i32 (x, y);
  *   counters [2] i32: [0] points used, [1] error bits (1 candidates, 2 contours > C, 4 points).
@@ -252,7 +267,7 @@ int demia_mask_place_tiles(const uint32_t* src, uint32_t* dst, const int32_t* x_
 int64_t demia_contour_work_ints(int M, int C, int max_points);
 int64_t demia_contour_work_floats(int M, int C, int max_points);
 int64_t demia_contour_work_doubles(int M, int C, int max_points);
-int demia_mask_contours(const uint32_t* masks, const uint32_t* filled, const int32_t* bbox, int M, int H, int W, int C,
+int demia_mask_contours(const uint32_t* masks, uint32_t* scratch, const int32_t* bbox, int M, int H, int W, int C,
                         int max_points, int32_t* count, int32_t* info, double* red, int32_t* points,
                         int32_t* counters, void* stream);
 int demia_contour_measure(const int32_t* select /* [M] or NULL */, const int32_t* count, const int32_t* info,

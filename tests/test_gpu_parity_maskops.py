@@ -265,3 +265,117 @@ def test_widths_not_multiple_of_32(ops, w):
                 assert int((t[:, :, -1] >> (w % 32)).abs().sum()) == 0
     finally:
         ops.set_frame_width(0)
+
+
+def _blobs(rng, n, h, w, rmax):
+    yy, xx = np.mgrid[0:h, 0:w]
+    out = []
+    for i in range(n):
+        m = np.zeros((h, w), dtype=bool)
+        for _ in range(int(rng.integers(1, 4))):
+            cy, cx, r = rng.uniform(0, h), rng.uniform(0, w), rng.uniform(3, rmax)
+            d2 = (yy - cy) ** 2 + (xx - cx) ** 2
+            m |= (d2 <= r * r) & (d2 >= (rng.uniform(0, 0.6) * r) ** 2)
+        if i % 5 == 0:
+            m &= rng.random((h, w)) > 0.3                # ragged: many holes, many components
+        out.append(m)
+    return np.stack(out)
+
+
+@pytest.mark.parametrize("hw", [(96, 160), (300, 1100)])
+def test_region_programs_vs_oracle_chain(ops, hw):
+    """demia_mask_program (fill / dilate / erode / drop_multi / gate, in place on the bbox region) against the
+    oracle's dense scipy/skimage restatement, with tight boxes and with generous superset boxes as hints."""
+    from oracle import postproc_ref as P
+
+    h, w = hw
+    rng = np.random.default_rng(h)
+    masks = _blobs(rng, 24, h, w, min(h, w) / 3)
+    masks[3] = False                                         # an empty mask
+    ops.set_frame_width(w)
+    try:
+        area0, tight = ops.area_bbox(ops.from_dense(masks))
+        loose = tight.clone()
+        nz = tight[:, 0] >= 0
+        loose[nz, 0] = (tight[nz, 0] - 7).clamp(min=0); loose[nz, 1] = (tight[nz, 1] - 40).clamp(min=0)
+        loose[nz, 2] = (tight[nz, 2] + 5).clamp(max=h - 1); loose[nz, 3] = (tight[nz, 3] + 33).clamp(max=w - 1)
+        active = torch.from_numpy((np.arange(len(masks)) % 2).astype(np.uint8)).to(ops.device)
+        for bbox in (tight, loose):
+            # a9: fill -> dilate -> erode
+            p = ops.from_dense(masks)
+            area, bb, _ = ops.program_(p, ["fill", "dilate", "erode"], bbox)
+            want = np.stack([P.erode_cross(P.dilate_cross(P.fill_holes(m))) for m in masks])
+            np.testing.assert_array_equal(ops.to_dense(p, w), want)
+            a2, b2 = ops.area_bbox(p)
+            assert torch.equal(area, a2) and torch.equal(bb, b2)           # the program's own reductions
+            # component drop, then the gated a11 chain
+            area, bb2, flag = ops.program_(p, ["drop_multi", "gate", "fill", "erode", "dilate"], bb, active)
+            exp = []
+            for i, m in enumerate(want):
+                multi = P.n_components8(m) > 1
+                assert int(flag[i]) == int(multi)
+                m = np.zeros_like(m) if multi else m
+                exp.append(P.dilate_cross(P.erode_cross(P.fill_holes(m))) if i % 2 else m)
+            np.testing.assert_array_equal(ops.to_dense(p, w), np.stack(exp))
+            a3, b3 = ops.area_bbox(p)
+            assert torch.equal(area, a3) and torch.equal(bb2, b3)
+            # hinted reduction == full-frame reduction
+            a4, b4 = ops.area_bbox(p, bb2)
+            assert torch.equal(a4, a3) and torch.equal(b4, b3)
+    finally:
+        ops.set_frame_width(0)
+
+
+def test_overlap_prefix_with_boxes_equals_streaming(ops):
+    h, w = 128, 200
+    rng = np.random.default_rng(5)
+    masks = _blobs(rng, 40, h, w, 40)
+    seg = torch.from_numpy(np.repeat(np.arange(4, dtype=np.int32), 10)).to(ops.device)
+    ops.set_frame_width(w)
+    try:
+        a, b = ops.from_dense(masks), ops.from_dense(masks)
+        _, bbox = ops.area_bbox(a)
+        ops.overlap_prefix_(a, seg)                  # streaming, full frame
+        ops.overlap_prefix_(b, seg, bbox)            # per mask, box-restricted, racing blocks
+        assert torch.equal(a, b)
+        want = masks.copy()
+        for s0 in range(0, 40, 10):
+            seen = np.zeros((h, w), dtype=bool)
+            for i in range(s0, s0 + 10):
+                want[i] = masks[i] & ~seen
+                seen |= masks[i]
+        np.testing.assert_array_equal(ops.to_dense(b, w), want)
+    finally:
+        ops.set_frame_width(0)
+
+
+def test_region_larger_than_lds_uses_the_frame_in_hbm(ops):
+    """A mask whose box needs more than the 2 x 32 KiB LDS buffers: same stages, same answers, through HBM."""
+    from oracle import postproc_ref as P
+
+    h, w = 700, 1600
+    yy, xx = np.mgrid[0:h, 0:w]
+    ring = ((yy - 350) ** 2 / 330.0 ** 2 + (xx - 800) ** 2 / 780.0 ** 2 <= 1) & \
+           ((yy - 350) ** 2 / 200.0 ** 2 + (xx - 800) ** 2 / 500.0 ** 2 >= 1)
+    spiral = np.zeros((h, w), dtype=bool)
+    for k in range(6):                                  # nested open rectangles: a long winding background path
+        o = 20 + 45 * k
+        spiral[o:h - o, o:o + 6] = True; spiral[o:h - o, w - o - 6:w - o] = True
+        spiral[o:o + 6, o:w - o] = True; spiral[h - o - 6:h - o, o + 60:w - o] = True
+    masks = np.stack([ring, spiral, ring & (xx % 7 != 0)])
+    ops.set_frame_width(w)
+    try:
+        p = ops.from_dense(masks)
+        assert ((700 + 4) * ((1600 + 4) // 32 + 2)) > 8192
+        np.testing.assert_array_equal(ops.to_dense(ops.fill_holes(p), w), np.stack([P.fill_holes(m) for m in masks]))
+        np.testing.assert_array_equal(ops.to_dense(ops.erode(ops.dilate(p)), w),
+                                      np.stack([P.erode_cross(P.dilate_cross(m)) for m in masks]))
+        assert ops.components_gt1(p).tolist() == [int(P.n_components8(m) > 1) for m in masks]
+        recs = ops.contours(p, max_contours=4096)
+        for i, m in enumerate(masks):
+            ref = P.find_external_contours(m)
+            assert len(ref) == len(recs[i])
+            for rec, c in zip(recs[i], ref):
+                np.testing.assert_array_equal(rec["points"], c)
+    finally:
+        ops.set_frame_width(0)

@@ -34,7 +34,8 @@ def env(gpu_device):
     img = synth.em_tile(0, 1024)
     ref = R.predict(img, sd, 50, THR, return_intermediates=True)
     eng = MaskRCNNEngine(sd, 50, K, THR, gpu_device, "f32")
-    return dict(sd=sd, img=img, ref=ref, eng=eng, R=R, synth=synth, dev=gpu_device)
+    eng3 = MaskRCNNEngine(sd, 50, K, THR, gpu_device, "f32x3")   # f32 operands on the bf16 pipe: same parity bar
+    return dict(sd=sd, img=img, ref=ref, eng=eng, f32=eng, f32x3=eng3, R=R, synth=synth, dev=gpu_device)
 
 
 def nhwc(t):
@@ -44,7 +45,7 @@ def nhwc(t):
 def test_library_is_the_hip_one(env):
     lib = env["eng"].lib
     assert lib.demia_build_arch().decode() == "gfx950"
-    assert lib.demia_abi_version() == 1
+    assert lib.demia_abi_version() == 2
 
 
 @pytest.mark.parametrize("hw", [(1024, 1024), (2048, 2048), (600, 600), (700, 1100), (1000, 2000)])
@@ -139,8 +140,9 @@ def test_conv_igemm_vs_torch(env, case, prec):
     assert err <= tol, err
 
 
-def test_backbone_fpn_features_f32(env):
-    eng, d = env["eng"], env["ref"]["dbg"]
+@pytest.mark.parametrize("prec", ["f32", "f32x3"])
+def test_backbone_fpn_features_f32(env, prec):
+    eng, d = env[prec], env["ref"]["dbg"]
     x = torch.from_numpy(env["img"])[None].to(env["dev"])
     xin, newh, neww, ph, pw = eng.preprocess(x)
     feats = eng.backbone(xin, ph, pw)
@@ -248,9 +250,14 @@ def test_paste_on_oracle_inputs(env):
     det_classes[0, :n] = d["det_classes"].int()
     newh, neww = d["resized"].shape[:2]
     h, w = env["img"].shape[:2]
-    ob, valid, packed = eng.paste(blocked.view(D * 196 * 4, 1, 1, 4).to(dev), det_boxes.to(dev), det_classes.to(dev),
-                                  torch.tensor([n], dtype=torch.int32, device=dev), newh, neww, h, w)
+    ob, valid, packed, hint = eng.paste(blocked.view(D * 196 * 4, 1, 1, 4).to(dev), det_boxes.to(dev), det_classes.to(dev),
+                                        torch.tensor([n], dtype=torch.int32, device=dev), newh, neww, h, w)
     masks = eng.unpack(packed[0, :n].contiguous(), h, w).cpu()
+    # the paste box handed to the packed-mask kernels as bbox hint contains every set pixel of its mask
+    area_h, bbox_h = eng.area_bbox(packed[0, :n].contiguous(), h, w, hint[0, :n].contiguous())
+    area_f, bbox_f = eng.area_bbox(packed[0, :n].contiguous(), h, w)
+    assert torch.equal(area_h, area_f) and torch.equal(bbox_h, bbox_f)
+    assert bool((hint[0, n:] == -1).all())
     assert bool(valid[0, :n].all()) and not bool(valid[0, n:].any())
     assert float((ob[0, :n].cpu() - ref["pred_boxes"]).abs().max()) < 1e-3
     r = ref["pred_masks"]
@@ -283,11 +290,12 @@ def test_unpack_and_area_bbox_bit_exact(env):
         assert bbox[i].cpu().tolist() == exp
 
 
-def test_end_to_end_f32_matches_oracle(env):
+@pytest.mark.parametrize("prec", ["f32", "f32x3"])
+def test_end_to_end_f32_matches_oracle(env, prec):
     from deepemia_amd.predictor import Predictor
 
     ref = env["ref"]
-    inst = Predictor(env["eng"])(env["img"])["instances"]
+    inst = Predictor(env[prec])(env["img"])["instances"]
     n = len(inst)
     assert n == ref["scores"].shape[0] == 100
     got = inst.to("cpu")
