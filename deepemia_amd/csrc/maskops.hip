@@ -18,7 +18,11 @@
 
 namespace {
 
-constexpr int REG_WORDS = 8192;       // LDS words per region buffer (two buffers = 64 KiB: e.g. 512 rows x 512 px)
+// LDS words per region buffer.  Two launches per program: most masks are a few hundred words and run in the SMALL
+// variant, whose 8 KiB of LDS fit beside the two resident workgroups of a convolution on the other stream (the next
+// batch's network runs concurrently); the few large masks take the 64 KiB variant, regions beyond that go through HBM.
+constexpr int REG_WORDS_SMALL = 1024;
+constexpr int REG_WORDS = 8192;
 
 // ---- per-mask stage programs on the bbox region, in place ----------------------------------------------------
 // program = up to 8 stage codes, 4 bits each, executed low nibble first (DEMIA_MOP_*).  The region (bbox grown by
@@ -37,15 +41,16 @@ struct ProgP {
     int* flag;
 };
 
-__global__ __launch_bounds__(512) void mask_program_kernel(const ProgP p) {
-    __shared__ uint32_t lds[2 * REG_WORDS];
+template <int RW, int NT>
+__global__ __launch_bounds__(NT) void mask_program_kernel(const ProgP p, const int lo) {
+    __shared__ uint32_t lds[2 * RW];
     __shared__ int s_changed, s_first, s_area, s_y0, s_y1, s_x0, s_x1;
     const long m = blockIdx.x;
     const int tid = threadIdx.x, nt = blockDim.x;
     const int wpr = (p.W + 31) >> 5;
     int cy0 = p.bbox[m * 4 + 0], cx0 = p.bbox[m * 4 + 1], cy1 = p.bbox[m * 4 + 2], cx1 = p.bbox[m * 4 + 3];
     if (cy0 < 0) {                      // empty mask stays empty under every stage
-        if (tid == 0) {
+        if (tid == 0 && lo == 0) {
             if (p.area) p.area[m] = 0;
             if (p.bbox_out) { p.bbox_out[m * 4 + 0] = -1; p.bbox_out[m * 4 + 1] = -1; p.bbox_out[m * 4 + 2] = -1; p.bbox_out[m * 4 + 3] = -1; }
             if (p.flag) p.flag[m] = 0;
@@ -58,10 +63,11 @@ __global__ __launch_bounds__(512) void mask_program_kernel(const ProgP p) {
     g.H = p.H; g.W = p.W; g.wpr = wpr;
     mreg::region_of(cy0, cx0, cy1, cx1, ndil + 1, p.H, p.W, g.ry0, g.wx0, g.rh, g.rw);
     const int n = g.rh * g.rw;
-    const bool use_lds = n <= REG_WORDS;
+    if (n <= lo || (n > RW && RW != REG_WORDS)) return;       // the other variant's mask
+    const bool use_lds = n <= RW;
     uint32_t* home = p.masks + m * (long)p.H * wpr + (long)g.ry0 * wpr + g.wx0;
     if (use_lds) {
-        g.A = lds; g.B = lds + REG_WORDS; g.stride = g.rw;
+        g.A = lds; g.B = lds + RW; g.stride = g.rw;
         for (int i = tid; i < n; i += nt) g.A[i] = home[(long)(i / g.rw) * wpr + i % g.rw];
     } else {
         g.A = home; g.B = p.scratch + m * (long)p.H * wpr + (long)g.ry0 * wpr + g.wx0; g.stride = wpr;
@@ -81,7 +87,7 @@ __global__ __launch_bounds__(512) void mask_program_kernel(const ProgP p) {
             }
             uint32_t* t = g.A; g.A = g.B; g.B = t;
         } else if (op == DEMIA_MOP_DROP_MULTI || op == DEMIA_MOP_FLAG_MULTI) {
-            const bool multi = mreg::more_than_one_component(g, &s_first, &s_changed);
+            const bool multi = mreg::more_than_one_component(g, cy0, cx0, cy1, cx1, &s_first, &s_changed);
             flagged |= multi;
             if (multi && op == DEMIA_MOP_DROP_MULTI) {
                 for (int i = tid; i < n; i += nt) g.A[(i / g.rw) * g.stride + i % g.rw] = 0u;
@@ -285,8 +291,10 @@ extern "C" int demia_mask_program(uint32_t* masks, uint32_t* scratch, const int3
     for (uint32_t q = program; q; q >>= 4) DEMIA_REQUIRE((q & 15u) <= DEMIA_MOP_GATE, "unknown stage code");
     if (M == 0) return DEMIA_OK;
     ProgP p{masks, scratch, bbox, active, program, H, W, area, bbox_out, flag};
-    hipLaunchKernelGGL(mask_program_kernel, dim3((int)M), dim3(512), 0, (hipStream_t)stream, p);
-    DEMIA_CHECK_LAUNCH("mask_program_kernel");
+    hipLaunchKernelGGL((mask_program_kernel<REG_WORDS_SMALL, 256>), dim3((int)M), dim3(256), 0, (hipStream_t)stream, p, 0);
+    DEMIA_CHECK_LAUNCH("mask_program_kernel<small>");
+    hipLaunchKernelGGL((mask_program_kernel<REG_WORDS, 512>), dim3((int)M), dim3(512), 0, (hipStream_t)stream, p, REG_WORDS_SMALL);
+    DEMIA_CHECK_LAUNCH("mask_program_kernel<large>");
     return DEMIA_OK;
 }
 

@@ -119,10 +119,9 @@ __device__ void flood(const uint32_t* P, uint32_t inv, uint32_t* R, int stride, 
     }
 }
 
-// scipy.ndimage.binary_fill_holes on the region: A <- A | (background not 4-connected to the outside).
-// (cy0, cx0, cy1, cx1): a bbox that contains every set pixel of A; background outside it, and background on the
-// image frame, is the outside.  Uses B.
-__device__ void fill_holes(const Reg& g, int cy0, int cx0, int cy1, int cx1, int* s_changed) {
+// B <- the OUTSIDE background of A: background pixels 4-connected to beyond the box (cy0, cx0, cy1, cx1) -- any box
+// that contains every set pixel of A -- or lying on the image frame.
+__device__ void outside_background(const Reg& g, int cy0, int cx0, int cy1, int cx1, int* s_changed) {
     const int tid = threadIdx.x, nt = blockDim.x, n = g.rh * g.rw;
     for (int i = tid; i < n; i += nt) {
         const int ly = i / g.rw, lx = i - ly * g.rw;
@@ -139,12 +138,68 @@ __device__ void fill_holes(const Reg& g, int cy0, int cx0, int cy1, int cx1, int
     }
     __syncthreads();
     flood<false>(g.A, 0xFFFFFFFFu, g.B, g.stride, g.rh, g.rw, s_changed);
+}
+
+// scipy.ndimage.binary_fill_holes on the region: A <- A | (background not 4-connected to the outside).  Uses B.
+__device__ void fill_holes(const Reg& g, int cy0, int cx0, int cy1, int cx1, int* s_changed) {
+    const int tid = threadIdx.x, nt = blockDim.x, n = g.rh * g.rw;
+    outside_background(g, cy0, cx0, cy1, cx1, s_changed);
     for (int i = tid; i < n; i += nt) {
         const int ly = i / g.rw, lx = i - ly * g.rw;
         const uint32_t valid = (g.wx0 + lx == g.wpr - 1 && (g.W & 31)) ? ((1u << (g.W & 31)) - 1u) : 0xFFFFFFFFu;
         g.A[ly * g.stride + lx] = ~g.B[ly * g.stride + lx] & valid;
     }
     __syncthreads();
+}
+
+// With B = outside_background(A): does A enclose any background?  s_flag is a shared int.
+__device__ bool has_holes(const Reg& g, int* s_flag) {
+    const int tid = threadIdx.x, nt = blockDim.x, n = g.rh * g.rw;
+    if (tid == 0) *s_flag = 0;
+    __syncthreads();
+    bool h = false;
+    for (int i = tid; i < n; i += nt) {
+        const int o = (i / g.rw) * g.stride + i % g.rw;
+        if (~(g.A[o] | g.B[o])) h = true;            // padding bits beyond W are seeds of B, so they never count
+    }
+    if (h) *s_flag = 1;
+    __syncthreads();
+    const bool res = *s_flag != 0;
+    __syncthreads();
+    return res;
+}
+
+// 4 x the Euler number of A for 8-connectivity (components - holes), by Gray's bit-quad counts over every 2 x 2
+// window of the zero-padded region: 4E = n(Q1) - n(Q3) - 2 n(QD).  A popcount reduction: no propagation at all.
+__device__ int euler8_x4(const Reg& g, int* s_acc) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int cols = g.rw + 1, n = (g.rh + 1) * cols;
+    if (tid == 0) *s_acc = 0;
+    __syncthreads();
+    int acc = 0;
+    for (int i = tid; i < n; i += nt) {
+        const int uy = i / cols - 1, lx = i - (uy + 1) * cols;     // window = rows uy, uy+1; right pixels in word lx
+        uint32_t U = 0u, Up = 0u, D = 0u, Dp = 0u;
+        if (uy >= 0) {
+            if (lx < g.rw) U = g.A[uy * g.stride + lx];
+            if (lx > 0) Up = g.A[uy * g.stride + lx - 1];
+        }
+        if (uy + 1 < g.rh) {
+            if (lx < g.rw) D = g.A[(uy + 1) * g.stride + lx];
+            if (lx > 0) Dp = g.A[(uy + 1) * g.stride + lx - 1];
+        }
+        const uint32_t a = (U << 1) | (Up >> 31), b = U, c = (D << 1) | (Dp >> 31), d = D;
+        const uint32_t odd = a ^ b ^ c ^ d;
+        const uint32_t two = (a & b) | (a & c) | (a & d) | (b & c) | (b & d) | (c & d);
+        const uint32_t qd = (a & d & ~b & ~c) | (b & c & ~a & ~d);
+        acc += __popc(odd & ~two) - __popc(odd & two) - 2 * __popc(qd);
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if ((tid & 63) == 0 && acc) atomicAdd(s_acc, acc);
+    __syncthreads();
+    const int res = *s_acc;
+    __syncthreads();
+    return res;
 }
 
 // skimage erosion / dilation with the 3x3 cross; 'reflect' border = the frame edge replicates, everything else
@@ -170,9 +225,14 @@ __device__ void morph_cross(const Reg& g) {
     __syncthreads();
 }
 
-// skimage.measure.label(A).max() > 1 (8-connected).  Uses B; s_first is a shared int.
-__device__ bool more_than_one_component(const Reg& g, int* s_first, int* s_changed) {
+// skimage.measure.label(A).max() > 1 (8-connected).  A mask without holes has exactly E8 components, and the hole
+// test is the cheap kind of flood (seeded all around the box, every wave busy from the first round); only a mask
+// WITH holes pays for the flood of one component from its first pixel (a single travelling front).
+// Uses B; (cy0, cx0, cy1, cx1) as in outside_background; s_first is a shared int.
+__device__ bool more_than_one_component(const Reg& g, int cy0, int cx0, int cy1, int cx1, int* s_first, int* s_changed) {
     const int tid = threadIdx.x, nt = blockDim.x, n = g.rh * g.rw;
+    outside_background(g, cy0, cx0, cy1, cx1, s_changed);
+    if (!has_holes(g, s_first)) return euler8_x4(g, s_first) > 4;
     if (tid == 0) *s_first = 0x7FFFFFFF;
     __syncthreads();
     for (int i = tid; i < n; i += nt) {
@@ -181,6 +241,7 @@ __device__ bool more_than_one_component(const Reg& g, int* s_first, int* s_chang
     }
     __syncthreads();
     const int first = *s_first;
+    __syncthreads();
     if (first == 0x7FFFFFFF) return false;                                    // empty mask: no component at all
     for (int i = tid; i < n; i += nt) {
         const int ly = i / g.rw, lx = i - ly * g.rw;

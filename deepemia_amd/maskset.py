@@ -196,7 +196,7 @@ class ContourSet:
         self.info = torch.zeros((M, C, 4), dtype=torch.int32, device=dev)
         self.red = torch.zeros((M, C, 2), dtype=torch.float64, device=dev)
         self.points = torch.empty((max_points, 2), dtype=torch.int32, device=dev)
-        self.counters = torch.zeros((2,), dtype=torch.int32, device=dev)
+        self.counters = torch.zeros((4,), dtype=torch.int32, device=dev)
         self._host = None
 
     def host(self):
@@ -204,7 +204,12 @@ class ContourSet:
             cnt = self.counters.cpu().numpy()
             if cnt[1] != 0:
                 raise _lib.HipKernelError(f"contour extraction overflow (flags {int(cnt[1])}): raise max_contours / max_points")
-            self._host = (self.count.cpu().numpy(), self.info.cpu().numpy(), self.red.cpu().numpy(), int(cnt[0]))
+            self.walker_stats = (int(cnt[3]), int(cnt[2]))      # masks traced by parallel walkers, of which fell back
+            count = self.count.cpu().numpy()
+            # only the contour slots in use cross PCIe ([M, C, ...] with C = 256 is mostly empty: usually one per mask)
+            self.max_count = mc = max(1, int(count.max()) if self.M else 1)
+            self._host = (count, self.info[:, :mc].contiguous().cpu().numpy(), self.red[:, :mc].contiguous().cpu().numpy(),
+                          int(cnt[0]))
         return self._host
 
     def first_contour_perimeter(self) -> np.ndarray:
@@ -220,9 +225,10 @@ class ContourSet:
         return out
 
     def measure(self, um_pix: float = 1.0, select: Optional[Sequence[int]] = None) -> np.ndarray:
-        """[M, C, 12] measurement values (only for the selected masks when ``select`` is given)."""
+        """[M, max contours per mask, 12] measurement values (only for the selected masks when ``select`` is given)."""
         ops = self.ops
-        M, C, mp = self.M, self.C, self.max_points
+        self.host()
+        M, C, mp, mc = self.M, self.C, self.max_points, self.max_count
         sel_t = None
         if select is not None:
             flags = np.zeros(M, dtype=np.int32)
@@ -231,10 +237,10 @@ class ContourSet:
         wi = torch.empty((int(ops.lib.demia_contour_work_ints(M, C, mp)),), dtype=torch.int32, device=ops.device)
         wf = torch.empty((int(ops.lib.demia_contour_work_floats(M, C, mp)),), dtype=torch.float32, device=ops.device)
         wd = torch.empty((int(ops.lib.demia_contour_work_doubles(M, C, mp)),), dtype=torch.float64, device=ops.device)
-        vals = torch.zeros((M, C, 12), dtype=torch.float64, device=ops.device)
+        vals = torch.zeros((M, mc, 12), dtype=torch.float64, device=ops.device)
         _lib.check(ops.lib.demia_contour_measure(_lib.ptr(sel_t), _lib.ptr(self.count), _lib.ptr(self.info), _lib.ptr(self.red),
                                                  _lib.ptr(self.points), M, C, mp, _lib.ptr(wi), _lib.ptr(wf), _lib.ptr(wd),
-                                                 float(um_pix), _lib.ptr(vals), ops._stream()), "demia_contour_measure")
+                                                 float(um_pix), _lib.ptr(vals), mc, ops._stream()), "demia_contour_measure")
         return vals.cpu().numpy()
 
     def records(self, um_pix: float = 1.0, measure: bool = True, select: Optional[Sequence[int]] = None, with_points: bool = True):

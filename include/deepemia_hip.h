@@ -259,11 +259,14 @@ int demia_mask_place_tiles(const uint32_t* src, uint32_t* dst, const int32_t* x_
  * scratch (same shape as masks) is only used by regions larger than the LDS buffers.
  *   count [M]; info [M, C, 4] = start x, start y, n points, offset into `points`;
  *   red [M, C, 2] f64 = area, perimeter; points [max_points, 2] i32 (x, y);
- *   counters [2] i32: [0] points used, [1] error bits (1 candidates, 2 contours > C, 4 points).
+ *   counters [4] i32: [0] points used, [1] error bits (1 candidates, 2 contours > C, 4 points),
+ *            [2] / [3] statistics: masks whose parallel border walk fell back to the sequential one / used it.
  * Contours of one mask come out unordered: OpenCV's order is descending (start y, start x).
  * demia_contour_measure = calculate_measurements (measurements.py:114-233) per contour:
- *   out [M, C, 12] f64 = major_axis_length, minor_axis_length, eccentricity, Length, Width,
- *   CircularED, Aspect_Ratio, Circularity, Chords, Feret_diam, Roundness, Sphericity.        */
+ *   out [M, out_c, 12] f64 = major_axis_length, minor_axis_length, eccentricity, Length, Width,
+ *   CircularED, Aspect_Ratio, Circularity, Chords, Feret_diam, Roundness, Sphericity; out_c <= C is the number
+ *   of contour slots per mask the caller wants back (contours c >= out_c are skipped): with one contour per mask
+ *   the table that crosses PCIe is M x 12 doubles instead of M x C x 12.                         */
 int64_t demia_contour_work_ints(int M, int C, int max_points);
 int64_t demia_contour_work_floats(int M, int C, int max_points);
 int64_t demia_contour_work_doubles(int M, int C, int max_points);
@@ -273,7 +276,7 @@ int demia_mask_contours(const uint32_t* masks, uint32_t* scratch, const int32_t*
 int demia_contour_measure(const int32_t* select /* [M] or NULL */, const int32_t* count, const int32_t* info,
                           const double* red, const int32_t* points, int M,
                           int C, int max_points, int32_t* work_i, float* work_f, double* work_d, double um_pix,
-                          double* out, void* stream);
+                          double* out, int out_c, void* stream);
 
 #ifdef __cplusplus
 }

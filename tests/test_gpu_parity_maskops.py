@@ -379,3 +379,69 @@ def test_region_larger_than_lds_uses_the_frame_in_hbm(ops):
                 np.testing.assert_array_equal(rec["points"], c)
     finally:
         ops.set_frame_width(0)
+
+
+def test_small_region_with_many_border_starts_is_handed_to_the_large_variant(ops):
+    """Salt-and-pepper mask in a region that fits the small LDS variant but has more start candidates than it
+    holds (count[m] = -1 hand-over), beside ordinary masks; contours equal the oracle's."""
+    from oracle import postproc_ref as P
+
+    h, w = 120, 200
+    rng = np.random.default_rng(11)
+    noise = rng.random((h, w)) > 0.85                    # sparse: hundreds of separate specks, each an outer border
+    masks = np.stack([noise, _blobs(rng, 1, h, w, 30)[0], noise & (np.mgrid[0:h, 0:w][1] < 150)])
+    ops.set_frame_width(w)
+    try:
+        recs = ops.contours(ops.from_dense(masks), max_contours=8192)
+        for i, m in enumerate(masks):
+            ref = P.find_external_contours(m)
+            assert len(ref) == len(recs[i]) and (i == 1 or len(ref) > 512)
+            for rec, c in zip(recs[i], ref):
+                np.testing.assert_array_equal(rec["points"], c)
+    finally:
+        ops.set_frame_width(0)
+
+
+def test_one_border_many_walkers_equals_sequential_walk(ops):
+    """Masks that are one component without holes are traced by up to 64 walkers sharing the border; the stitched
+    result must be OpenCV's sequential walk point for point (thin spurs, one-pixel bridges, frame contact)."""
+    from oracle import postproc_ref as P
+
+    h, w = 260, 420
+    rng = np.random.default_rng(3)
+    yy, xx = np.mgrid[0:h, 0:w]
+    masks = []
+    for i in range(40):
+        m = np.zeros((h, w), dtype=bool)
+        cy, cx = rng.uniform(40, h - 40), rng.uniform(60, w - 60)
+        for _ in range(int(rng.integers(1, 6))):                 # a chain of overlapping discs, rough edges
+            r = rng.uniform(6, 45)
+            m |= (yy - cy) ** 2 + (xx - cx) ** 2 <= r * r
+            cy = float(np.clip(cy + rng.uniform(-r, r), 5, h - 5)); cx = float(np.clip(cx + rng.uniform(-r, r), 5, w - 5))
+        if i % 3 == 0:
+            m &= rng.random((h, w)) > 0.08                       # pepper the edge, then keep the largest piece
+        if i % 4 == 0:
+            m[int(cy) % h, :] |= m.any(0)                        # a one-pixel-high spur across the shape
+        if i % 7 == 0:
+            m[:, 0] |= m.any(1)                                  # touches the left frame
+        from scipy import ndimage as ndi
+        lab, nl = ndi.label(m, structure=np.ones((3, 3)))
+        if nl == 0:
+            continue
+        big = 1 + int(np.argmax(np.bincount(lab.ravel())[1:]))
+        masks.append(P.fill_holes(lab == big))
+    masks = np.stack(masks)
+    ops.set_frame_width(w)
+    try:
+        cs = ops.trace(ops.from_dense(masks), max_contours=16)
+        recs = cs.records(measure=False)
+        used, fell_back = cs.walker_stats
+        assert used == len(masks) and fell_back == 0
+        for i, m in enumerate(masks):
+            ref = P.find_external_contours(m)
+            assert len(ref) == len(recs[i]) == 1
+            np.testing.assert_array_equal(recs[i][0]["points"], ref[0], err_msg=f"mask {i}")
+            assert recs[i][0]["area"] == P.contour_area(ref[0])
+            assert abs(recs[i][0]["perimeter"] - P.arc_length(ref[0])) <= 1e-9 * max(1.0, P.arc_length(ref[0]))
+    finally:
+        ops.set_frame_width(0)
