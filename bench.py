@@ -71,7 +71,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=8, help="tiles per GPU per step")
+    ap.add_argument("--batch", type=int, default=16, help="tiles per GPU per step")
     ap.add_argument("--precision", choices=["f32", "f32x3", "bf16"], default="f32")
     ap.add_argument("--depth", type=int, default=101)
     ap.add_argument("--size", type=int, default=2048)
@@ -79,6 +79,8 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="do not overlap batch i+1's network with batch i's post-processing")
     ap.add_argument("--forward-only", action="store_true", help="time predictor(tile) only, without the per-tile post-processing")
+    ap.add_argument("--post-priority", choices=["default", "high", "low"], default="default", help="(experiment) priority of the post-processing stream")
+    ap.add_argument("--no-conv-events", action="store_true", help="(experiment) do not bracket the conv launches with HIP events")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -112,7 +114,8 @@ def main() -> None:
             torch.cuda.synchronize()
 
     net_stream = torch.cuda.Stream(device=dev)      # network of batch i+1 ...
-    post_stream = torch.cuda.Stream(device=dev)     # ... runs under the post-processing of batch i
+    prio = {"default": 0, "high": -1, "low": 1}[args.post_priority]
+    post_stream = torch.cuda.Stream(device=dev, priority=prio)     # ... runs under the post-processing of batch i
 
     def launch(i):
         with torch.cuda.stream(net_stream):
@@ -151,7 +154,7 @@ def main() -> None:
     for i in range(args.warmup):
         step(-1 - i)
     sync_all()
-    eng.conv_events = []
+    eng.conv_events = None if args.no_conv_events else []
     t0 = time.perf_counter()
     if args.forward_only or args.no_overlap:
         for i in range(args.steps):
@@ -166,7 +169,7 @@ def main() -> None:
             handle = nxt
     sync_all()
     dt = time.perf_counter() - t0
-    events, eng.conv_events = eng.conv_events, None
+    events, eng.conv_events = eng.conv_events or [], None
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

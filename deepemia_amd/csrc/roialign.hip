@@ -1,7 +1,7 @@
 // ROIAlignV2 (aligned=True, sampling_ratio=0 -> adaptive grid) over the FPN pyramid, NHWC.
-// HBM/L2 gather-bound: one wavefront per output bin, lanes span the channel axis so every
-// bilinear tap is one coalesced 256..1024-byte row read; the adaptive sample grid is walked
-// in registers.  -ffp-contract=off: coordinate arithmetic follows torchvision's op order.
+// HBM/L2 gather-bound: one workgroup per ROI (geometry once), one wavefront per output bin in turn, lanes span
+// the channel axis (16 B per lane) so every bilinear tap is one coalesced row read; the adaptive sample grid is
+// walked in registers.  -ffp-contract=off: coordinate arithmetic follows torchvision's op order.
 //
 // Replaces detectron2.modeling.poolers.ROIPooler.forward -> torchvision.ops.roi_align
 // (v0.11.1 roi_align_kernel.cpp) incl. assign_boxes_to_levels, as run by
@@ -20,21 +20,42 @@ struct RoiP {
     void* out;
 };
 
+template <typename T> struct Vec4;
+template <> struct Vec4<float> {
+    static __device__ __forceinline__ void load(const float* p, float v[4]) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+    static __device__ __forceinline__ void store(float* p, const float v[4]) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <> struct Vec4<bf16_t> {
+    static __device__ __forceinline__ void load(const bf16_t* p, float v[4]) {
+        const bf16x4 t = *reinterpret_cast<const bf16x4*>(p);
+        v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
+    }
+    static __device__ __forceinline__ void store(bf16_t* p, const float v[4]) {
+        bf16x4 o;
+        o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
+        *reinterpret_cast<bf16x4*>(p) = o;
+    }
+};
+
+// One workgroup per ROI: the box -> level / scale / bin geometry is worked out once, then the four waves walk the
+// P x P bins (wave w takes bins w, w + 4, ...).  Lanes span the channel axis, four channels per lane, so every
+// bilinear tap is one 16-byte load per lane = one coalesced 1 KiB row read per wave (C = 256).
 template <typename T>
 __global__ __launch_bounds__(256) void roi_align_kernel(const RoiP p) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const long bin = (long)blockIdx.x * 4 + wave;
+    const long roi = blockIdx.x;  // n*R + r
     const int PP = p.P * p.P;
-    const long total = (long)p.N * p.R * PP;
-    if (bin >= total) return;
-    const int pw = (int)(bin % p.P);
-    const int ph = (int)((bin / p.P) % p.P);
-    const long roi = bin / PP;  // n*R + r
     const int n = (int)(roi / p.R), r = (int)(roi % p.R);
-    T* out = reinterpret_cast<T*>(p.out) + bin * p.C;
-    const int cpl = p.C / 64;  // channels per lane (C = 256 -> 4)
+    const int cpl = p.C / 64;     // channels per lane group: lanes with lane * 4 >= C idle (C = 256 -> all busy)
+    const bool lane_on = lane * 4 < p.C;
+    (void)cpl;
+    T* out0 = reinterpret_cast<T*>(p.out) + roi * PP * p.C + lane * 4;
     if (r >= p.count[n]) {
-        for (int c = 0; c < cpl; ++c) out[lane * cpl + c] = from_f32<T>(0.f);
+        const float z[4] = {0.f, 0.f, 0.f, 0.f};
+        if (lane_on) for (int bin = wave; bin < PP; bin += 4) Vec4<T>::store(out0 + (long)bin * p.C, z);
         return;
     }
     const float4 b = reinterpret_cast<const float4*>(p.boxes)[roi];
@@ -45,7 +66,7 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiP p) {
     const int lv = (int)lvf - 2;
     const int H = p.H[lv], W = p.W[lv];
     const float scale = 1.0f / (float)(4 << lv);
-    const T* feat = reinterpret_cast<const T*>(p.feat[lv]) + (long)n * H * W * p.C;
+    const T* feat = reinterpret_cast<const T*>(p.feat[lv]) + (long)n * H * W * p.C + lane * 4;
 
     const float rsw = b.x * scale - 0.5f, rsh = b.y * scale - 0.5f;
     const float rew = b.z * scale - 0.5f, reh = b.w * scale - 0.5f;
@@ -53,45 +74,51 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiP p) {
     const float bin_h = rh / (float)p.P, bin_w = rw / (float)p.P;
     const int gh = (int)ceilf(rh / (float)p.P), gw = (int)ceilf(rw / (float)p.P);
     const float cnt = (float)max(gh * gw, 1);
+    if (!lane_on) return;
 
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int iy = 0; iy < gh; ++iy) {
-        float y = rsh + (float)ph * bin_h + ((float)iy + 0.5f) * bin_h / (float)gh;
-        const bool oy = (y < -1.0f) || (y > (float)H);
-        if (y <= 0.f) y = 0.f;
-        int yl = (int)y, yh;
-        if (yl >= H - 1) { yl = yh = H - 1; y = (float)yl; } else { yh = yl + 1; }
-        const float ly = y - (float)yl, hy = 1.0f - ly;
-        for (int ix = 0; ix < gw; ++ix) {
-            float x = rsw + (float)pw * bin_w + ((float)ix + 0.5f) * bin_w / (float)gw;
-            const bool ox = (x < -1.0f) || (x > (float)W);
-            if (oy || ox) continue;
-            if (x <= 0.f) x = 0.f;
-            int xl = (int)x, xh;
-            if (xl >= W - 1) { xl = xh = W - 1; x = (float)xl; } else { xh = xl + 1; }
-            const float lx = x - (float)xl, hx = 1.0f - lx;
-            const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
-            const T* p1 = feat + ((long)yl * W + xl) * p.C + lane * cpl;
-            const T* p2 = feat + ((long)yl * W + xh) * p.C + lane * cpl;
-            const T* p3 = feat + ((long)yh * W + xl) * p.C + lane * cpl;
-            const T* p4 = feat + ((long)yh * W + xh) * p.C + lane * cpl;
-            for (int c = 0; c < 4; ++c) {
-                if (c < cpl) {
-                    const float v = w1 * to_f32<T>(p1[c]) + w2 * to_f32<T>(p2[c]) + w3 * to_f32<T>(p3[c]) +
-                                    w4 * to_f32<T>(p4[c]);
+    for (int bin = wave; bin < PP; bin += 4) {
+        const int ph = bin / p.P, pw = bin - ph * p.P;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int iy = 0; iy < gh; ++iy) {
+            float y = rsh + (float)ph * bin_h + ((float)iy + 0.5f) * bin_h / (float)gh;
+            const bool oy = (y < -1.0f) || (y > (float)H);
+            if (y <= 0.f) y = 0.f;
+            int yl = (int)y, yh;
+            if (yl >= H - 1) { yl = yh = H - 1; y = (float)yl; } else { yh = yl + 1; }
+            const float ly = y - (float)yl, hy = 1.0f - ly;
+            for (int ix = 0; ix < gw; ++ix) {
+                float x = rsw + (float)pw * bin_w + ((float)ix + 0.5f) * bin_w / (float)gw;
+                const bool ox = (x < -1.0f) || (x > (float)W);
+                if (oy || ox) continue;
+                if (x <= 0.f) x = 0.f;
+                int xl = (int)x, xh;
+                if (xl >= W - 1) { xl = xh = W - 1; x = (float)xl; } else { xh = xl + 1; }
+                const float lx = x - (float)xl, hx = 1.0f - lx;
+                const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+                float v1[4], v2[4], v3[4], v4[4];
+                Vec4<T>::load(feat + ((long)yl * W + xl) * p.C, v1);
+                Vec4<T>::load(feat + ((long)yl * W + xh) * p.C, v2);
+                Vec4<T>::load(feat + ((long)yh * W + xl) * p.C, v3);
+                Vec4<T>::load(feat + ((long)yh * W + xh) * p.C, v4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float v = w1 * v1[c] + w2 * v2[c] + w3 * v3[c] + w4 * v4[c];
                     acc[c] += v;
                 }
             }
         }
+        float o[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o[c] = acc[c] / cnt;
+        Vec4<T>::store(out0 + (long)bin * p.C, o);
     }
-    for (int c = 0; c < cpl && c < 4; ++c) out[lane * cpl + c] = from_f32<T>(acc[c] / cnt);
 }
 
 }  // namespace
 
 extern "C" int demia_roi_align(const demia_roialign_desc* d, void* stream) {
     DEMIA_REQUIRE(d && d->boxes && d->count && d->out, "null pointer");
-    DEMIA_REQUIRE(d->C % 64 == 0 && d->C <= 256, "C must be 64, 128, 192 or 256");
+    DEMIA_REQUIRE(d->C % 4 == 0 && d->C <= 256, "C must be a multiple of 4, at most 256");
     DEMIA_REQUIRE(d->P > 0, "P");
     RoiP p;
     for (int l = 0; l < 4; ++l) {
@@ -99,9 +126,9 @@ extern "C" int demia_roi_align(const demia_roialign_desc* d, void* stream) {
         p.feat[l] = d->feat[l]; p.H[l] = d->H[l]; p.W[l] = d->W[l];
     }
     p.N = d->N; p.R = d->R; p.C = d->C; p.P = d->P; p.boxes = d->boxes; p.count = d->count; p.out = d->out;
-    const long total = (long)d->N * d->R * d->P * d->P;
-    if (total == 0) return DEMIA_OK;
-    const int grid = (int)((total + 3) / 4);
+    const long total = (long)d->N * d->R;
+    if (total == 0 || d->P == 0) return DEMIA_OK;
+    const int grid = (int)total;
     if (d->dtype == DEMIA_BF16)
         hipLaunchKernelGGL(roi_align_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     else
