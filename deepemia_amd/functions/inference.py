@@ -128,6 +128,11 @@ class _Detections:
                  bbox: Optional[torch.Tensor] = None):
         self.packed, self.scores, self.classes, self.hw = packed, scores, classes, hw
         self.bbox = bbox      # [n, 4] int32 on the device: the paste boxes (supersets of the tight mask boxes) or None
+        # the forward's whole mask / box tables ([B * D, H, W/32], [B * D, 4]) and this call's rows in them: lets a
+        # batched stage gather the masks of MANY tiles with one launch
+        self.base: Optional[torch.Tensor] = None
+        self.base_bbox: Optional[torch.Tensor] = None
+        self.base_idx: Optional[np.ndarray] = None
 
 
 class EmptyEnsembleTypeError(ValueError):
@@ -185,7 +190,13 @@ class InferencePipeline:
                 else:
                     si = torch.from_numpy(sel).to(self.dev)
                     packed, bbox = raw.packed[b, si], (None if raw.bbox is None else raw.bbox[b, si])
-                out.append(_Detections(packed, scores[b, :n][sel], classes[b, :n][sel], (h, w), bbox))
+                det = _Detections(packed, scores[b, :n][sel], classes[b, :n][sel], (h, w), bbox)
+                if raw.bbox is not None:
+                    D = int(raw.packed.shape[1])
+                    det.base = raw.packed.view((-1,) + tuple(raw.packed.shape[2:]))
+                    det.base_bbox = raw.bbox.view(-1, 4)
+                    det.base_idx = (b * D + sel).astype(np.int64)
+                out.append(det)
         return out
 
     def _predict_batch(self, model_idx: int, key: str, images: torch.Tensor) -> List[_Detections]:
@@ -436,24 +447,42 @@ class InferencePipeline:
         other kernel is per mask anyway.  Returns per tile (index tensor into the returned big tensor, scores)."""
         T = len(dets)
         dev = self.dev
-        sels, parts, hints = [], [], []
+        sels = []
         for det in dets:
             sel = np.nonzero(det.classes == target_class)[0]
-            sel = sel[det.scores[sel] >= conf]
-            sels.append(sel)
-            if len(sel):
-                si = torch.from_numpy(sel).to(dev)
-                parts.append(det.packed[si])
-                hints.append(None if det.bbox is None else det.bbox[si])
+            sels.append(sel[det.scores[sel] >= conf])
         lens = [len(x) for x in sels]
         empty = [([], []) for _ in range(T)]
         if sum(lens) == 0:
             return None, empty, None
-        packed = torch.cat(parts, dim=0)          # our own copy: every stage below works on it in place
-        if any(h is None for h in hints):
+        # our own copy of the selected masks (every stage below works on it in place): ONE gather per forward table
+        packed = torch.empty((sum(lens),) + tuple(dets[0].packed.shape[1:]), dtype=dets[0].packed.dtype, device=dev)
+        bbox = torch.empty((sum(lens), 4), dtype=torch.int32, device=dev)
+        have_hint, pos, t = True, 0, 0
+        while t < T:
+            if dets[t].base is not None:                       # the run of tiles that share this forward's table
+                t1 = t
+                while t1 < T and dets[t1].base is dets[t].base:
+                    t1 += 1
+                gi = np.concatenate([dets[u].base_idx[sels[u]] for u in range(t, t1)])
+                if len(gi):
+                    gt = torch.from_numpy(gi).to(dev)
+                    torch.index_select(dets[t].base, 0, gt, out=packed[pos:pos + len(gi)])
+                    torch.index_select(dets[t].base_bbox, 0, gt, out=bbox[pos:pos + len(gi)])
+                pos += len(gi)
+                t = t1
+            else:
+                if lens[t]:
+                    si = torch.from_numpy(sels[t]).to(dev)
+                    torch.index_select(dets[t].packed, 0, si, out=packed[pos:pos + lens[t]])
+                    if dets[t].bbox is None:
+                        have_hint = False
+                    else:
+                        torch.index_select(dets[t].bbox, 0, si, out=bbox[pos:pos + lens[t]])
+                pos += lens[t]
+                t += 1
+        if not have_hint:
             _, bbox = self.ops.area_bbox(packed)
-        else:
-            bbox = torch.cat(hints, dim=0).contiguous()
         is_small = target_class in small_classes
         min_size = self.class_specific_settings.get(f"class_{target_class}", {}).get("min_size", 5 if is_small else 25)
         seg_np = np.repeat(np.arange(T, dtype=np.int32), lens)
@@ -558,31 +587,36 @@ class InferencePipeline:
             dets = self._predict_batch(model_ids[0], key, tiles)
         self.ops.set_frame_width(int(tiles.shape[2]))
         T, dev = len(dets), self.dev
-        per_tile_parts: List[List[torch.Tensor]] = [[] for _ in range(T)]
-        per_tile_scores: List[list] = [[] for _ in range(T)]
-        per_tile_classes: List[list] = [[] for _ in range(T)]
-        per_tile_area: List[list] = [[] for _ in range(T)]
-        per_tile_bbox: List[list] = [[] for _ in range(T)]
+        # ---- class loop: one batched pass per class; what survives is gathered ONCE per class into `allp` (class-major
+        # storage; every tile keeps its own index list in the reference's order: class by class, score order inside)
+        passes = []
         for cls, (conf, iou_thr) in class_thresholds.items():
             big, res, calg = self._single_class_pass_batched(dets, cls, small_classes, conf, iou_thr)
-            if big is None:
-                continue
-            for t, (kept, sc) in enumerate(res):
-                if kept:
-                    per_tile_parts[t].append(big[torch.tensor(kept, dtype=torch.long, device=dev)])
-                    per_tile_scores[t].extend(sc)
-                    per_tile_classes[t].extend([cls] * len(kept))
-                    per_tile_area[t].append(calg.area[kept])           # already reduced by the class pass
-                    per_tile_bbox[t].append(calg.bbox[kept])
-        # ---- cross-class dedup (a14) for all tiles: one contour launch, one pair-count launch -------------------
-        lens = [sum(int(p.shape[0]) for p in per_tile_parts[t]) for t in range(T)]
+            if big is not None and any(len(k) for k, _ in res):
+                passes.append((cls, big, res, calg))
         out = [(None, [], [], []) for _ in range(T)]
-        if sum(lens) == 0:
+        total = sum(len(k) for _, _, res, _ in passes for k, _ in res)
+        if total == 0:
             return out
-        allp = torch.cat([p for t in range(T) for p in per_tile_parts[t]], dim=0)
-        bounds = np.concatenate(([0], np.cumsum(lens)))
-        area_all = np.concatenate([a for t in range(T) for a in per_tile_area[t]])
-        bbox_all = np.concatenate([b for t in range(T) for b in per_tile_bbox[t]])
+        allp = torch.empty((total,) + tuple(passes[0][1].shape[1:]), dtype=passes[0][1].dtype, device=dev)
+        tile_items: List[List[int]] = [[] for _ in range(T)]
+        scores_all, classes_all, area_parts, bbox_parts = [], [], [], []
+        off = 0
+        for cls, big, res, calg in passes:
+            src = [i for kept, _ in res for i in kept]
+            pos = off
+            for t, (kept, sc) in enumerate(res):
+                tile_items[t].extend(range(pos, pos + len(kept)))
+                pos += len(kept)
+                scores_all.extend(sc)
+            classes_all.extend([cls] * len(src))
+            torch.index_select(big, 0, torch.tensor(src, dtype=torch.long, device=dev), out=allp[off:off + len(src)])
+            area_parts.append(calg.area[src])           # already reduced by the class pass
+            bbox_parts.append(calg.bbox[src])
+            off += len(src)
+        # ---- cross-class dedup (a14) for all tiles: one contour launch, one pair-count launch -------------------
+        area_all = np.concatenate(area_parts)
+        bbox_all = np.concatenate(bbox_parts)
         alg = DeviceMaskAlgebra(self.ops, allp, area=area_all, bbox=bbox_all)
         # traced ONCE: reused for the final measurements
         cset = self.ops.trace(allp, max_contours=256, bbox=alg._bbox_dev, total_area=int(area_all.sum()))
@@ -590,7 +624,7 @@ class InferencePipeline:
         keep0_all, groups = [], []
         for t in range(T):
             k0 = []
-            for idx in range(bounds[t], bounds[t + 1]):
+            for idx in tile_items[t]:
                 if alg.bbox[idx, 0] < 0:
                     continue
                 per = per0[idx]
@@ -598,7 +632,7 @@ class InferencePipeline:
                     continue
                 k0.append(idx)
             keep0_all.append(k0)
-            cl = [per_tile_classes[t][i - bounds[t]] for i in k0]
+            cl = [classes_all[i] for i in k0]
             for c in set(cl):
                 g = [k0[i] for i in range(len(k0)) if cl[i] == c]
                 if len(g) > 1:
@@ -607,8 +641,8 @@ class InferencePipeline:
         final_idx: List[List[int]] = []
         for t in range(T):
             k0 = keep0_all[t]
-            scores = [per_tile_scores[t][i - bounds[t]] for i in k0]
-            classes = [per_tile_classes[t][i - bounds[t]] for i in k0]
+            scores = [scores_all[i] for i in k0]
+            classes = [classes_all[i] for i in k0]
             bb = [(int(alg.bbox[i, 0]), int(alg.bbox[i, 2]), int(alg.bbox[i, 1]), int(alg.bbox[i, 3])) for i in k0]
             keep = self._dedup_smart_order(alg, k0, scores, classes, bb, 0.7) if k0 else []
             gl = [k0[i] for i in keep]
