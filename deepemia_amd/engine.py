@@ -166,7 +166,7 @@ class RawDetections:
 
 class MaskRCNNEngine:
     def __init__(self, state_dict: Dict[str, torch.Tensor], depth: int, num_classes: int, score_thresh: float,
-                 device: str = "cuda:0", precision: str = "bf16"):
+                 device: str = "cuda:0", precision: str = "f32x3"):
         if depth not in RES_BLOCKS:
             raise ValueError(f"unsupported ResNet depth {depth}")
         if not torch.cuda.is_available():
@@ -183,7 +183,7 @@ class MaskRCNNEngine:
         self.tdt = torch.bfloat16 if precision == "bf16" else torch.float32
         self._tables: Dict[Tuple[int, int], dict] = {}
         self._cell = cell_anchor_table()
-        self.conv_events = None   # bench hook: list of (start_event, end_event, algorithmic_flops)
+        self.conv_events = None   # bench hook: list of (start_event, end_event, algorithmic_flops, kernel kind, algorithmic_bytes)
         self.unmatched_keys: List[str] = []
         self._used = set()
         self._pack(state_dict)
@@ -300,7 +300,12 @@ class MaskRCNNEngine:
         _lib.check(self.lib.demia_conv2d_nhwc(C.byref(d), self._stream()), "demia_conv2d_nhwc")
         if ev is not None:
             e1.record(torch.cuda.current_stream(self.device))
-            ev.append((e0, e1, 2.0 * n * ho * wo * L.cout * L.kh * L.kw * cin))
+            esz = 2 if self.dt == BF16 else 4
+            osz = 2 if odt == torch.bfloat16 else 4
+            nbytes = (n * h * w * cin * esz + L.cout_pad * L.kh * L.kw * cin * (6 if use3 else esz) + n * ho * wo * L.cout * osz +
+                      (0 if residual is None else residual.numel() * osz))     # every operand once: the algorithmic traffic
+            ev.append((e0, e1, 2.0 * n * ho * wo * L.cout * L.kh * L.kw * cin,
+                       "f32x3" if use3 else ("bf16" if self.dt == BF16 else "f32"), nbytes))
         return out
 
     def _resize_tables(self, h: int, w: int):

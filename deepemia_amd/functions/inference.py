@@ -182,6 +182,9 @@ class InferencePipeline:
             valid = raw.valid.cpu().numpy().astype(bool)
             scores = raw.scores.cpu().numpy()
             classes = raw.classes.cpu().numpy().astype(np.int64)
+            # ONE view object per forward: detections of the same forward are recognised by `base is base`
+            base = None if raw.bbox is None else raw.packed.view((-1,) + tuple(raw.packed.shape[2:]))
+            base_bbox = None if raw.bbox is None else raw.bbox.view(-1, 4)
             for b in range(raw.count.shape[0]):
                 n = int(counts[b])
                 sel = np.nonzero(valid[b, :n])[0]
@@ -191,11 +194,9 @@ class InferencePipeline:
                     si = torch.from_numpy(sel).to(self.dev)
                     packed, bbox = raw.packed[b, si], (None if raw.bbox is None else raw.bbox[b, si])
                 det = _Detections(packed, scores[b, :n][sel], classes[b, :n][sel], (h, w), bbox)
-                if raw.bbox is not None:
-                    D = int(raw.packed.shape[1])
-                    det.base = raw.packed.view((-1,) + tuple(raw.packed.shape[2:]))
-                    det.base_bbox = raw.bbox.view(-1, 4)
-                    det.base_idx = (b * D + sel).astype(np.int64)
+                if base is not None:
+                    det.base, det.base_bbox = base, base_bbox
+                    det.base_idx = (b * int(raw.packed.shape[1]) + sel).astype(np.int64)
                 out.append(det)
         return out
 
