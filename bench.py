@@ -86,15 +86,22 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal of the N > 1 path on a one-GPU box: DEEPEMIA_BENCH_BACKEND=gloo DEEPEMIA_BENCH_ONE_DEVICE=1 (all ranks on cuda:0)
+    backend = os.environ.get("DEEPEMIA_BENCH_BACKEND", "nccl")
+    one_dev = os.environ.get("DEEPEMIA_BENCH_ONE_DEVICE", "0") == "1"
+    dev_index = 0 if (world == 1 or one_dev) else local_rank
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{dev_index}"))
+        else:
+            dist.init_process_group(backend)
     else:
         dist = None
         torch.cuda.set_device(0)
-    dev = f"cuda:{local_rank if world > 1 else 0}"
+    dev = f"cuda:{dev_index}"
 
     from deepemia_amd import parallel, synth
     from deepemia_amd.engine import MaskRCNNEngine
@@ -135,15 +142,18 @@ def main() -> None:
         n_inst = sum(0 if r[0] is None else int(r[0].shape[0]) for r in res)
         n_rows = sum(len(c) for r in res for c in r[3])
         if dist is not None:
-            # the one exchange of the path: instance tables of every rank's tiles (unit id = global tile index)
+            # the one exchange of the path: instance tables of every rank's tiles (unit id = global tile index);
+            # areas / boxes come from the reductions the path has already done, the crop is one launch
             parts = [r[0] for r in res if r[0] is not None and r[0].shape[0]]
-            packed = torch.cat(parts) if parts else None
-            scores = [s_ for r in res for s_ in r[1]]
-            classes = [c_ for r in res for c_ in r[2]]
-            units = [rank * args.batch + t for t, r in enumerate(res) for _ in r[1]]
-            if packed is not None:
-                a, b = pipe.ops.area_bbox(packed)
-                hdr, pay = parallel.encode_instance_table(packed, scores, classes, units, b.cpu().numpy(), a.cpu().numpy())
+            if parts:
+                packed = torch.cat(parts)
+                scores = [s_ for r in res for s_ in r[1]]
+                classes = [c_ for r in res for c_ in r[2]]
+                units = [rank * args.batch + t for t, r in enumerate(res) for _ in r[1]]
+                stats = [st for st, r in zip(pipe.last_batch_stats, res) if r[0] is not None and r[0].shape[0]]
+                area = np.concatenate([a for a, _ in stats])
+                bbox = np.concatenate([b for _, b in stats])
+                hdr, pay = parallel.encode_instance_table(packed, scores, classes, units, bbox, area)
             else:
                 hdr = torch.zeros((0, parallel.HDR), dtype=torch.int32, device=dev)
                 pay = torch.zeros((0,), dtype=torch.int32, device=dev)
@@ -171,7 +181,7 @@ def main() -> None:
     dt = time.perf_counter() - t0
     events, eng.conv_events = eng.conv_events or [], None
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 

@@ -278,6 +278,26 @@ __global__ void place_tile_kernel(const uint32_t* __restrict__ src, uint32_t* __
     }
 }
 
+// ---- instance tables (what crosses xGMI): the bbox rows x word columns of every mask, back to back --------------
+// offsets = exclusive prefix sums of (rows * word columns) per mask; PACK: masks -> payload, else payload -> masks
+// (the destination planes are zero everywhere else: the caller hands in a zeroed tensor).
+template <bool PACK>
+__global__ __launch_bounds__(256) void crop_copy_kernel(uint32_t* masks, const int* __restrict__ bbox, const long* __restrict__ offsets,
+                                                        int H, int W, uint32_t* payload) {
+    const int m = blockIdx.x;
+    const int y0 = bbox[m * 4 + 0], x0 = bbox[m * 4 + 1], y1 = bbox[m * 4 + 2], x1 = bbox[m * 4 + 3];
+    if (y0 < 0) return;
+    const int wpr = (W + 31) >> 5;
+    const int c0 = x0 >> 5, cols = (x1 >> 5) - c0 + 1, rows = y1 - y0 + 1;
+    uint32_t* plane = masks + (long)m * H * wpr + (long)y0 * wpr + c0;
+    uint32_t* seg = payload + offsets[m];
+    for (int t = threadIdx.x; t < rows * cols; t += blockDim.x) {
+        const int ry = t / cols, cx = t - ry * cols;
+        if (PACK) seg[t] = plane[(long)ry * wpr + cx];
+        else plane[(long)ry * wpr + cx] = seg[t];
+    }
+}
+
 inline int grid_for(long total, int block) {
     long g = (total + block - 1) / block;
     return (int)(g > 32768 ? 32768 : (g < 1 ? 1 : g));
@@ -345,5 +365,25 @@ extern "C" int demia_mask_place_tiles(const uint32_t* src, uint32_t* dst, const 
     hipLaunchKernelGGL(place_tile_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, x_off, y_off,
                        (int)T, src_h, src_w, tile_h, tile_w, H, W);
     DEMIA_CHECK_LAUNCH("place_tile_kernel");
+    return DEMIA_OK;
+}
+
+extern "C" int demia_mask_crop_pack(const uint32_t* masks, const int32_t* bbox, const int64_t* offsets, int64_t M, int H, int W,
+                                    uint32_t* payload, void* stream) {
+    DEMIA_REQUIRE(masks && bbox && offsets && payload && W > 0, "args");
+    if (M == 0) return DEMIA_OK;
+    hipLaunchKernelGGL(crop_copy_kernel<true>, dim3((int)M), dim3(256), 0, (hipStream_t)stream, const_cast<uint32_t*>(masks), bbox,
+                       reinterpret_cast<const long*>(offsets), H, W, payload);
+    DEMIA_CHECK_LAUNCH("crop_copy_kernel<pack>");
+    return DEMIA_OK;
+}
+
+extern "C" int demia_mask_crop_unpack(const uint32_t* payload, const int32_t* bbox, const int64_t* offsets, int64_t M, int H, int W,
+                                      uint32_t* masks, void* stream) {
+    DEMIA_REQUIRE(masks && bbox && offsets && payload && W > 0, "args");
+    if (M == 0) return DEMIA_OK;
+    hipLaunchKernelGGL(crop_copy_kernel<false>, dim3((int)M), dim3(256), 0, (hipStream_t)stream, masks, bbox,
+                       reinterpret_cast<const long*>(offsets), H, W, const_cast<uint32_t*>(payload));
+    DEMIA_CHECK_LAUNCH("crop_copy_kernel<unpack>");
     return DEMIA_OK;
 }

@@ -154,6 +154,7 @@ class InferencePipeline:
         self.ensemble_weights = list(gens.get("weights", {"R50": 0.6, "R101": 0.4}).values())
         self.class_specific_settings = inf_settings.get("class_specific_settings", {})
         self._cache: Dict[Tuple[int, str], List[_Detections]] = {}
+        self.last_batch_stats = None
         self.forward_calls = 0
         import torch.distributed as dist
         self.rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
@@ -659,6 +660,8 @@ class InferencePipeline:
         finalp = allp[torch.tensor(flat, dtype=torch.long, device=dev)].contiguous()
         recs = cset.records(um_pix=um_pix, measure=True, select=flat)
         pos = 0
+        # pixel counts / tight boxes of the final masks, per tile (what an instance table needs; already reduced)
+        self.last_batch_stats = [(alg.area[final_idx[t]], alg.bbox[final_idx[t]]) for t in range(T)]
         for t in range(T):
             n = len(final_idx[t])
             if n:

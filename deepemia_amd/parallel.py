@@ -35,41 +35,83 @@ def _crop_words(bbox_row) -> Tuple[int, int, int, int]:
     return y0, y1 + 1, x0 >> 5, (x1 >> 5) + 1
 
 
+def _payload_lengths(hdr: np.ndarray) -> np.ndarray:
+    """Words of payload per instance: bbox rows x word columns (0 for an empty mask)."""
+    lens = np.zeros(hdr.shape[0], dtype=np.int64)
+    ok = hdr[:, 4] >= 0
+    lens[ok] = (hdr[ok, 6].astype(np.int64) - hdr[ok, 4] + 1) * ((hdr[ok, 7] >> 5) - (hdr[ok, 5] >> 5) + 1)
+    return lens
+
+
+def _offsets(lens: np.ndarray) -> np.ndarray:
+    return np.concatenate(([0], np.cumsum(lens)[:-1])).astype(np.int64) if len(lens) else np.zeros((0,), dtype=np.int64)
+
+
 def encode_instance_table(packed: Optional[torch.Tensor], scores: Sequence[float], classes: Sequence[int], unit_ids: Sequence[int],
                           bbox: np.ndarray, area: np.ndarray) -> Tuple[torch.Tensor, torch.Tensor]:
-    """-> (header [n, 10] int32, payload [L] int32) on the masks' device."""
+    """-> (header [n, 10] int32, payload [L] int32) on the masks' device.  Device masks are cropped by ONE launch
+    (``demia_mask_crop_pack``); host masks (the gloo tests) by numpy slicing."""
     n = 0 if packed is None else int(packed.shape[0])
     dev = packed.device if packed is not None else torch.device("cpu")
     hdr = np.zeros((n, HDR), dtype=np.int32)
-    chunks = []
+    if n == 0:
+        return torch.from_numpy(hdr).to(dev), torch.zeros((0,), dtype=torch.int32, device=dev)
+    hdr[:, 0] = np.asarray(unit_ids, dtype=np.int32)
+    hdr[:, 1] = np.asarray(classes, dtype=np.int32)
+    hdr[:, 2:4] = np.asarray(scores, dtype=np.float64).reshape(n, 1).view(np.int32)   # exact: ensemble scores are f64 products
+    hdr[:, 4:8] = np.asarray(bbox, dtype=np.int32).reshape(n, 4)
+    hdr[:, 8] = np.asarray(area, dtype=np.int32)
+    lens = _payload_lengths(hdr)
+    offs = _offsets(lens)
+    total = int(lens.sum())
+    if packed.is_cuda:
+        from . import _lib
+
+        payload = torch.empty((total,), dtype=torch.int32, device=dev)
+        hdr_t = torch.from_numpy(hdr).to(dev)
+        if total:
+            pk = packed.contiguous()
+            bb = hdr_t[:, 4:8].contiguous()
+            of = torch.from_numpy(offs).to(dev)
+            H, W = int(pk.shape[1]), int(pk.shape[2]) * 32
+            _lib.check(_lib.load().demia_mask_crop_pack(_lib.ptr(pk), _lib.ptr(bb), _lib.ptr(of), n, H, W, _lib.ptr(payload),
+                                                        int(torch.cuda.current_stream(dev).cuda_stream)), "demia_mask_crop_pack")
+        return hdr_t, payload
+    pk = packed.numpy()
+    out = np.empty((total,), dtype=np.int32)
     for i in range(n):
-        hdr[i, 0] = int(unit_ids[i])
-        hdr[i, 1] = int(classes[i])
-        hdr[i, 2:4] = np.array([scores[i]], dtype=np.float64).view(np.int32)   # exact: ensemble scores are f64 products
-        hdr[i, 4:8] = bbox[i]
-        hdr[i, 8] = int(area[i])
-        if bbox[i, 0] >= 0:
-            r0, r1, c0, c1 = _crop_words(bbox[i])
-            chunks.append(packed[i, r0:r1, c0:c1].reshape(-1))
-    payload = torch.cat(chunks) if chunks else torch.zeros((0,), dtype=torch.int32, device=dev)
-    return torch.from_numpy(hdr).to(dev), payload.to(torch.int32)
+        if lens[i]:
+            r0, r1, c0, c1 = _crop_words(hdr[i, 4:8])
+            out[offs[i]: offs[i] + lens[i]] = pk[i, r0:r1, c0:c1].reshape(-1)
+    return torch.from_numpy(hdr), torch.from_numpy(out)
 
 
 def decode_instance_table(header: torch.Tensor, payload: torch.Tensor, H: int, W: int, device=None):
     """-> (packed [n, H, W/32] int32, scores list, classes list, unit ids list)."""
-    device = header.device if device is None else device
+    device = torch.device(header.device if device is None else device)
     hdr = header.cpu().numpy()
     n = hdr.shape[0]
-    packed = torch.zeros((n, H, (W + 31) // 32), dtype=torch.int32, device=device)
-    payload = payload.to(device)
-    off = 0
-    for i in range(n):
-        if hdr[i, 4] < 0:
-            continue
-        r0, r1, c0, c1 = _crop_words(hdr[i, 4:8])
-        cnt = (r1 - r0) * (c1 - c0)
-        packed[i, r0:r1, c0:c1] = payload[off:off + cnt].view(r1 - r0, c1 - c0)
-        off += cnt
+    wpr = (W + 31) // 32
+    lens = _payload_lengths(hdr)
+    offs = _offsets(lens)
+    if device.type == "cuda":
+        from . import _lib
+
+        packed = torch.zeros((n, H, wpr), dtype=torch.int32, device=device)
+        if n and int(lens.sum()):
+            pay = payload.to(device).contiguous()
+            bb = torch.from_numpy(np.ascontiguousarray(hdr[:, 4:8])).to(device)
+            of = torch.from_numpy(offs).to(device)
+            _lib.check(_lib.load().demia_mask_crop_unpack(_lib.ptr(pay), _lib.ptr(bb), _lib.ptr(of), n, H, W, _lib.ptr(packed),
+                                                          int(torch.cuda.current_stream(device).cuda_stream)), "demia_mask_crop_unpack")
+    else:
+        pk = np.zeros((n, H, wpr), dtype=np.int32)
+        pay = payload.cpu().numpy()
+        for i in range(n):
+            if lens[i]:
+                r0, r1, c0, c1 = _crop_words(hdr[i, 4:8])
+                pk[i, r0:r1, c0:c1] = pay[offs[i]: offs[i] + lens[i]].reshape(r1 - r0, c1 - c0)
+        packed = torch.from_numpy(pk)
     scores = [float(v) for v in np.ascontiguousarray(hdr[:, 2:4]).view(np.float64).reshape(-1)] if n else []
     return packed, scores, [int(v) for v in hdr[:, 1]], [int(v) for v in hdr[:, 0]]
 
@@ -78,51 +120,47 @@ def all_gather_instance_tables(header: torch.Tensor, payload: torch.Tensor, grou
     """All ranks contribute their table; every rank returns the GLOBAL table ordered by (unit id, local
     order).  Works with RCCL (device tensors) and gloo (host tensors)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return _sort_by_unit(header, payload)
+        return _merge_tables([header], [payload])
     world = dist.get_world_size(group)
     backend = dist.get_backend(group)
     comm_dev = header.device if backend == "nccl" else torch.device("cpu")
     h = header.to(comm_dev).contiguous()
     p = payload.to(comm_dev).contiguous()
     sizes = torch.tensor([h.shape[0], p.shape[0]], dtype=torch.int64, device=comm_dev)
-    all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
-    dist.all_gather(all_sizes, sizes, group=group)
-    max_n = max(int(s[0]) for s in all_sizes)
-    max_p = max(int(s[1]) for s in all_sizes)
+    all_sizes = torch.zeros((world, 2), dtype=torch.int64, device=comm_dev)
+    dist.all_gather_into_tensor(all_sizes, sizes, group=group) if backend == "nccl" else \
+        dist.all_gather(list(all_sizes.unbind(0)), sizes, group=group)
+    all_sizes = all_sizes.cpu().numpy()
+    max_n, max_p = int(all_sizes[:, 0].max()), int(all_sizes[:, 1].max())
     buf = torch.zeros((max_n * HDR + max_p,), dtype=torch.int32, device=comm_dev)
     buf[: h.numel()] = h.reshape(-1)
     buf[max_n * HDR: max_n * HDR + p.numel()] = p
-    gathered = [torch.zeros_like(buf) for _ in range(world)]
-    dist.all_gather(gathered, buf, group=group)
-    hs, ps = [], []
-    for r in range(world):
-        n_r, p_r = int(all_sizes[r][0]), int(all_sizes[r][1])
-        hs.append(gathered[r][: n_r * HDR].view(n_r, HDR))
-        ps.append(gathered[r][max_n * HDR: max_n * HDR + p_r])
+    gathered = torch.empty((world, buf.numel()), dtype=torch.int32, device=comm_dev)
+    if backend == "nccl":
+        dist.all_gather_into_tensor(gathered, buf, group=group)      # one direct all-gather over the xGMI mesh
+    else:
+        dist.all_gather(list(gathered.unbind(0)), buf, group=group)
+    hs = [gathered[r, : int(all_sizes[r, 0]) * HDR].view(-1, HDR) for r in range(world)]
+    ps = [gathered[r, max_n * HDR: max_n * HDR + int(all_sizes[r, 1])] for r in range(world)]
     out_h, out_p = _merge_tables(hs, ps)
     return out_h.to(header.device), out_p.to(payload.device)
 
 
-def _payload_lengths(hdr: np.ndarray) -> np.ndarray:
-    lens = np.zeros(hdr.shape[0], dtype=np.int64)
-    ok = hdr[:, 4] >= 0
-    lens[ok] = (hdr[ok, 6] - hdr[ok, 4] + 1) * ((hdr[ok, 7] >> 5) - (hdr[ok, 5] >> 5) + 1)
-    return lens
-
-
 def _merge_tables(headers: List[torch.Tensor], payloads: List[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Concatenate rank tables and order instances by unit id (stable: local order within a unit)."""
-    recs = []
-    for r, (h, p) in enumerate(zip(headers, payloads)):
-        hn = h.cpu().numpy()
-        offs = np.concatenate(([0], np.cumsum(_payload_lengths(hn))))
-        for i in range(hn.shape[0]):
-            recs.append((int(hn[i, 0]), r, i, h[i], p[int(offs[i]): int(offs[i + 1])]))
-    recs.sort(key=lambda t: (t[0], t[1], t[2]))
-    if not recs:
-        return headers[0][:0], payloads[0][:0]
-    return torch.stack([t[3] for t in recs]), torch.cat([t[4] for t in recs])
-
-
-def _sort_by_unit(header: torch.Tensor, payload: torch.Tensor):
-    return _merge_tables([header], [payload])
+    """Concatenate rank tables and order instances by unit id (stable: rank, then local order within a unit).
+    Round-robin / blocked unit assignment usually leaves the concatenation already ordered; otherwise the payload
+    segments are permuted with one index gather."""
+    hcat = torch.cat(headers, dim=0) if len(headers) > 1 else headers[0]
+    pcat = torch.cat(payloads, dim=0) if len(payloads) > 1 else payloads[0]
+    hn = hcat.cpu().numpy()
+    n = hn.shape[0]
+    if n == 0:
+        return hcat, pcat
+    order = np.argsort(hn[:, 0], kind="stable")                   # concatenation order = (rank, local index): stable sort keeps it
+    if np.array_equal(order, np.arange(n)):
+        return hcat, pcat
+    lens = _payload_lengths(hn)
+    offs = _offsets(lens)
+    idx = np.concatenate([np.arange(offs[i], offs[i] + lens[i], dtype=np.int64) for i in order]) if int(lens.sum()) else np.zeros((0,), dtype=np.int64)
+    ot = torch.from_numpy(order).to(hcat.device)
+    return hcat[ot].contiguous(), pcat[torch.from_numpy(idx).to(pcat.device)].contiguous()

@@ -250,6 +250,14 @@ int demia_mask_pair_intersections(const uint32_t* a, const uint32_t* b, const in
                                   int H, int W, void* stream);
 int demia_mask_place_tiles(const uint32_t* src, uint32_t* dst, const int32_t* x_off, const int32_t* y_off, int64_t T,
                            int src_h, int src_w, int tile_h, int tile_w, int H, int W, void* stream);
+/* Instance tables (what the ranks exchange before the global duplicate / containment filters,
+ * inference.py:2452-2460): the payload of mask m is its bbox rows x word columns, row-major, at payload[offsets[m]];
+ * offsets [M] i64 = exclusive prefix sums of rows * word columns (0 for empty masks, bbox -1).  crop_unpack writes
+ * the regions into `masks`, which the caller has zeroed.                                                           */
+int demia_mask_crop_pack(const uint32_t* masks, const int32_t* bbox, const int64_t* offsets, int64_t M, int H, int W,
+                         uint32_t* payload, void* stream);
+int demia_mask_crop_unpack(const uint32_t* payload, const int32_t* bbox, const int64_t* offsets, int64_t M, int H, int W,
+                           uint32_t* masks, void* stream);
 
 /* a17/a18: contours and morphometrics ---------------------------------------------------------
  * demia_mask_contours = cv2.findContours(mask, RETR_EXTERNAL, CHAIN_APPROX_SIMPLE) per mask
