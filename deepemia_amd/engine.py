@@ -214,7 +214,7 @@ class MaskRCNNEngine:
         dev = self.device
         w3 = None
         if self.precision == "f32x3" and cout_pad % 64 == 0 and cin % 32 == 0:
-            w3 = split3_bf16(wp).to(dev).contiguous()
+            w3 = split3_bf16(wp.to(dev)).contiguous()          # split on the device: same round-to-nearest casts
         return ConvLayer(wp.to(dev, self.tdt).contiguous(),
                          None if scale is None else scale.to(dev).contiguous(),
                          None if b is None else b.to(dev).contiguous(), cin, cout, cout_pad, kh, kw, stride, pad, w3)

@@ -34,7 +34,7 @@ from ..utils.config import get_config
 from ..utils.logger_utils import log_memory_usage, system_logger
 from ..utils.mask_algebra import DeviceMaskAlgebra
 from ..utils.mask_utils import (postprocess_masks_device, postprocess_masks_universal_device, process_masks_device,
-                                rle_encoding)
+                                rle_encoding_packed)
 from ..utils.spatial_constraints import apply_spatial_constraints_indices, load_spatial_constraints
 
 CSV_HEADER = ["Instance_ID", "Class", "Class_Name", "Major axis length", "Minor axis length", "Eccentricity", "C. Length",
@@ -792,11 +792,10 @@ def run_inference(dataset_name, output_dir, visualize=True, threshold=0.65, draw
                                    "hw": (int(image_dev.shape[0]), int(image_dev.shape[1]))}
             processed.add(name)
             if n_final:
-                dense = pipe.ops.to_dense(packed, int(image_dev.shape[1]))
-                for i in range(n_final):
+                pipe.ops.set_frame_width(int(image_dev.shape[1]))
+                for runs in rle_encoding_packed(pipe.ops, packed, int(image_dev.shape[1])):
                     Img_ID.append(name.rsplit(".", 1)[0])
-                    EncodedPixels.append(" ".join(map(str, rle_encoding(dense[i]))))
-                del dense
+                    EncodedPixels.append(" ".join(map(str, runs)))
             system_logger.info(f"Image {name}: {n_final} instances in {time.perf_counter() - t0:.2f}s")
         except Exception as e:  # reference semantics: log, skip the image, continue (inference.py:928-931)
             system_logger.error(f"Error processing image {name}: {e}", exc_info=True)

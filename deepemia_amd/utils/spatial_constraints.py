@@ -6,6 +6,7 @@ GPU bit-packed and are consulted through :class:`~deepemia_amd.utils.mask_algebr
 """
 from __future__ import annotations
 
+import numpy as np
 from typing import Dict, List, Sequence, Set
 
 from .config import get_config
@@ -93,16 +94,20 @@ def filter_by_overlap_rules(alg, scores: Sequence[float], classes: Sequence[int]
         if allow_overlap and max_iou >= 0.9:
             continue
         order = sorted(positions, key=lambda p: scores[p], reverse=True)
+        # box-overlap matrix of this class once (numpy) instead of one Python box test per pair: same pairs, same order
+        bb = np.asarray([alg.bbox[idx[p]] for p in order], dtype=np.int64).reshape(-1, 4)
+        okb = bb[:, 0] >= 0
+        ov = ~((bb[:, None, 3] < bb[None, :, 1]) | (bb[None, :, 3] < bb[:, None, 1]) |
+               (bb[:, None, 2] < bb[None, :, 0]) | (bb[None, :, 2] < bb[:, None, 0])) & okb[:, None] & okb[None, :]
+        gone = np.zeros(len(order), dtype=bool)
         for a, p1 in enumerate(order):
-            if p1 in removed:
+            if gone[a]:
                 continue
-            for p2 in order[a + 1:]:
-                if p2 in removed:
-                    continue
-                if not bboxes_overlap(alg.bbox_of(idx[p1]), alg.bbox_of(idx[p2])):
-                    continue
-                if calculate_iou(alg, idx[p1], idx[p2]) > max_iou:
-                    removed.add(p2)
+            cand = np.nonzero(ov[a, a + 1:] & ~gone[a + 1:])[0] + a + 1
+            for b in cand:
+                if calculate_iou(alg, idx[p1], idx[order[b]]) > max_iou:
+                    gone[b] = True
+                    removed.add(order[b])
     return removed
 
 
@@ -123,25 +128,29 @@ def filter_by_containment_rules(alg, scores: Sequence[float], classes: Sequence[
             removed.update(by_class[child_class])
             continue
         parents = [p for p in by_class[parent_class] if p not in removed and alg.bbox_of(idx[p]) is not None]
+        children = by_class[child_class]
+        # child x parent box-overlap matrix once (numpy): the pairs the reference tests one by one
+        cb = np.asarray([alg.bbox[idx[c]] for c in children], dtype=np.int64).reshape(-1, 4)
+        pb = np.asarray([alg.bbox[idx[q]] for q in parents], dtype=np.int64).reshape(-1, 4)
+        ov = ~((cb[:, None, 3] < pb[None, :, 1]) | (pb[None, :, 3] < cb[:, None, 1]) |
+               (cb[:, None, 2] < pb[None, :, 0]) | (pb[None, :, 2] < cb[:, None, 0])) & (cb[:, 0] >= 0)[:, None]
         pi, pj = [], []
-        for ch in by_class[child_class]:
-            for p in parents:
-                if bboxes_overlap(alg.bbox_of(idx[ch]), alg.bbox_of(idx[p])) and (idx[ch], idx[p]) not in alg._cache:
-                    pi.append(idx[ch])
-                    pj.append(idx[p])
+        for a, b in zip(*np.nonzero(ov)):
+            if (idx[children[a]], idx[parents[b]]) not in alg._cache:
+                pi.append(idx[children[a]])
+                pj.append(idx[parents[b]])
         if pi:
             alg.intersections(pi, pj)
-        for ch in by_class[child_class]:
+        for a, ch in enumerate(children):
             if ch in removed:
                 continue
             if alg.bbox_of(idx[ch]) is None:
                 removed.add(ch)
                 continue
             max_containment = 0.0
-            for p in parents:
+            for b in np.nonzero(ov[a])[0]:
+                p = parents[b]
                 if p in removed:
-                    continue
-                if not bboxes_overlap(alg.bbox_of(idx[ch]), alg.bbox_of(idx[p])):
                     continue
                 c = calculate_containment(alg, idx[ch], idx[p])
                 if c > max_containment:

@@ -220,3 +220,28 @@ def test_tiles_and_edge_filter():
     big = np.zeros((128, 128), bool)
     big[2:5, 6:9] = True
     np.testing.assert_array_equal(P.resize_nearest(big, 64, 64), big[::2, ::2])
+
+
+def test_rle_from_bbox_crop_equals_full_frame_encoding():
+    """The CSV writer encodes every mask from its bounding-box crop (only those words leave the GPU); same runs as
+    the reference's full-frame, column-major encoding -- including runs that wrap from the last row of a column to
+    the first row of the next one."""
+    from deepemia_amd.utils.mask_utils import rle_encoding, rle_from_crop
+
+    rng = np.random.default_rng(0)
+    for t in range(200):
+        H, W = int(rng.integers(1, 40)), int(rng.integers(1, 50))
+        m = rng.random((H, W)) > rng.uniform(0.1, 0.9)
+        if t % 5 == 0:
+            m[:, :] = True
+        if t % 3 == 0:
+            m[0, :] = True
+            m[-1, :] = True
+        if t % 7 == 0:
+            m[:] = False
+        ys, xs = np.nonzero(m)
+        if len(ys) == 0:
+            assert rle_from_crop(m[:0, :0], 0, 0, H) == [] == rle_encoding(m)
+            continue
+        y0, y1, x0, x1 = ys.min(), ys.max(), xs.min(), xs.max()
+        assert rle_from_crop(m[y0:y1 + 1, x0:x1 + 1], int(y0), int(x0), H) == rle_encoding(m)

@@ -445,3 +445,19 @@ def test_one_border_many_walkers_equals_sequential_walk(ops):
             assert abs(recs[i][0]["perimeter"] - P.arc_length(ref[0])) <= 1e-9 * max(1.0, P.arc_length(ref[0]))
     finally:
         ops.set_frame_width(0)
+
+
+def test_rle_of_packed_masks_equals_reference_encoding(ops):
+    from deepemia_amd.utils.mask_utils import rle_encoding, rle_encoding_packed
+
+    h, w = 90, 150
+    rng = np.random.default_rng(2)
+    masks = _blobs(rng, 10, h, w, 30)
+    masks[2] = False
+    masks[3][:, 40:43] = True                # full-height columns: runs wrap from one column into the next
+    ops.set_frame_width(w)
+    try:
+        got = rle_encoding_packed(ops, ops.from_dense(masks), w)
+        assert got == [rle_encoding(m) for m in masks]
+    finally:
+        ops.set_frame_width(0)
