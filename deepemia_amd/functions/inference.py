@@ -33,8 +33,8 @@ from ..maskset import MaskOps
 from ..utils.config import get_config
 from ..utils.logger_utils import log_memory_usage, system_logger
 from ..utils.mask_algebra import DeviceMaskAlgebra
-from ..utils.mask_utils import (postprocess_masks_device, postprocess_masks_universal_device, process_masks_device,
-                                rle_encoding_packed)
+from ..utils.mask_utils import (mask_crops, postprocess_masks_device, postprocess_masks_universal_device,
+                                process_masks_device, rle_encoding_packed)
 from ..utils.spatial_constraints import apply_spatial_constraints_indices, load_spatial_constraints
 
 CSV_HEADER = ["Instance_ID", "Class", "Class_Name", "Major axis length", "Minor axis length", "Eccentricity", "C. Length",
@@ -824,19 +824,24 @@ def run_inference(dataset_name, output_dir, visualize=True, threshold=0.65, draw
     return dedup_results
 
 
-def write_predictions_png(path: str, image_bgr: np.ndarray, dense_masks: np.ndarray, classes: Sequence[int], contours, thing_classes) -> None:
+def write_predictions_png(path: str, image_bgr: np.ndarray, crops, classes: Sequence[int], contours, thing_classes) -> None:
     """``<img>_predictions.png`` (``inference.py:1080-1145``): per mask a 50 % colour overlay (``addWeighted(vis, 1, colour, .5)``),
     its external contours in the class colour, instance number and class name at the centroid.  Output formatting only --
-    drawn with Pillow (OpenCV's Hershey font / line rasteriser are not reproduced)."""
+    drawn with Pillow (OpenCV's Hershey font / line rasteriser are not reproduced).  ``crops`` = ``mask_crops(...)``: the
+    masks arrive as bounding-box crops, never as dense frames."""
     from PIL import Image, ImageDraw
 
     vis = image_bgr.astype(np.float32)
-    for m, cls in zip(dense_masks, classes):
+    for c, cls in zip(crops, classes):
+        if c is None:
+            continue
+        y0, x0, sub = c
         color = np.asarray(CLASS_COLORS[int(cls) % len(CLASS_COLORS)], dtype=np.float32)
-        vis[m] = np.clip(np.rint(vis[m] + 0.5 * color), 0, 255)
+        win = vis[y0:y0 + sub.shape[0], x0:x0 + sub.shape[1]]
+        win[sub] = np.clip(np.rint(win[sub] + 0.5 * color), 0, 255)
     im = Image.fromarray(vis.astype(np.uint8)[:, :, ::-1].copy())       # BGR -> RGB for Pillow
     draw = ImageDraw.Draw(im)
-    for i, (m, cls, recs) in enumerate(zip(dense_masks, classes, contours)):
+    for i, (c, cls, recs) in enumerate(zip(crops, classes, contours)):
         b, g, r = CLASS_COLORS[int(cls) % len(CLASS_COLORS)]
         for rec in recs:
             pts = [tuple(int(v) for v in p) for p in rec["points"]]
@@ -844,9 +849,9 @@ def write_predictions_png(path: str, image_bgr: np.ndarray, dense_masks: np.ndar
                 draw.line(pts + [pts[0]], fill=(r, g, b), width=1)
             elif pts:
                 draw.point(pts, fill=(r, g, b))
-        ys, xs = np.nonzero(m)
+        ys, xs = np.nonzero(c[2]) if c is not None else ((), ())
         if len(ys):
-            cx, cy = int(xs.sum() / len(xs)), int(ys.sum() / len(ys))
+            cx, cy = int((xs.sum() + c[1] * len(xs)) / len(xs)), int((ys.sum() + c[0] * len(ys)) / len(ys))
             cname = thing_classes[int(cls)] if int(cls) < len(thing_classes) else f"class_{int(cls)}"
             draw.text((cx, cy - 18), f"{i + 1}", fill=(255, 255, 255))
             draw.text((cx, cy + 6), cname, fill=(255, 255, 255))
@@ -876,7 +881,7 @@ def write_measurements(ops: MaskOps, dedup_results: Dict[str, dict], test_img_pa
             if visualize:
                 im = imread_bgr(os.path.join(test_img_path, test_img))
                 if im is not None:
-                    write_predictions_png(os.path.join(output_dir, f"{test_img}_predictions.png"), im, ops.to_dense(packed, wd),
+                    write_predictions_png(os.path.join(output_dir, f"{test_img}_predictions.png"), im, mask_crops(ops, packed),
                                           classes, recs, metadata.thing_classes)
             rows = []
             for instance_id, (cls, contours) in enumerate(zip(classes, recs), 1):

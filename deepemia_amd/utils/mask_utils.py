@@ -51,29 +51,36 @@ def rle_from_crop(sub: np.ndarray, y0: int, x0: int, H: int) -> List[int]:
     return out.tolist()
 
 
-def rle_encoding_packed(ops, packed: torch.Tensor, W: int) -> List[List[int]]:
-    """``rle_encoding`` of every packed device mask: only the bounding-box words cross PCIe (one crop launch)."""
+def mask_crops(ops, packed: torch.Tensor):
+    """Per packed device mask its bounding-box crop on the host: ``(y0, x0, bool[h, w])`` or ``None`` for an empty
+    mask.  Only the bounding-box words cross PCIe (one crop launch for the whole set)."""
     from .. import parallel
 
-    n, H = int(packed.shape[0]), int(packed.shape[1])
+    n = int(packed.shape[0])
     if n == 0:
         return []
     area, bbox = ops.area_bbox(packed)
     bb = bbox.cpu().numpy()
-    hdr, pay = parallel.encode_instance_table(packed, [0.0] * n, [0] * n, [0] * n, bb, area.cpu().numpy())
+    _, pay = parallel.encode_instance_table(packed, [0.0] * n, [0] * n, [0] * n, bb, area.cpu().numpy())
     pay = pay.cpu().numpy().view(np.uint32)
     off, out = 0, []
     for i in range(n):
         y0, x0, y1, x1 = (int(v) for v in bb[i])
         if y0 < 0:
-            out.append([])
+            out.append(None)
             continue
         rows, c0, cols = y1 - y0 + 1, x0 >> 5, (x1 >> 5) - (x0 >> 5) + 1
         words = pay[off: off + rows * cols].reshape(rows, cols)
         off += rows * cols
         bits = np.unpackbits(words.view(np.uint8), axis=1, bitorder="little")       # [rows, cols * 32]
-        out.append(rle_from_crop(bits[:, x0 - 32 * c0: x1 - 32 * c0 + 1], y0, x0, H))
+        out.append((y0, x0, bits[:, x0 - 32 * c0: x1 - 32 * c0 + 1].astype(bool)))
     return out
+
+
+def rle_encoding_packed(ops, packed: torch.Tensor, W: int) -> List[List[int]]:
+    """``rle_encoding`` of every packed device mask, from its bounding-box crop."""
+    H = int(packed.shape[1])
+    return [[] if c is None else rle_from_crop(c[2], c[0], c[1], H) for c in mask_crops(ops, packed)]
 
 
 def postprocess_masks_device(ops, packed: torch.Tensor, scores: np.ndarray, min_crys_size: Optional[int] = None,
