@@ -70,9 +70,13 @@ def imread_bgr(path: str) -> Optional[np.ndarray]:
 
     try:
         with Image.open(path) as im:
-            if im.mode in ("I;16", "I;16B", "I;16L", "I"):
+            if im.mode in ("I;16", "I;16B", "I;16L"):
+                # cv2.imread(IMREAD_COLOR) reduces 16-bit samples to 8 bits by 1/256 (convertTo: round half to even)
+                a = np.rint(np.asarray(im).astype(np.float64) / 256.0)
+                rgb = np.repeat(np.clip(a, 0, 255).astype(np.uint8)[:, :, None], 3, axis=2)
+            elif im.mode == "I":
                 a = np.asarray(im).astype(np.float64)
-                a = (a / 256.0) if a.max() > 255 else a
+                a = np.rint(a / 256.0) if a.max() > 255 else a
                 rgb = np.repeat(np.clip(a, 0, 255).astype(np.uint8)[:, :, None], 3, axis=2)
             else:
                 rgb = np.asarray(im.convert("RGB"))

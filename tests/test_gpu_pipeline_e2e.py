@@ -235,3 +235,41 @@ def test_tiles_sharded_over_two_ranks_equal_single_process(gpu_device, tmp_path)
             assert sa == sb and ca == cb
     assert out[1][1] < calls1                      # rank 1 ran fewer forwards (no full-image pass, half the tiles)
     assert sum(len(x[1]) for x in single) > 20
+
+
+def test_cli_edge_inputs_nothing_detected_grayscale_and_odd_sizes(tmp_path, monkeypatch, gpu_device):
+    """Edge inputs of the CLI path: a threshold nothing passes (header-only CSVs, no crash), an 8-bit grayscale PNG,
+    a 16-bit TIFF, and image sizes that are neither square nor multiples of 32 or of the tile size."""
+    import main as cli
+    from deepemia_amd import synth
+    from deepemia_amd.utils import config as C
+
+    tile = {"tile_size": 256, "overlap_ratio": 0.125, "upscale_factor": 1.0, "edge_filter_enabled": True}
+    ds_cfg = {"inference_overrides": {"confidence_mode": "manual",
+                                      "class_specific_settings": {"class_0": {"confidence_threshold": 0.3, "iou_threshold": 0.6, "min_size": 25},
+                                                                  "class_1": {"confidence_threshold": 0.35, "iou_threshold": 0.5, "min_size": 5}},
+                                      "tile_settings": tile, "spatial_constraints": {"enabled": False}}}
+    cfgdir, split, sds, images = _write_tree(tmp_path, [50], 0.5, 6.0, 0, 512, ds_cfg)
+    inf = tmp_path / "DATASET" / "INFERENCE"
+    base = synth.em_tile(77, 512)
+    Image.fromarray(base[:300, :417, 0]).save(inf / "gray_300x417.png")                       # mode L, odd size
+    Image.fromarray((base[:260, :500, 0].astype(np.uint16) << 8)).save(inf / "deep_260x500.tif")   # 16-bit
+    Image.fromarray(base[:200, :200, ::-1]).save(inf / "small_200.jpg")                           # smaller than a tile
+    monkeypatch.setenv("DEEPEMIA_CONFIG_DIR", str(cfgdir))
+    monkeypatch.setenv("DEEPEMIA_OFFLINE", "1")
+    monkeypatch.chdir(tmp_path)
+    for thr, expect_rows in (("0.3", True), ("0.999999", False)):
+        C.reset_cache()
+        assert cli.main(["--task", "inference", "--dataset_name", DATASET, "--threshold", thr, "--no-gpu-check"]) == 0
+        rows = list(csv.reader(open(split / "measurements_results.csv")))
+        rle = list(csv.reader(open(split / "R50_flip_results.csv")))
+        assert rle[0] == ["ImageId", "EncodedPixels"]
+        if expect_rows:
+            names = {r[19] for r in rows[1:]}
+            assert names == {"gray_300x417.png", "deep_260x500.tif", "small_200.jpg"}, names
+            assert len(rle) - 1 >= len({r[0] for r in rows[1:]}) > 0
+            for r in rows[1:]:
+                assert all(np.isfinite(float(r[c])) for c in NUMERIC)
+        else:
+            assert len(rows) == 1 and len(rle) == 1          # header only
+    C.reset_cache()
