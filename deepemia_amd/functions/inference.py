@@ -447,26 +447,17 @@ class InferencePipeline:
             out.append((packed, scores, classes, recs))
         return out
 
-    def _single_class_pass_batched(self, dets: Sequence[_Detections], target_class: int, small_classes, conf, iou_threshold):
-        """a6 + a9 + a11 + a12 for ONE class over MANY tiles with one launch per kernel: the masks of all tiles are
-        concatenated and carry a segment id (tile index); overlap removal and column counts are segment-aware, every
-        other kernel is per mask anyway.  Returns per tile (index tensor into the returned big tensor, scores)."""
-        T = len(dets)
+    def _gather_selected(self, dets: Sequence[_Detections], sels: Sequence[np.ndarray]):
+        """Our own copy of the selected masks of many detections sets (every later stage works on it in place) and
+        their bbox hints: ONE gather per run of sets that share a forward's table."""
         dev = self.dev
-        sels = []
-        for det in dets:
-            sel = np.nonzero(det.classes == target_class)[0]
-            sels.append(sel[det.scores[sel] >= conf])
         lens = [len(x) for x in sels]
-        empty = [([], []) for _ in range(T)]
-        if sum(lens) == 0:
-            return None, empty, None
-        # our own copy of the selected masks (every stage below works on it in place): ONE gather per forward table
+        T = len(dets)
         packed = torch.empty((sum(lens),) + tuple(dets[0].packed.shape[1:]), dtype=dets[0].packed.dtype, device=dev)
         bbox = torch.empty((sum(lens), 4), dtype=torch.int32, device=dev)
         have_hint, pos, t = True, 0, 0
         while t < T:
-            if dets[t].base is not None:                       # the run of tiles that share this forward's table
+            if dets[t].base is not None:                       # the run of sets that share this forward's table
                 t1 = t
                 while t1 < T and dets[t1].base is dets[t].base:
                     t1 += 1
@@ -489,6 +480,93 @@ class InferencePipeline:
                 t += 1
         if not have_hint:
             _, bbox = self.ops.area_bbox(packed)
+        return packed, bbox
+
+    def _ensemble_class_pass_batched(self, dets_per_model: Sequence[Sequence[_Detections]], target_class: int, small_classes,
+                                     conf, iou_threshold):
+        """a10 + a14 (``run_ensemble_inference``, ``inference.py:1464-1598``) for ONE class over MANY tiles: every model's
+        selected masks of every tile go through ONE stage program (fill -> erosion [-> dilation]), one contour trace and
+        one pair-count launch; the per-tile decisions (min size, compactness, smart dedup, N6 included) then run on the
+        host over integers exactly as the tile-by-tile version does.  Returns (big, per tile (kept indices, scores), alg)."""
+        T, dev = len(dets_per_model[0]), self.dev
+        is_small = target_class in small_classes
+        hw = dets_per_model[0][0].hw
+        area_img = hw[0] * hw[1]
+        min_size = max(3, int(area_img * 0.000005)) if is_small else max(25, int(area_img * 0.0001))
+        flat_dets, sels, owner, weights = [], [], [], []
+        for m, (dets, weight) in enumerate(zip(dets_per_model, self.ensemble_weights)):     # model-major: one gather per model
+            for t, det in enumerate(dets):
+                sel = np.nonzero((det.classes == target_class) & (det.scores >= conf))[0] if len(det.scores) else np.zeros((0,), dtype=np.int64)
+                flat_dets.append(det)
+                sels.append(sel)
+                owner.append((t, m))
+                weights.append(weight)
+        empty = [([], []) for _ in range(T)]
+        if sum(len(x) for x in sels) == 0:
+            return None, empty, None
+        packed, bbox = self._gather_selected(flat_dets, sels)
+        area, bbox, _ = self.ops.program_(packed, ["fill", "erode"] if is_small else ["fill", "erode", "dilate"], bbox)
+        alg = DeviceMaskAlgebra(self.ops, packed, area=area, bbox=bbox)
+        cset = self.ops.trace(packed, max_contours=256, bbox=alg._bbox_dev, total_area=int(alg.area.sum()))
+        per0 = cset.first_contour_perimeter()
+        # per tile, in the reference's order (model by model): survivors of the min-size rule with their weighted scores
+        tile_items: List[List[int]] = [[] for _ in range(T)]
+        tile_scores: List[List[float]] = [[] for _ in range(T)]
+        pos = 0
+        by_owner = {}
+        for (t, m), det, sel, wgt in zip(owner, flat_dets, sels, weights):
+            by_owner[(t, m)] = (pos, det, sel, wgt)
+            pos += len(sel)
+        for t in range(T):
+            for m in range(len(dets_per_model)):
+                p0, det, sel, wgt = by_owner[(t, m)]
+                for k in range(len(sel)):
+                    if alg.area[p0 + k] >= min_size:
+                        tile_items[t].append(p0 + k)
+                        tile_scores[t].append(float(det.scores[sel][k]) * wgt)
+        keep0_all, groups = [], []
+        for t in range(T):
+            k0 = []
+            for j, idx in enumerate(tile_items[t]):
+                if alg.bbox[idx, 0] < 0:
+                    continue
+                per = per0[idx]
+                if per > 0 and (4 * np.pi * int(alg.area[idx])) / (per ** 2) < 0.15:
+                    continue
+                k0.append(j)
+            keep0_all.append(k0)
+            if len(k0) > 1:
+                groups.append([tile_items[t][j] for j in k0])
+        alg.prefetch_overlapping_pairs(groups)
+        out = []
+        for t in range(T):
+            k0 = keep0_all[t]
+            if not k0:
+                out.append(([], []))
+                continue
+            gidx = [tile_items[t][j] for j in k0]
+            scores = [tile_scores[t][j] for j in k0]
+            classes = [target_class] * len(k0)
+            bb = [(int(alg.bbox[i, 0]), int(alg.bbox[i, 2]), int(alg.bbox[i, 1]), int(alg.bbox[i, 3])) for i in gidx]
+            keep = self._dedup_smart_order(alg, gidx, scores, classes, bb, iou_threshold)
+            out.append(([gidx[i] for i in keep], [scores[i] for i in keep]))
+        return packed, out, alg
+
+    def _single_class_pass_batched(self, dets: Sequence[_Detections], target_class: int, small_classes, conf, iou_threshold):
+        """a6 + a9 + a11 + a12 for ONE class over MANY tiles with one launch per kernel: the masks of all tiles are
+        concatenated and carry a segment id (tile index); overlap removal and column counts are segment-aware, every
+        other kernel is per mask anyway.  Returns per tile (index tensor into the returned big tensor, scores)."""
+        T = len(dets)
+        dev = self.dev
+        sels = []
+        for det in dets:
+            sel = np.nonzero(det.classes == target_class)[0]
+            sels.append(sel[det.scores[sel] >= conf])
+        lens = [len(x) for x in sels]
+        empty = [([], []) for _ in range(T)]
+        if sum(lens) == 0:
+            return None, empty, None
+        packed, bbox = self._gather_selected(dets, sels)
         is_small = target_class in small_classes
         min_size = self.class_specific_settings.get(f"class_{target_class}", {}).get("min_size", 5 if is_small else 25)
         seg_np = np.repeat(np.arange(T, dtype=np.int32), lens)
@@ -587,9 +665,11 @@ class InferencePipeline:
         contour measurements (a17, a18).  Every kernel is launched ONCE for all tiles (segment-aware where the
         reference's loop carries state), so 256 CUs see hundreds of masks per launch instead of a few dozen.
         Same results as :meth:`process_tile_batch_unbatched`.  Returns per tile ``(packed, scores, classes, records)``."""
-        if len(model_ids) > 1:
-            return self.process_tile_batch_unbatched(key, tiles, small_classes, class_thresholds, spatial_cfg, um_pix, model_ids)
-        if dets is None:
+        ensemble = len(model_ids) > 1
+        if ensemble:
+            dets_per_model = [self._predict_batch(m, key, tiles) for m in model_ids]
+            dets = dets_per_model[0]
+        elif dets is None:
             dets = self._predict_batch(model_ids[0], key, tiles)
         self.ops.set_frame_width(int(tiles.shape[2]))
         T, dev = len(dets), self.dev
@@ -597,7 +677,10 @@ class InferencePipeline:
         # storage; every tile keeps its own index list in the reference's order: class by class, score order inside)
         passes = []
         for cls, (conf, iou_thr) in class_thresholds.items():
-            big, res, calg = self._single_class_pass_batched(dets, cls, small_classes, conf, iou_thr)
+            if ensemble:
+                big, res, calg = self._ensemble_class_pass_batched(dets_per_model, cls, small_classes, conf, iou_thr)
+            else:
+                big, res, calg = self._single_class_pass_batched(dets, cls, small_classes, conf, iou_thr)
             if big is not None and any(len(k) for k, _ in res):
                 passes.append((cls, big, res, calg))
         out = [(None, [], [], []) for _ in range(T)]

@@ -154,21 +154,26 @@ def test_cli_inference_matches_oracle_pipeline(case, tmp_path, monkeypatch, gpu_
     _compare(split, images, ref_rows, ref_masks)
 
 
-def test_batched_tile_pipeline_equals_tile_by_tile(gpu_device):
+@pytest.mark.parametrize("models", ["single_r50", "ensemble_r50_r101"])
+def test_batched_tile_pipeline_equals_tile_by_tile(gpu_device, models):
     """process_tile_batch launches every kernel once for all tiles (segment-aware); it must give exactly what the
-    reference-shaped tile-by-tile, class-by-class loop gives -- at the full 2048^2 tile size of BASELINE configs[1]."""
+    reference-shaped tile-by-tile, class-by-class loop gives -- at the full 2048^2 tile size of BASELINE configs[1];
+    single model (configs[1]) and the R50 + R101 ensemble (configs[3])."""
     from deepemia_amd import synth
     from deepemia_amd.engine import MaskRCNNEngine
     from deepemia_amd.functions.inference import InferencePipeline
     from deepemia_amd.predictor import Predictor
 
-    sd = synth.random_d2_state_dict(50, 2, seed=0, mask_bias=0.5, mask_gain=6.0)
-    pipe = InferencePipeline([Predictor(MaskRCNNEngine(sd, 50, 2, 0.3, gpu_device, "f32"))], "t", {}, {})
+    depths = (50,) if models == "single_r50" else (50, 101)
+    preds = [Predictor(MaskRCNNEngine(synth.random_d2_state_dict(d, 2, seed=0, mask_bias=0.5, mask_gain=6.0), d, 2, 0.3, gpu_device, "f32"))
+             for d in depths]
+    pipe = InferencePipeline(preds, "t", {}, {})
     x = torch.from_numpy(np.stack([synth.em_tile(60 + i, 2048) for i in range(3)])).to(gpu_device)
     thr = {0: (0.3, 0.7), 1: (0.35, 0.5)}
     spatial = {"enabled": True, "containment_rules": {}, "overlap_rules": {0: {"allow_overlap": False, "max_iou_threshold": 0.3}}}
-    a = pipe.process_tile_batch("k", x, {1}, thr, spatial_cfg=spatial, um_pix=0.5)
-    b = pipe.process_tile_batch_unbatched("k", x, {1}, thr, spatial_cfg=spatial, um_pix=0.5)
+    mids = tuple(range(len(depths)))
+    a = pipe.process_tile_batch("k", x, {1}, thr, spatial_cfg=spatial, um_pix=0.5, model_ids=mids)
+    b = pipe.process_tile_batch_unbatched("k", x, {1}, thr, spatial_cfg=spatial, um_pix=0.5, model_ids=mids)
     assert len(a) == len(b) == 3
     total = 0
     for (pa, sa, ca, ra), (pb, sb, cb, rb) in zip(a, b):
