@@ -354,27 +354,39 @@ class InferencePipeline:
             tile_dets = [self._predict_batch(m, f"{image_key}|tiles{tile_size}/{overlap_ratio}/{upscale_factor}/{rank}of{world}", my_tiles)
                          for m in model_ids]
         edge = int(tile_size * overlap_ratio / 2)
-        for k, t in enumerate(mine):
-            x_off, y_off = offs[t]
-            tm, ts, tc = class_pass([d[k] for d in tile_dets])
-            if tm is None or isinstance(tm, str) or tm.shape[0] == 0:
-                continue
-            n = int(tm.shape[0])
-            small = self.ops.place_tiles(tm, [0] * n, [0] * n, tile_size, tile_size, tile_size, tile_size)
-            keep = list(range(n))
-            if edge_filter_enabled:
-                _, bb = self.ops.area_bbox(small)
-                bb = bb.cpu().numpy()
-                keep = [i for i in range(n) if not (bb[i, 0] < 0 or bb[i, 0] < edge or bb[i, 2] > tile_size - edge
-                                                    or bb[i, 1] < edge or bb[i, 3] > tile_size - edge)]
-            if not keep:
-                continue
-            sel = torch.tensor(keep, dtype=torch.long, device=self.dev)
-            glob = self.ops.place_tiles(small[sel].contiguous(), [x_off] * len(keep), [y_off] * len(keep), tile_size, tile_size, h, w)
-            tile_masks.append(glob)
-            tile_scores.extend(ts[i] for i in keep)
-            tile_classes.extend(tc[i] for i in keep)
-            tile_units.extend([1 + t] * len(keep))
+        if mine:
+            # a6 + a9..a12 (or a10 + a14) for ALL of this rank's tiles with one launch per kernel, then a13 likewise: one
+            # nearest-resize launch to tile scale, one bbox reduction for the edge test, one paste into the global frame
+            if ensemble:
+                big, res, _ = self._ensemble_class_pass_batched(tile_dets, target_class, small_classes, confidence_threshold, iou_threshold)
+            else:
+                big, res, _ = self._single_class_pass_batched(tile_dets[0], target_class, small_classes, confidence_threshold, iou_threshold)
+            src, xo, yo, un, sc_all = [], [], [], [], []
+            for k, t in enumerate(mine):
+                kept, sc = res[k]
+                src.extend(kept)
+                xo.extend([offs[t][0]] * len(kept))
+                yo.extend([offs[t][1]] * len(kept))
+                un.extend([1 + t] * len(kept))
+                sc_all.extend(sc)
+            if src:
+                n = len(src)
+                tm = big[torch.tensor(src, dtype=torch.long, device=self.dev)].contiguous()
+                small = self.ops.place_tiles(tm, [0] * n, [0] * n, tile_size, tile_size, tile_size, tile_size)
+                keep = list(range(n))
+                if edge_filter_enabled:
+                    _, bb = self.ops.area_bbox(small)
+                    bb = bb.cpu().numpy()
+                    keep = [i for i in range(n) if not (bb[i, 0] < 0 or bb[i, 0] < edge or bb[i, 2] > tile_size - edge
+                                                        or bb[i, 1] < edge or bb[i, 3] > tile_size - edge)]
+                if keep:
+                    sel = torch.tensor(keep, dtype=torch.long, device=self.dev)
+                    glob = self.ops.place_tiles(small[sel].contiguous(), [xo[i] for i in keep], [yo[i] for i in keep],
+                                                tile_size, tile_size, h, w)
+                    tile_masks.append(glob)
+                    tile_scores.extend(sc_all[i] for i in keep)
+                    tile_classes.extend([target_class] * len(keep))
+                    tile_units.extend(un[i] for i in keep)
         if world > 1:
             # the ONE exchange of the path: every rank receives every rank's instance table, ordered by unit id
             empty_full = isinstance(full_masks, str)
@@ -822,15 +834,30 @@ def run_inference(dataset_name, output_dir, visualize=True, threshold=0.65, draw
     dev = pipe.dev
     spatial_cfg = load_spatial_constraints(dataset_name)
 
+    # decode on a helper thread, one image ahead of the GPU work (the reference preloads with a thread pool too,
+    # inference.py:150-166); the first <= 5 decoded images are kept for the small-class statistics and reused
+    from concurrent.futures import ThreadPoolExecutor
+
+    decoder = ThreadPoolExecutor(max_workers=2)
+    decoded: Dict[str, object] = {}
+
+    def prefetch(name):
+        if name not in decoded:
+            decoded[name] = decoder.submit(imread_bgr, os.path.join(inpath, name))
+
     def load(name):
-        img = imread_bgr(os.path.join(inpath, name))
+        prefetch(name)
+        img = decoded.pop(name).result()
         return None if img is None else torch.from_numpy(img).to(dev)
 
+    for name in images_name[:6]:
+        prefetch(name)
     sample = []
     for name in images_name[:5]:
         t = load(name)
         if t is not None:
             sample.append((name, t))
+    sample_dev = dict(sample)          # the first images are already on the device: no second decode
     small_classes = determine_small_classes(pipe.calculate_average_mask_sizes(sample), 50)
     system_logger.info(f"Small classes: {sorted(small_classes)}")
 
@@ -841,7 +868,10 @@ def run_inference(dataset_name, output_dir, visualize=True, threshold=0.65, draw
     for gi, name in enumerate(images_name):
         t0 = time.perf_counter()
         log_memory_usage(f"Before image {gi + 1}/{len(images_name)}: {name}")
-        image_dev = load(name)
+        for nxt in images_name[gi + 1: gi + 3]:
+            if nxt not in sample_dev:
+                prefetch(nxt)
+        image_dev = sample_dev.pop(name) if name in sample_dev else load(name)
         if image_dev is None:
             system_logger.warning(f"Could not load image: {name}")
             continue
@@ -889,6 +919,7 @@ def run_inference(dataset_name, output_dir, visualize=True, threshold=0.65, draw
         finally:
             pipe.clear_cache()
             log_memory_usage(f"After image {gi + 1}/{len(images_name)}: {name}")
+    decoder.shutdown(wait=False)
     total = time.perf_counter() - t_all
     system_logger.info(f"Inference complete: {len(processed)}/{len(images_name)} images, avg "
                        f"{total / max(len(images_name), 1):.2f}s/image, {pipe.forward_calls} batched forwards")
