@@ -7,13 +7,15 @@
 //            -> int truncation -> imutils order_points -> mid-point distances; fitEllipse
 //            (algebraic least squares); the 12 derived values of the CSV row.
 //
-// Parallel decomposition (order/compare work, latency-bound): a border can only start at a pixel
-// whose west, north-west, north and north-east neighbours are background; every such pixel that also
-// has TRUE outside background to its west (not a hole of the filled mask) is traced by one lane with
-// Suzuki-Abe's 8-neighbour rule, and the trace is kept iff it never meets a pixel that precedes its
-// start in raster order -- i.e. iff the start is the component's first pixel, which is where OpenCV's
-// sequential raster scan starts the same border.  Pass A validates and reduces (area, perimeter,
-// point count), pass B writes the SIMPLE points at an atomically reserved offset.
+// Parallel decomposition (order/compare work, latency-bound).  The usual instance mask -- one component, no holes
+// (hole test + Euler number, maskregion.h) -- has ONE border: up to 64 walkers start on the flanks of evenly spaced
+// rows and each walks to the next walker's start state; stitched in cycle order from the raster-first pixel this is
+// OpenCV's sequential walk point for point.  Any other mask: a border can only start at a pixel whose west,
+// north-west, north and north-east neighbours are background; every such pixel that also has TRUE outside background
+// to its west (not a hole) is traced by one lane with Suzuki-Abe's 8-neighbour rule, and the trace is kept iff it
+// never meets a pixel that precedes its start in raster order -- i.e. iff the start is the component's first pixel,
+// which is where OpenCV's raster scan starts the same border; valid traces are walked again to emit their points.
+// Measurements: one wave per contour (rank sort + Jacobi least squares over the lanes).
 // Compiled with -ffp-contract=off: the f32 calipers follow OpenCV's operation order.
 #include "common.h"
 #include "maskregion.h"
@@ -407,8 +409,6 @@ __global__ __launch_bounds__(256) void contour_trace_kernel(const ContourP p) {
 // =============================================================================================
 // measurements: one wave per contour
 // =============================================================================================
-struct Pt { int x, y; };
-
 __device__ __forceinline__ bool pt_less(const int* pts, int a, int b) {
     const int ax = pts[2 * a], ay = pts[2 * a + 1], bx = pts[2 * b], by = pts[2 * b + 1];
     if (ax != bx) return ax < bx;
@@ -652,59 +652,6 @@ __device__ void svd_lstsq(double* A, int n, const double* bvec, double bconst, d
         const double f = utb[j] / (w[j] * w[j]);   // (u_j . b) / w_j, with u_j = a_j / w_j
         for (int i = 0; i < K; ++i) x[i] += f * V[i][j];
     }
-}
-
-// cv::fitEllipse (fitEllipseNoDirect): returns width <= height.  Ad: scratch of 5 * n doubles
-__device__ void fit_ellipse(const int* pts, int n, double* Ad, float* bw, float* bh) {
-    float csx = 0.f, csy = 0.f;
-    for (int i = 0; i < n; ++i) { csx += (float)pts[2 * i]; csy += (float)pts[2 * i + 1]; }
-    const float cx = csx / (float)n, cy = csy / (float)n;
-    double s = 0;
-    for (int i = 0; i < n; ++i) s += fabs((double)((float)pts[2 * i] - cx)) + fabs((double)((float)pts[2 * i + 1] - cy));
-    const double eps32 = 1.1920928955078125e-07;
-    const double scale = 100.0 / (s > eps32 ? s : eps32);
-    double gfp[5], wmax, wmin;
-    float eps = 0.f;
-    int attempt = 0;
-    auto point = [&](int i, double& px, double& py) {
-        float fxp = (float)pts[2 * i], fyp = (float)pts[2 * i + 1];
-        if (attempt) { fxp = fxp + (float)((i & 1) * 2 - 1) * eps; fyp = fyp + (float)((i & 2) - 1) * eps; }
-        px = (double)(fxp - cx) * scale; py = (double)(fyp - cy) * scale;
-    };
-    for (;; ++attempt) {
-        for (int i = 0; i < n; ++i) {
-            double px, py;
-            point(i, px, py);
-            Ad[i * 5 + 0] = -px * px; Ad[i * 5 + 1] = -py * py; Ad[i * 5 + 2] = -px * py; Ad[i * 5 + 3] = px; Ad[i * 5 + 4] = py;
-        }
-        svd_lstsq<5>(Ad, n, nullptr, 10000.0, gfp, &wmax, &wmin);
-        if (attempt == 1 || !(wmax * eps32 > wmin)) break;
-        eps = (float)(s / (n * 2) * 1e-3);
-    }
-    double rp[5];
-    {
-        double m2[4] = {2 * gfp[0], gfp[2], gfp[2], 2 * gfp[1]}, b2[2] = {gfp[3], gfp[4]}, c2[2], a, b;
-        svd_lstsq<2>(m2, 2, b2, 0.0, c2, &a, &b);
-        rp[0] = c2[0]; rp[1] = c2[1];
-    }
-    double g[3];
-    for (int i = 0; i < n; ++i) {
-        double px, py;
-        point(i, px, py);
-        Ad[i * 3 + 0] = (px - rp[0]) * (px - rp[0]); Ad[i * 3 + 1] = (py - rp[1]) * (py - rp[1]); Ad[i * 3 + 2] = (px - rp[0]) * (py - rp[1]);
-    }
-    svd_lstsq<3>(Ad, n, nullptr, 1.0, g, &wmax, &wmin);
-    rp[4] = -0.5 * atan2(g[2], g[1] - g[0]);
-    double t;
-    if (fabs(g[2]) > 1e-8) t = g[2] / sin(-2.0 * rp[4]);
-    else t = g[1] - g[0];
-    rp[2] = fabs(g[0] + g[1] - t);
-    if (rp[2] > 1e-8) rp[2] = sqrt(2.0 / rp[2]);
-    rp[3] = fabs(g[0] + g[1] + t);
-    if (rp[3] > 1e-8) rp[3] = sqrt(2.0 / rp[3]);
-    float w = (float)(rp[2] * 2 / scale), h = (float)(rp[3] * 2 / scale);
-    if (w > h) { const float tt = w; w = h; h = tt; }
-    *bw = w; *bh = h;
 }
 
 __device__ __forceinline__ double wave_sum(double v) {
