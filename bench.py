@@ -86,6 +86,11 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(16, ncpu // max(world, 1))))      # N ranks share the host: no oversubscription
     # rehearsal of the N > 1 path on a one-GPU box: DEEPEMIA_BENCH_BACKEND=gloo DEEPEMIA_BENCH_ONE_DEVICE=1 (all ranks on cuda:0)
     backend = os.environ.get("DEEPEMIA_BENCH_BACKEND", "nccl")
     one_dev = os.environ.get("DEEPEMIA_BENCH_ONE_DEVICE", "0") == "1"
