@@ -13,7 +13,7 @@ from pathlib import Path
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "csrc" / "libdeepemia_hip.so"
 
-F32, BF16, F32X3 = 0, 1, 2
+F32, BF16, F32X3, BF16X2 = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 RES_NONE, RES_SAME, RES_UP2 = 0, 1, 2
 # stage codes of demia_mask_program (DEMIA_MOP_*)

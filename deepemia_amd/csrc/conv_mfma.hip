@@ -320,15 +320,18 @@ __device__ __forceinline__ f32x16 mma_bf16(const uint4& a, const uint4& b, f32x1
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&a), *reinterpret_cast<const bf16x8*>(&b), c, 0, 0, 0);
 }
 
-template <typename TO, int WM, int WN, int TM, int TN>
+// NP = 3: "f32x3" as above.  NP = 2 ("bf16x2"): two planes and the three products a1b1, a1b2, a2b1 -- 16 significand
+// bits per operand, dropped terms <= 3 * 2^-16 |ab|: 256 x less exact than f32, 256 x more exact than plain bf16, at half
+// the matrix work of f32x3 (an opt-in speed mode; the default stays f32x3).
+template <typename TO, int WM, int WN, int TM, int TN, int NP = 3>
 __global__ __launch_bounds__(256) void conv_igemm_split_kernel(const ConvP p) {
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
     constexpr int BK = 32;
     constexpr int AV = BM / 32;                 // f32 vectors (4 elements) of A per thread per K-step
-    constexpr int BVT = 3 * BN / 64;            // 16-B bf16 vectors (8 elements) of the B planes per thread per K-step
+    constexpr int BVT = NP * BN / 64;           // 16-B bf16 vectors (8 elements) of the B planes per thread per K-step
     constexpr int PLANE_A = BM * ROWS3, PLANE_B = BN * ROWS3;
-    static_assert((3 * BN) % 64 == 0, "BN must be a multiple of 64 / 3");
+    static_assert((NP * BN) % 64 == 0, "NP * BN must be a multiple of 64");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -368,7 +371,7 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(const ConvP p) {
         const int co = n0 + row;
         b_vm[j] = co < p.CoutPad;
         b_off[j] = plane * plane_stride + (long)(b_vm[j] ? co : 0) * Ktot + c8 * 8;
-        b_lds[j] = 3 * PLANE_A + plane * PLANE_B + row * ROWS3 + c8 * 16;
+        b_lds[j] = NP * PLANE_A + plane * PLANE_B + row * ROWS3 + c8 * 16;
     }
 
     // ONE LDS stage (61 KiB for 128x128) so that TWO workgroups share a CU: while one is in its barrier / split /
@@ -401,7 +404,7 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(const ConvP p) {
             char* dst = smem + (lrow + 32 * i) * ROWS3 + chunk * 8;
             *reinterpret_cast<bf16x4*>(dst) = h;
             *reinterpret_cast<bf16x4*>(dst + PLANE_A) = m;
-            *reinterpret_cast<bf16x4*>(dst + 2 * PLANE_A) = l;
+            if (NP == 3) *reinterpret_cast<bf16x4*>(dst + 2 * PLANE_A) = l;
         }
 #pragma unroll
         for (int j = 0; j < BVT; ++j) *reinterpret_cast<uint4*>(smem + b_lds[j]) = rb[j];
@@ -418,7 +421,7 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(const ConvP p) {
     const int frag_off = (lane & 31) * ROWS3 + (lane >> 5) * 16;
     const int a_row0 = wm * TM * 32, b_row0 = wn * TN * 32;
     const char* sA = smem + a_row0 * ROWS3 + frag_off;
-    const char* sB = smem + 3 * PLANE_A + b_row0 * ROWS3 + frag_off;
+    const char* sB = smem + NP * PLANE_A + b_row0 * ROWS3 + frag_off;
 
     load_step();
     store_step();
@@ -428,9 +431,9 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(const ConvP p) {
         if (more) load_step();
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            uint4 fa[3][TM], fb[3][TN];
+            uint4 fa[NP][TM], fb[NP][TN];
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
+            for (int q = 0; q < NP; ++q) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) fa[q][i] = *reinterpret_cast<const uint4*>(sA + q * PLANE_A + i * 32 * ROWS3 + kk * 32);
 #pragma unroll
@@ -441,9 +444,11 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(const ConvP p) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     f32x16 c = acc[i][j];
-                    c = mma_bf16(fa[0][i], fb[2][j], c);   // smallest terms first
-                    c = mma_bf16(fa[1][i], fb[1][j], c);
-                    c = mma_bf16(fa[2][i], fb[0][j], c);
+                    if (NP == 3) {
+                        c = mma_bf16(fa[0][i], fb[NP - 1][j], c);   // smallest terms first
+                        c = mma_bf16(fa[1][i], fb[1][j], c);
+                        c = mma_bf16(fa[NP - 1][i], fb[0][j], c);
+                    }
                     c = mma_bf16(fa[0][i], fb[1][j], c);
                     c = mma_bf16(fa[1][i], fb[0][j], c);
                     c = mma_bf16(fa[0][i], fb[0][j], c);
@@ -457,14 +462,14 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(const ConvP p) {
     conv_epilogue<TO, BM, BN, TM, TN>(p, smem, acc, a_row0, b_row0, m0, n0);
 }
 
-template <typename TO, int WM, int WN, int TM, int TN>
+template <typename TO, int WM, int WN, int TM, int TN, int NP = 3>
 int launch_split_cfg(ConvP p, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int stage = 3 * (BM + BN) * ROWS3, epi = BM * (BN * 4 + 16);
+    constexpr int stage = NP * (BM + BN) * ROWS3, epi = BM * (BN * 4 + 16);
     constexpr int smem = stage > epi ? stage : epi;      // one tile stage, re-used by the epilogue
     p.ntn = cdiv(p.CoutPad, BN);
     p.nwg = p.ntn * cdiv(p.M, BM);
-    auto k = conv_igemm_split_kernel<TO, WM, WN, TM, TN>;
+    auto k = conv_igemm_split_kernel<TO, WM, WN, TM, TN, NP>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -510,10 +515,11 @@ int launch_typed(ConvP p, int bn, hipStream_t st) {
 
 extern "C" int demia_conv2d_nhwc(const demia_conv_desc* d, void* stream) {
     DEMIA_REQUIRE(d && d->in && d->w && d->out, "null pointer");
-    DEMIA_REQUIRE(d->dtype == DEMIA_F32 || d->dtype == DEMIA_BF16 || d->dtype == DEMIA_F32X3, "dtype");
+    DEMIA_REQUIRE(d->dtype == DEMIA_F32 || d->dtype == DEMIA_BF16 || d->dtype == DEMIA_F32X3 || d->dtype == DEMIA_BF16X2, "dtype");
     DEMIA_REQUIRE(d->out_dtype == DEMIA_F32 || d->out_dtype == DEMIA_BF16, "out_dtype");
     const int bk = d->dtype == DEMIA_BF16 ? 64 : 32;
-    DEMIA_REQUIRE(d->dtype != DEMIA_F32X3 || (d->CoutPad % 64 == 0 && d->out_dtype == DEMIA_F32), "f32x3 needs CoutPad % 64 == 0, f32 output");
+    DEMIA_REQUIRE((d->dtype != DEMIA_F32X3 && d->dtype != DEMIA_BF16X2) || (d->CoutPad % 64 == 0 && d->out_dtype == DEMIA_F32),
+                  "f32x3 / bf16x2 need CoutPad % 64 == 0, f32 output");
     DEMIA_REQUIRE(d->Cin > 0 && d->Cin % bk == 0, "Cin must be a multiple of 64 (bf16) / 32 (f32)");
     DEMIA_REQUIRE(d->CoutPad >= d->Cout && d->CoutPad % 32 == 0, "CoutPad");
     DEMIA_REQUIRE(d->KH > 0 && d->KW > 0 && d->stride > 0 && d->pad >= 0, "kernel geometry");
@@ -538,6 +544,12 @@ extern "C" int demia_conv2d_nhwc(const demia_conv_desc* d, void* stream) {
     int bn = d->tile_hint;
     if (bn != 128 && bn != 64 && bn != 32) bn = d->CoutPad >= 128 ? 128 : (d->CoutPad >= 64 ? 64 : 32);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (d->dtype == DEMIA_BF16X2) {
+        if (d->CoutPad % 128 != 0) return launch_split_cfg<float, 4, 1, 1, 2, 2>(p, st);
+        const long blocks128 = (long)cdiv(p.M, 128) * cdiv(p.CoutPad, 128);
+        if (blocks128 < 1300) return launch_split_cfg<float, 2, 2, 1, 2, 2>(p, st);
+        return launch_split_cfg<float, 2, 2, 2, 2, 2>(p, st);
+    }
     if (d->dtype == DEMIA_F32X3) {
         if (d->CoutPad % 128 != 0) return launch_split_cfg<float, 4, 1, 1, 2>(p, st);            // 128 x 64
         const long blocks128 = (long)cdiv(p.M, 128) * cdiv(p.CoutPad, 128);

@@ -26,7 +26,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, BF16, F32, F32X3, RES_NONE, RES_SAME, RES_UP2
+from ._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, BF16, BF16X2, F32, F32X3, RES_NONE, RES_SAME, RES_UP2
 
 RES_BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}
 PIXEL_MEAN = (103.530, 116.280, 123.675)
@@ -147,7 +147,7 @@ class ConvLayer:
     kw: int
     stride: int
     pad: int
-    w3: Optional[torch.Tensor] = None   # f32x3 mode: the three bf16 planes of w, [3, CoutPad, KH, KW, Cin]
+    w3: Optional[torch.Tensor] = None   # f32x3 / bf16x2 mode: the three / two bf16 planes of w, [NP, CoutPad, KH, KW, Cin]
 
 
 @dataclass
@@ -177,8 +177,9 @@ class MaskRCNNEngine:
         self.score_thresh = float(score_thresh)
         self.device = torch.device(device)
         self.precision = precision
-        if precision not in ("f32", "f32x3", "bf16"):
-            raise ValueError("precision must be 'f32' (exact-f32 MFMA), 'f32x3' (f32 on the bf16 pipe, 3-way split) or 'bf16'")
+        if precision not in ("f32", "f32x3", "bf16x2", "bf16"):
+            raise ValueError("precision must be 'f32' (exact-f32 MFMA), 'f32x3' (f32 on the bf16 pipe, 3-way split), "
+                             "'bf16x2' (16-bit operands on the bf16 pipe, 2-way split) or 'bf16'")
         self.dt = BF16 if precision == "bf16" else F32
         self.tdt = torch.bfloat16 if precision == "bf16" else torch.float32
         self._tables: Dict[Tuple[int, int], dict] = {}
@@ -213,8 +214,9 @@ class MaskRCNNEngine:
             b = self._get(sd, prefix + ".bias") if bias_t is None else bias_t
         dev = self.device
         w3 = None
-        if self.precision == "f32x3" and cout_pad % 64 == 0 and cin % 32 == 0:
-            w3 = split3_bf16(wp.to(dev)).contiguous()          # split on the device: same round-to-nearest casts
+        if self.precision in ("f32x3", "bf16x2") and cout_pad % 64 == 0 and cin % 32 == 0:
+            w3 = split3_bf16(wp.to(dev))                       # split on the device: same round-to-nearest casts
+            w3 = (w3 if self.precision == "f32x3" else w3[:2]).contiguous()
         return ConvLayer(wp.to(dev, self.tdt).contiguous(),
                          None if scale is None else scale.to(dev).contiguous(),
                          None if b is None else b.to(dev).contiguous(), cin, cout, cout_pad, kh, kw, stride, pad, w3)
@@ -292,7 +294,8 @@ class MaskRCNNEngine:
         use3 = L.w3 is not None and odt == torch.float32
         d = _lib.ConvDesc(_lib.ptr(x), _lib.ptr(L.w3 if use3 else L.w), _lib.ptr(L.scale), _lib.ptr(L.bias), _lib.ptr(residual),
                           _lib.ptr(out), n, h, w, cin, ho, wo, L.cout, L.cout_pad, L.kh, L.kw, L.stride, L.pad,
-                          F32X3 if use3 else self.dt, BF16 if odt == torch.bfloat16 else F32, act, res_mode, ld, tile_hint)
+                          (F32X3 if L.w3.shape[0] == 3 else BF16X2) if use3 else self.dt, BF16 if odt == torch.bfloat16 else F32,
+                          act, res_mode, ld, tile_hint)
         ev = self.conv_events
         if ev is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -302,10 +305,10 @@ class MaskRCNNEngine:
             e1.record(torch.cuda.current_stream(self.device))
             esz = 2 if self.dt == BF16 else 4
             osz = 2 if odt == torch.bfloat16 else 4
-            nbytes = (n * h * w * cin * esz + L.cout_pad * L.kh * L.kw * cin * (6 if use3 else esz) + n * ho * wo * L.cout * osz +
+            nbytes = (n * h * w * cin * esz + L.cout_pad * L.kh * L.kw * cin * (2 * int(L.w3.shape[0]) if use3 else esz) + n * ho * wo * L.cout * osz +
                       (0 if residual is None else residual.numel() * osz))     # every operand once: the algorithmic traffic
             ev.append((e0, e1, 2.0 * n * ho * wo * L.cout * L.kh * L.kw * cin,
-                       "f32x3" if use3 else ("bf16" if self.dt == BF16 else "f32"), nbytes))
+                       ("f32x3" if L.w3.shape[0] == 3 else "bf16x2") if use3 else ("bf16" if self.dt == BF16 else "f32"), nbytes))
         return out
 
     def _resize_tables(self, h: int, w: int):

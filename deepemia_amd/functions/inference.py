@@ -614,8 +614,9 @@ class InferencePipeline:
             area, bbox, _ = self.ops.program_(packed, ["drop_multi"], bbox)
         closed = packed
         thr = 0.5 if is_small else iou_threshold
-        alg = DeviceMaskAlgebra(self.ops, closed, area=area, bbox=bbox)
         bounds = np.concatenate(([0], np.cumsum(new_lens)))
+        alg = DeviceMaskAlgebra(self.ops, closed, area=area, bbox=bbox,
+                                blocks=[np.arange(bounds[t], bounds[t + 1]) for t in range(T)])
         alg.prefetch_overlapping_pairs([list(range(bounds[t], bounds[t + 1])) for t in range(T) if new_lens[t] > 1])
         out = []
         for t in range(T):
@@ -718,7 +719,7 @@ class InferencePipeline:
         # ---- cross-class dedup (a14) for all tiles: one contour launch, one pair-count launch -------------------
         area_all = np.concatenate(area_parts)
         bbox_all = np.concatenate(bbox_parts)
-        alg = DeviceMaskAlgebra(self.ops, allp, area=area_all, bbox=bbox_all)
+        alg = DeviceMaskAlgebra(self.ops, allp, area=area_all, bbox=bbox_all, blocks=tile_items)
         # traced ONCE: reused for the final measurements
         cset = self.ops.trace(allp, max_contours=256, bbox=alg._bbox_dev, total_area=int(area_all.sum()))
         per0 = cset.first_contour_perimeter()

@@ -19,9 +19,11 @@ def _overlap(b1, b2) -> bool:
 
 
 class DeviceMaskAlgebra:
-    def __init__(self, ops, packed: torch.Tensor, area=None, bbox=None):
+    def __init__(self, ops, packed: torch.Tensor, area=None, bbox=None, blocks=None):
         """``area`` / ``bbox`` (device tensors or host arrays): the exact pixel counts and tight boxes when an earlier
-        kernel has already reduced them (``MaskOps.program_`` does) -- otherwise one ``demia_mask_area_bbox`` launch."""
+        kernel has already reduced them (``MaskOps.program_`` does) -- otherwise one ``demia_mask_area_bbox`` launch.
+        ``blocks``: index arrays (e.g. the masks of one tile each); pairs are only ever asked for INSIDE a block, so the
+        box-disjointness table is built block by block (16 x 100^2 instead of 1600^2 entries for a 16-tile batch)."""
         self.ops = ops
         self.packed = packed
         self.n = int(packed.shape[0])
@@ -43,16 +45,20 @@ class DeviceMaskAlgebra:
         # dense view for the vectorised greedy loops: I[i, j] = |mask_i & mask_j| where known (pairs whose
         # boxes cannot overlap are known to be 0 without asking the GPU)
         self.I = np.zeros((self.n, self.n), dtype=np.int64)
+        self.known = np.zeros((self.n, self.n), dtype=bool)
         if self.n:
-            b = self.bbox
-            emp = b[:, 0] < 0
-            far = ((b[:, None, 3] < b[None, :, 1]) | (b[None, :, 3] < b[:, None, 1]) |
-                   (b[:, None, 2] < b[None, :, 0]) | (b[None, :, 2] < b[:, None, 0]) | emp[:, None] | emp[None, :])
-            self.known = far
-            np.fill_diagonal(self.I, self.area)
-            np.fill_diagonal(self.known, True)
-        else:
-            self.known = np.zeros((0, 0), dtype=bool)
+            for blk in ([np.arange(self.n)] if blocks is None else blocks):
+                blk = np.asarray(blk, dtype=np.int64)
+                if len(blk) == 0:
+                    continue
+                b = self.bbox[blk]
+                emp = b[:, 0] < 0
+                far = ((b[:, None, 3] < b[None, :, 1]) | (b[None, :, 3] < b[:, None, 1]) |
+                       (b[:, None, 2] < b[None, :, 0]) | (b[None, :, 2] < b[:, None, 0]) | emp[:, None] | emp[None, :])
+                self.known[np.ix_(blk, blk)] = far
+            d = np.arange(self.n)
+            self.I[d, d] = self.area
+            self.known[d, d] = True
 
     def view(self, indices: Sequence[int]) -> "AlgebraView":
         """The same answers for a subset of the masks, renumbered 0..len(indices)-1 (no copy, no launch)."""

@@ -35,6 +35,7 @@ extern "C" {
 #define DEMIA_F32 0
 #define DEMIA_BF16 1
 #define DEMIA_F32X3 2   /* conv only: f32 activations, weights pre-split into 3 bf16 planes [3, CoutPad, KH*KW*Cin] */
+#define DEMIA_BF16X2 3  /* conv only: f32 activations, weights as 2 bf16 planes [2, CoutPad, KH*KW*Cin]: 16-bit operands */
 
 #define DEMIA_ACT_NONE 0
 #define DEMIA_ACT_RELU 1
@@ -60,7 +61,8 @@ const char* demia_build_arch(void);   /* "gfx950" */
  *   out       [N, Ho, Wo, Cout]      dtype `out_dtype`
  * Cin must be a multiple of 64 (bf16) / 32 (f32, f32x3).  dtype DEMIA_F32X3 computes the f32 product on the bf16
  * matrix pipe from three-way split operands (six bf16 MFMAs per f32 FMA tile, error ~ one f32 rounding): `in` is
- * f32, `w` holds the three bf16 planes of the f32 weights, CoutPad % 64 == 0, output f32.  */
+ * f32, `w` holds the three bf16 planes of the f32 weights, CoutPad % 64 == 0, output f32.  DEMIA_BF16X2 is the same
+ * with two planes and three MFMAs (16 significand bits per operand, error <= 3 * 2^-16 per product).  */
 typedef struct demia_conv_desc {
     const void* in;
     const void* w;

@@ -7,7 +7,7 @@ from deepemia_amd.functions.inference import InferencePipeline
 sd = synth.random_d2_state_dict(101, 2, 0)
 eng = MaskRCNNEngine(sd, 101, 2, 0.3, 'cuda:0', 'f32x3')
 pipe = InferencePipeline([Predictor(eng)], 'bench', {}, {})
-x = torch.from_numpy(np.stack([synth.em_tile(i, 2048) for i in range(8)])).cuda()
+x = torch.from_numpy(np.stack([synth.em_tile(i, 2048) for i in range(16)])).cuda()
 thr = {0: (0.3, 0.7), 1: (0.3, 0.5)}
 for _ in range(2):
     pipe.clear_cache(); pipe.process_tile_batch('k', x, {1}, thr)

@@ -83,7 +83,7 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("prec", ["f32", "f32x3", "bf16"])
+@pytest.mark.parametrize("prec", ["f32", "f32x3", "bf16x2", "bf16"])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_igemm_vs_torch(env, case, prec):
     from deepemia_amd import engine as E
@@ -117,12 +117,13 @@ def test_conv_igemm_vs_torch(env, case, prec):
     wp[:cout] = wt.permute(0, 2, 3, 1)
     dev = env["dev"]
     L = E.ConvLayer(wp.to(dev, eng.tdt), scale.to(dev), bias.to(dev), cin, cout, cout_pad, k, k, stride, pad)
-    if prec == "f32x3":
+    if prec in ("f32x3", "bf16x2"):
         # f32 operands on the bf16 matrix pipe (3-way split, 6 products): same tolerance as the exact-f32 kernel;
-        # shapes the split kernel does not take stay on the f32 kernel, exactly as the engine packs them
+        # bf16x2 = 2 planes, 3 products: 16-bit operands, tolerance 2e-4.  Shapes the split kernel does not take stay
+        # on the f32 kernel, exactly as the engine packs them
         if cout_pad % 64 or cin % 32:
             pytest.skip("shape stays on the exact-f32 kernel")
-        L.w3 = E.split3_bf16(wp).to(dev).contiguous()
+        L.w3 = E.split3_bf16(wp).to(dev)[: 3 if prec == "f32x3" else 2].contiguous()
     rdev = None if residual is None else nhwc(residual).to(dev, eng.tdt)
     if prec == "bf16" and residual is not None:
         # the reference must see the rounded residual as well
@@ -135,7 +136,7 @@ def test_conv_igemm_vs_torch(env, case, prec):
     out = eng.conv(nhwc(x).to(dev, eng.tdt), L, act=ACT_RELU if relu else ACT_NONE, residual=rdev,
                    res_mode=(RES_NONE, RES_SAME, RES_UP2)[res], out_dtype=odt)
     got = out.float().cpu().permute(0, 3, 1, 2)
-    tol = 2e-5 if prec != "bf16" else 3e-2
+    tol = {"f32": 2e-5, "f32x3": 2e-5, "bf16x2": 2e-4, "bf16": 3e-2}[prec]
     err = float((got - y).abs().max() / y.abs().max())
     assert err <= tol, err
 
