@@ -626,48 +626,78 @@ class InferencePipeline:
         return closed, out, alg
 
     @staticmethod
+    def _row_bits(rows: np.ndarray) -> List[int]:
+        """Boolean matrix -> one Python int per row (bit j = rows[i, j]): the greedy loops below then run on integer
+        bit operations instead of one small numpy call per candidate."""
+        if rows.shape[0] == 0:
+            return []
+        packed = np.packbits(rows, axis=1, bitorder="little")
+        return [int.from_bytes(packed[i].tobytes(), "little") for i in range(rows.shape[0])]
+
+    @staticmethod
+    def _pair_tables(alg: DeviceMaskAlgebra, ka: np.ndarray, need: np.ndarray):
+        """|a & b| and IoU (float64 ``inter / union``, 0 where the union is empty -- ``inference.py:422-435, 2697-2719``)
+        for every pair of ``ka`` that ``need`` marks; pairs the algebra does not know yet are fetched with ONE launch."""
+        miss = need & ~alg.known[np.ix_(ka, ka)]
+        miss = np.triu(miss | miss.T, 1)
+        if miss.any():
+            ii, jj = np.nonzero(miss)
+            alg.intersections(ka[ii], ka[jj])
+        inter = alg.I[np.ix_(ka, ka)]
+        area = alg.area[ka]
+        union = area[:, None] + area[None, :] - inter
+        iou = np.divide(inter, union, out=np.zeros(inter.shape, dtype=np.float64), where=union > 0)
+        return inter, iou
+
+    @staticmethod
     def _dedup_smart_order(alg: DeviceMaskAlgebra, k0: Sequence[int], scores, classes, bb, iou_threshold: float) -> List[int]:
-        """Step 2 of ``deduplicate_masks_smart`` (``inference.py:2640-2671``), one candidate row at a time:
-        ``sorted_indices[idx+1:]`` sliced by MASK INDEX and the mixed-axis bbox pre-filter are kept literally (N6)."""
+        """Step 2 of ``deduplicate_masks_smart`` (``inference.py:2640-2671``): ``sorted_indices[idx+1:]`` sliced by MASK
+        INDEX and the mixed-axis bbox pre-filter are kept literally (N6).  The pair conditions are evaluated as matrices
+        once; the order-dependent part is the reference's loop on bit sets."""
+        n = len(k0)
+        if n == 0:
+            return []
         k0a = np.asarray(k0, dtype=np.int64)
         cls = np.asarray(classes)
         b = np.asarray(bb, dtype=np.int64).reshape(-1, 4)       # stored (y_min, y_max, x_min, x_max) ...
         order = np.argsort(np.asarray(scores, dtype=np.float64), kind="stable")[::-1]
-        removed = np.zeros(len(k0), dtype=bool)
+        # ... read as (y_min, x_min, y_max, x_max): b1 = row mask, b2 = column mask
+        lit = ~((b[:, None, 3] < b[None, :, 1]) | (b[None, :, 3] < b[:, None, 1]) |
+                (b[:, None, 2] < b[None, :, 0]) | (b[None, :, 2] < b[:, None, 0]))
+        cand = (cls[:, None] == cls[None, :]) & lit
+        inter, iou = InferencePipeline._pair_tables(alg, k0a, cand)
+        hit = InferencePipeline._row_bits(cand & (inter > 0) & (iou > iou_threshold))
+        after = [0] * n                                          # bit set of order[p + 1:] for p = 0 .. n-1
+        acc = 0
+        for p in range(n - 1, -1, -1):
+            after[p] = acc
+            acc |= 1 << int(order[p])
+        removed = 0
         keep: List[int] = []
-        for idx in order:
-            if removed[idx]:
+        for idx in order.tolist():
+            if (removed >> idx) & 1:
                 continue
-            keep.append(int(idx))
-            others = order[idx + 1:]
-            if len(others) == 0:
-                continue
-            b1, b2 = b[idx], b[others]                           # ... read as (y_min, x_min, y_max, x_max)
-            cand = (~removed[others]) & (cls[others] == cls[idx]) & \
-                ~((b1[3] < b2[:, 1]) | (b2[:, 3] < b1[1]) | (b1[2] < b2[:, 0]) | (b2[:, 2] < b1[0]))
-            oc = others[cand]
-            if len(oc) == 0:
-                continue
-            inter = alg.inter_row(int(k0a[idx]), k0a[oc])
-            union = alg.area[k0a[idx]] + alg.area[k0a[oc]] - inter
-            iou = np.divide(inter, union, out=np.zeros(len(oc), dtype=np.float64), where=union > 0)
-            removed[oc[(inter > 0) & (iou > iou_threshold)]] = True
+            keep.append(idx)
+            removed |= hit[idx] & after[idx]                     # `others = sorted_indices[idx + 1:]`: idx used as a position
         return keep
 
     @staticmethod
     def _greedy_keep(alg: DeviceMaskAlgebra, indices, thr: float) -> List[int]:
-        """``inference.py:1451-1459`` over an index range, IoU row at a time (same integer counts, same float64
-        division as the scalar loop)."""
-        kept: List[int] = []
-        for i in indices:
-            if kept:
-                ka = np.asarray(kept, dtype=np.int64)
-                inter = alg.inter_row(i, ka)
-                union = alg.area[i] + alg.area[ka] - inter
-                iou = np.divide(inter, union, out=np.zeros(len(ka), dtype=np.float64), where=union > 0)
-                if (iou > thr).any():
-                    continue
-            kept.append(i)
+        """``inference.py:1451-1459`` over an index range (same integer counts, same float64 division as the scalar
+        loop): keep mask i unless IoU(mask_i, kept_j) > thr for a mask kept before it."""
+        idx = [int(i) for i in indices]
+        n = len(idx)
+        if n == 0:
+            return []
+        ka = np.asarray(idx, dtype=np.int64)
+        _, iou = InferencePipeline._pair_tables(alg, ka, np.ones((n, n), dtype=bool))
+        hit = InferencePipeline._row_bits(iou > thr)
+        kept_bits, kept = 0, []
+        for p in range(n):
+            if hit[p] & kept_bits:
+                continue
+            kept_bits |= 1 << p
+            kept.append(idx[p])
         return kept
 
     def process_tile_batch(self, key: str, tiles: torch.Tensor, small_classes, class_thresholds: Dict[int, Tuple[float, float]],
