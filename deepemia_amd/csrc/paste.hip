@@ -26,7 +26,7 @@ struct PasteP {
     int* out_bbox;
 };
 
-constexpr int PASTE_ROWS = 8;
+constexpr int PASTE_ROWS = 16;   // rows per block: 4 KiB of packed output at 2048 px (most blocks only write zeros)
 
 __global__ __launch_bounds__(256) void paste_kernel(const PasteP p) {
     __shared__ float sm[28 * 28];
@@ -73,7 +73,13 @@ __global__ __launch_bounds__(256) void paste_kernel(const PasteP p) {
     const int x1i = min((int)ceilf(x1) + 1, p.out_w), y1i = min((int)ceilf(y1) + 1, p.out_h);
     const bool live = sflag && (row0 < y1i) && (row0 + nrows > y0i);
     if (!live) {
-        for (int w = tid; w < nrows * wpr; w += 256) dst[w] = 0u;
+        const int nw = nrows * wpr;
+        if ((wpr & 3) == 0) {            // rows are 16-byte multiples (and the plane base is): 16-byte stores
+            uint4* d4 = reinterpret_cast<uint4*>(dst);
+            for (int w = tid; w < (nw >> 2); w += 256) d4[w] = make_uint4(0u, 0u, 0u, 0u);
+        } else {
+            for (int w = tid; w < nw; w += 256) dst[w] = 0u;
+        }
         return;
     }
     {
