@@ -325,8 +325,6 @@ class InferencePipeline:
                                       iou_threshold=0.7, edge_filter_enabled=True):
         """``inference.py:2299-2485`` for one class."""
         h, w = int(image_dev.shape[0]), int(image_dev.shape[1])
-        if tile_size % 32:
-            raise ValueError("tile_size must be a multiple of 32 (bit-packed tile masks)")
         self.ops.set_frame_width(w)
         ensemble = len(model_ids) > 1
 
@@ -338,8 +336,6 @@ class InferencePipeline:
         rank, world = self.rank, self.world
         tiles, offs = self._make_tiles(image_dev, tile_size, overlap_ratio)
         uh, uw = int(tile_size * upscale_factor), int(tile_size * upscale_factor)
-        if uw % 32:
-            raise ValueError("upscaled tile width must be a multiple of 32")
         # unit 0 = the full-image pass (rank 0), unit 1 + t = tile t (rank t % world): SURVEY.md section 8(e)
         mine = parallel.shard_indices(len(offs), rank, world)
         full_masks, full_scores, full_classes = None, [], []
@@ -357,6 +353,7 @@ class InferencePipeline:
         if mine:
             # a6 + a9..a12 (or a10 + a14) for ALL of this rank's tiles with one launch per kernel, then a13 likewise: one
             # nearest-resize launch to tile scale, one bbox reduction for the edge test, one paste into the global frame
+            self.ops.set_frame_width(uw)           # the tile masks' own frame: its right border is pixel uw - 1
             if ensemble:
                 big, res, _ = self._ensemble_class_pass_batched(tile_dets, target_class, small_classes, confidence_threshold, iou_threshold)
             else:
@@ -372,7 +369,8 @@ class InferencePipeline:
             if src:
                 n = len(src)
                 tm = big[torch.tensor(src, dtype=torch.long, device=self.dev)].contiguous()
-                small = self.ops.place_tiles(tm, [0] * n, [0] * n, tile_size, tile_size, tile_size, tile_size)
+                small = self.ops.place_tiles(tm, [0] * n, [0] * n, tile_size, tile_size, tile_size, tile_size, src_w=uw)
+                self.ops.set_frame_width(tile_size)
                 keep = list(range(n))
                 if edge_filter_enabled:
                     _, bb = self.ops.area_bbox(small)
@@ -382,11 +380,12 @@ class InferencePipeline:
                 if keep:
                     sel = torch.tensor(keep, dtype=torch.long, device=self.dev)
                     glob = self.ops.place_tiles(small[sel].contiguous(), [xo[i] for i in keep], [yo[i] for i in keep],
-                                                tile_size, tile_size, h, w)
+                                                tile_size, tile_size, h, w, src_w=tile_size)
                     tile_masks.append(glob)
                     tile_scores.extend(sc_all[i] for i in keep)
                     tile_classes.extend([target_class] * len(keep))
                     tile_units.extend(un[i] for i in keep)
+            self.ops.set_frame_width(w)
         if world > 1:
             # the ONE exchange of the path: every rank receives every rank's instance table, ordered by unit id
             empty_full = isinstance(full_masks, str)

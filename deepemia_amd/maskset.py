@@ -145,13 +145,15 @@ class MaskOps:
         return self.program_(packed, ["flag_multi"], bbox)[2]
 
     def place_tiles(self, src: torch.Tensor, x_off: Sequence[int], y_off: Sequence[int], tile_h: int, tile_w: int,
-                    H: int, W: int) -> torch.Tensor:
+                    H: int, W: int, src_w: Optional[int] = None) -> torch.Tensor:
+        """``cv2.resize(mask, (tile_w, tile_h), INTER_NEAREST)`` + paste at (x_off, y_off) into a zero (H, W) frame.
+        ``src_w``: true pixel width of the source masks (default: 32 x their words per row)."""
         T, sh, swpr = src.shape
         dst = torch.empty((T, H, (W + 31) // 32), dtype=torch.int32, device=self.device)
         xo = torch.tensor(list(x_off), dtype=torch.int32, device=self.device)
         yo = torch.tensor(list(y_off), dtype=torch.int32, device=self.device)
-        _lib.check(self.lib.demia_mask_place_tiles(_lib.ptr(src), _lib.ptr(dst), _lib.ptr(xo), _lib.ptr(yo), T, sh, swpr * 32,
-                                                   tile_h, tile_w, H, W, self._stream()), "demia_mask_place_tiles")
+        _lib.check(self.lib.demia_mask_place_tiles(_lib.ptr(src), _lib.ptr(dst), _lib.ptr(xo), _lib.ptr(yo), T, sh,
+                                                   swpr * 32 if src_w is None else int(src_w), tile_h, tile_w, H, W, self._stream()), "demia_mask_place_tiles")
         return dst
 
     # -- contours + measurements ----------------------------------------------------------------

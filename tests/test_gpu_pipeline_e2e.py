@@ -115,7 +115,8 @@ def _compare(split, images, ref_rows, ref_masks):
 
 
 @pytest.mark.parametrize("case", ["single_r50_blobby_upscale2", "ensemble_r50_r101_upscale1",
-                                  "single_r50_blobby_upscale2_f32x3", "ensemble_r50_r101_upscale1_f32x3"])
+                                  "single_r50_blobby_upscale2_f32x3", "ensemble_r50_r101_upscale1_f32x3",
+                                  "single_r50_tile200_upscale1p5_f32x3"])
 def test_cli_inference_matches_oracle_pipeline(case, tmp_path, monkeypatch, gpu_device):
     from oracle import pipeline_ref as PR
     from deepemia_amd.data import models as DM
@@ -126,7 +127,11 @@ def test_cli_inference_matches_oracle_pipeline(case, tmp_path, monkeypatch, gpu_
     spatial = {"enabled": True, "containment_rules": {1: 0}, "containment_threshold": 0.5,
                "overlap_rules": {0: {"allow_overlap": False, "max_iou_threshold": 0.3},
                                  1: {"allow_overlap": False, "max_iou_threshold": 0.5}}}
-    if case == "single_r50_blobby_upscale2":
+    if case.startswith("single_r50_tile200"):
+        # tile and upscaled-tile sizes that are not multiples of 32 (200 -> 300 px), tiles cropped at the image edge
+        depths, bias, gain, size = [50], 0.5, 6.0, 512
+        tile = {"tile_size": 200, "overlap_ratio": 0.1, "upscale_factor": 1.5, "edge_filter_enabled": True}
+    elif case.startswith("single_r50_blobby_upscale2"):
         depths, bias, gain, size = [50], 0.5, 6.0, 512
         tile = {"tile_size": 256, "overlap_ratio": 0.125, "upscale_factor": 2.0, "edge_filter_enabled": True}
     else:
