@@ -91,6 +91,35 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, char* smem, f32x16
     constexpr int EROW = BN * 4 + 16;          // epilogue LDS row (f32) + pad
     const int tid = threadIdx.x;
     const int lane = tid & 63;
+    constexpr int G = BN / 4;          // 4-channel groups per row
+    constexpr int RPP = 256 / G;       // rows per pass
+    constexpr int NR = BM / RPP;       // passes
+    const int g = tid % G;
+    const int r0 = tid / G;
+    const int co = n0 + g * 4;
+    const TO* __restrict__ res = reinterpret_cast<const TO*>(p.residual);
+    // The residual rows of this thread are requested BEFORE the accumulators go through LDS: a short-K layer
+    // (1x1, K <= 256) is otherwise one exposed global round trip per pass.
+    const bool res_pref = p.res_mode != DEMIA_RES_NONE && p.vec_ok && co < p.Cout;
+    float rv[NR][4];
+    if (res_pref) {
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const int m = m0 + r0 + k * RPP;
+            const int mm = m < p.M ? m : p.M - 1;
+            long ridx;
+            if (p.res_mode == DEMIA_RES_SAME) {
+                ridx = (long)mm * p.Cout + co;
+            } else {
+                const int n = mm / p.HoWo;
+                const int rem = mm - n * p.HoWo;
+                const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+                const int Hr = (p.Ho + 1) >> 1, Wr = (p.Wo + 1) >> 1;
+                ridx = (((long)n * Hr + (ho >> 1)) * Wr + (wo >> 1)) * p.Cout + co;
+            }
+            load4<TO>(res + ridx, rv[k]);
+        }
+    }
     __syncthreads();
     // ---- epilogue: accumulators -> LDS (f32) -> 16-byte rows --------------------------
     // C layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
@@ -110,13 +139,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, char* smem, f32x16
     }
     __syncthreads();
     {
-        constexpr int G = BN / 4;          // 4-channel groups per row
-        constexpr int RPP = 256 / G;       // rows per pass
-        const int g = tid % G;
-        const int r0 = tid / G;
-        const int co = n0 + g * 4;
         TO* __restrict__ out = reinterpret_cast<TO*>(p.out);
-        const TO* __restrict__ res = reinterpret_cast<const TO*>(p.residual);
         if (co < p.Cout) {
             float sc[4], bs[4];
 #pragma unroll
@@ -126,44 +149,43 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, char* smem, f32x16
                 bs[q] = (p.bias && ok) ? p.bias[co + q] : 0.0f;
             }
             const char* e = smem;
-            for (int r = r0; r < BM; r += RPP) {
+#pragma unroll
+            for (int k = 0; k < NR; ++k) {
+                const int r = r0 + k * RPP;
                 const int m = m0 + r;
-                if (m >= p.M) break;
-                const float4 a4 = *reinterpret_cast<const float4*>(e + r * EROW + g * 16);
-                float v[4] = {a4.x, a4.y, a4.z, a4.w};
+                if (m < p.M) {
+                    const float4 a4 = *reinterpret_cast<const float4*>(e + r * EROW + g * 16);
+                    float v[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = v[q] * sc[q] + bs[q];
-                if (p.res_mode != DEMIA_RES_NONE) {
-                    long ridx;
-                    if (p.res_mode == DEMIA_RES_SAME) {
-                        ridx = (long)m * p.Cout + co;
-                    } else {
-                        const int n = m / p.HoWo;
-                        const int rem = m - n * p.HoWo;
-                        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-                        const int Hr = (p.Ho + 1) >> 1, Wr = (p.Wo + 1) >> 1;
-                        ridx = (((long)n * Hr + (ho >> 1)) * Wr + (wo >> 1)) * p.Cout + co;
-                    }
-                    if (p.vec_ok) {
-                        float rv[4];
-                        load4<TO>(res + ridx, rv);
+                    for (int q = 0; q < 4; ++q) v[q] = v[q] * sc[q] + bs[q];
+                    if (res_pref) {
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) v[q] += rv[q];
-                    } else {
+                        for (int q = 0; q < 4; ++q) v[q] += rv[k][q];
+                    } else if (p.res_mode != DEMIA_RES_NONE) {
+                        long ridx;
+                        if (p.res_mode == DEMIA_RES_SAME) {
+                            ridx = (long)m * p.Cout + co;
+                        } else {
+                            const int n = m / p.HoWo;
+                            const int rem = m - n * p.HoWo;
+                            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+                            const int Hr = (p.Ho + 1) >> 1, Wr = (p.Wo + 1) >> 1;
+                            ridx = (((long)n * Hr + (ho >> 1)) * Wr + (wo >> 1)) * p.Cout + co;
+                        }
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
                             if (co + q < p.Cout) v[q] += to_f32<TO>(res[ridx + q]);
                     }
-                }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = apply_act(v[q], p.act);
-                TO* o = out + (long)m * p.out_ld + co;
-                if (p.vec_ok) {
-                    store4<TO>(o, v);
-                } else {
+                    for (int q = 0; q < 4; ++q) v[q] = apply_act(v[q], p.act);
+                    TO* o = out + (long)m * p.out_ld + co;
+                    if (p.vec_ok) {
+                        store4<TO>(o, v);
+                    } else {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (co + q < p.Cout) o[q] = from_f32<TO>(v[q]);
+                        for (int q = 0; q < 4; ++q)
+                            if (co + q < p.Cout) o[q] = from_f32<TO>(v[q]);
+                    }
                 }
             }
         }
