@@ -12,5 +12,5 @@ extern "C" void demia_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* demia_last_error(void) { return g_err; }
-extern "C" int demia_abi_version(void) { return 2; }
+extern "C" int demia_abi_version(void) { return 3; }
 extern "C" const char* demia_build_arch(void) { return "gfx950"; }

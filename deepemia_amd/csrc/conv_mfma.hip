@@ -326,7 +326,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
 // f32 accumulator of v_mfma_f32_32x32x16_bf16; the dropped terms are <= 3 * 2^-24 |ab|, the size of one f32
 // rounding.  Six bf16 MFMAs (6 x 32 cycles per 32x32x16) replace eight f32 MFMAs (8 x 64 cycles), so the matrix
 // pipe does the same f32 dot product 2.7x faster.  Activations stay f32 in HBM (nothing else changes): the A tile
-// is split in registers on its way to LDS; weights are split once on the host ([3][CoutPad][K] bf16).
+// is split in registers on its way to LDS; weights are split and tiled once on the host
+// ([CoutPad / 64][ksteps][3][64][32] bf16, see the B loads below).
 // K-step = 32 elements; LDS rows are 64 B + 16 B pad (80 B: conflict-free ds_read_b128); 2 stages x 3 planes.
 constexpr int ROWS3 = 80;
 
@@ -380,8 +381,9 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(const ConvP p) {
         a_wi0[i] = wo * p.stride - p.pad;
         a_base[i] = (((long)n * p.H + a_hi0[i]) * p.W + a_wi0[i]) * p.Cin + chunk * 4;
     }
-    const long Ktot = (long)p.KH * p.KW * p.Cin;
-    const long plane_stride = (long)p.CoutPad * Ktot;
+    // Weight planes arrive TILED: [CoutPad / 64][ksteps][NP][64 rows][32 k] bf16 -- the 64 x 32 piece of one plane that a
+    // K-step needs is 4 KiB contiguous, so the B loads of a wave are whole 128-byte lines (row-major [CoutPad][K]
+    // planes made every 16-lane group touch four half-used lines).
     long b_off[BVT];
     int b_lds[BVT];
     bool b_vm[BVT];
@@ -392,9 +394,11 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(const ConvP p) {
         const int row = rem >> 2, c8 = rem & 3;
         const int co = n0 + row;
         b_vm[j] = co < p.CoutPad;
-        b_off[j] = plane * plane_stride + (long)(b_vm[j] ? co : 0) * Ktot + c8 * 8;
+        const int n64 = (b_vm[j] ? co : 0) >> 6;
+        b_off[j] = ((long)n64 * p.ksteps * NP + plane) * 2048 + (co & 63) * 32 + c8 * 8;
         b_lds[j] = NP * PLANE_A + plane * PLANE_B + row * ROWS3 + c8 * 16;
     }
+    long b_step = 0;
 
     // ONE LDS stage (61 KiB for 128x128) so that TWO workgroups share a CU: while one is in its barrier / split /
     // store phase the other one's MFMAs keep the matrix pipe busy (a K-step is only 48 MFMAs, ~1.5k cycles, far
@@ -409,10 +413,10 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(const ConvP p) {
             const bool ok = a_vm[i] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
             ra[i] = ok ? *reinterpret_cast<const uint4*>(in + a_base[i] + tap) : make_uint4(0, 0, 0, 0);
         }
-        const long kof = ((long)kh * p.KW + kw) * p.Cin + c0;
 #pragma unroll
         for (int j = 0; j < BVT; ++j)
-            rb[j] = b_vm[j] ? *reinterpret_cast<const uint4*>(wt + b_off[j] + kof) : make_uint4(0, 0, 0, 0);
+            rb[j] = b_vm[j] ? *reinterpret_cast<const uint4*>(wt + b_off[j] + b_step) : make_uint4(0, 0, 0, 0);
+        b_step += NP * 2048;
         c0 += BK;
         if (c0 >= p.Cin) { c0 = 0; if (++kw == p.KW) { kw = 0; ++kh; } }
     };

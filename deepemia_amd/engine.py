@@ -124,6 +124,16 @@ def split3_bf16(w: torch.Tensor) -> torch.Tensor:
     return torch.stack([h, m, l], dim=0)
 
 
+def tile_weight_planes(w3: torch.Tensor) -> torch.Tensor:
+    """[NP, CoutPad, KH, KW, Cin] bf16 planes -> the layout ``demia_conv2d_nhwc`` reads for DEMIA_F32X3 / DEMIA_BF16X2:
+    [CoutPad / 64, ksteps, NP, 64, 32] with K = (kh, kw, cin) walked in steps of 32, so that the 64 x 32 piece of one
+    plane that a K-step needs is 4 KiB contiguous (``include/deepemia_hip.h``)."""
+    npl, cout_pad = int(w3.shape[0]), int(w3.shape[1])
+    k = w3[0, 0].numel()
+    assert cout_pad % 64 == 0 and k % 32 == 0, (cout_pad, k)
+    return w3.reshape(npl, cout_pad // 64, 64, k // 32, 32).permute(1, 3, 0, 2, 4).contiguous()
+
+
 def cell_anchor_table() -> np.ndarray:
     out = np.zeros((5, 3, 4), dtype=np.float32)
     for l, size in enumerate(ANCHOR_SIZES):
@@ -147,7 +157,7 @@ class ConvLayer:
     kw: int
     stride: int
     pad: int
-    w3: Optional[torch.Tensor] = None   # f32x3 / bf16x2 mode: the three / two bf16 planes of w, [NP, CoutPad, KH, KW, Cin]
+    w3: Optional[torch.Tensor] = None   # f32x3 / bf16x2 mode: the three / two bf16 planes of w, tiled [CoutPad/64, ksteps, NP, 64, 32]
 
 
 @dataclass
@@ -216,7 +226,7 @@ class MaskRCNNEngine:
         w3 = None
         if self.precision in ("f32x3", "bf16x2") and cout_pad % 64 == 0 and cin % 32 == 0:
             w3 = split3_bf16(wp.to(dev))                       # split on the device: same round-to-nearest casts
-            w3 = (w3 if self.precision == "f32x3" else w3[:2]).contiguous()
+            w3 = tile_weight_planes(w3 if self.precision == "f32x3" else w3[:2])
         return ConvLayer(wp.to(dev, self.tdt).contiguous(),
                          None if scale is None else scale.to(dev).contiguous(),
                          None if b is None else b.to(dev).contiguous(), cin, cout, cout_pad, kh, kw, stride, pad, w3)
@@ -294,7 +304,7 @@ class MaskRCNNEngine:
         use3 = L.w3 is not None and odt == torch.float32
         d = _lib.ConvDesc(_lib.ptr(x), _lib.ptr(L.w3 if use3 else L.w), _lib.ptr(L.scale), _lib.ptr(L.bias), _lib.ptr(residual),
                           _lib.ptr(out), n, h, w, cin, ho, wo, L.cout, L.cout_pad, L.kh, L.kw, L.stride, L.pad,
-                          (F32X3 if L.w3.shape[0] == 3 else BF16X2) if use3 else self.dt, BF16 if odt == torch.bfloat16 else F32,
+                          (F32X3 if L.w3.shape[2] == 3 else BF16X2) if use3 else self.dt, BF16 if odt == torch.bfloat16 else F32,
                           act, res_mode, ld, tile_hint)
         ev = self.conv_events
         if ev is not None:
@@ -305,10 +315,10 @@ class MaskRCNNEngine:
             e1.record(torch.cuda.current_stream(self.device))
             esz = 2 if self.dt == BF16 else 4
             osz = 2 if odt == torch.bfloat16 else 4
-            nbytes = (n * h * w * cin * esz + L.cout_pad * L.kh * L.kw * cin * (2 * int(L.w3.shape[0]) if use3 else esz) + n * ho * wo * L.cout * osz +
+            nbytes = (n * h * w * cin * esz + L.cout_pad * L.kh * L.kw * cin * (2 * int(L.w3.shape[2]) if use3 else esz) + n * ho * wo * L.cout * osz +
                       (0 if residual is None else residual.numel() * osz))     # every operand once: the algorithmic traffic
             ev.append((e0, e1, 2.0 * n * ho * wo * L.cout * L.kh * L.kw * cin,
-                       ("f32x3" if L.w3.shape[0] == 3 else "bf16x2") if use3 else ("bf16" if self.dt == BF16 else "f32"), nbytes))
+                       ("f32x3" if L.w3.shape[2] == 3 else "bf16x2") if use3 else ("bf16" if self.dt == BF16 else "f32"), nbytes))
         return out
 
     def _resize_tables(self, h: int, w: int):

@@ -34,8 +34,8 @@ extern "C" {
 
 #define DEMIA_F32 0
 #define DEMIA_BF16 1
-#define DEMIA_F32X3 2   /* conv only: f32 activations, weights pre-split into 3 bf16 planes [3, CoutPad, KH*KW*Cin] */
-#define DEMIA_BF16X2 3  /* conv only: f32 activations, weights as 2 bf16 planes [2, CoutPad, KH*KW*Cin]: 16-bit operands */
+#define DEMIA_F32X3 2   /* conv only: f32 activations, weights pre-split into 3 bf16 planes, tiled (see demia_conv2d_nhwc) */
+#define DEMIA_BF16X2 3  /* conv only: f32 activations, weights as 2 bf16 planes (same tiling): 16-bit operands */
 
 #define DEMIA_ACT_NONE 0
 #define DEMIA_ACT_RELU 1
@@ -62,7 +62,11 @@ const char* demia_build_arch(void);   /* "gfx950" */
  * Cin must be a multiple of 64 (bf16) / 32 (f32, f32x3).  dtype DEMIA_F32X3 computes the f32 product on the bf16
  * matrix pipe from three-way split operands (six bf16 MFMAs per f32 FMA tile, error ~ one f32 rounding): `in` is
  * f32, `w` holds the three bf16 planes of the f32 weights, CoutPad % 64 == 0, output f32.  DEMIA_BF16X2 is the same
- * with two planes and three MFMAs (16 significand bits per operand, error <= 3 * 2^-16 per product).  */
+ * with two planes and three MFMAs (16 significand bits per operand, error <= 3 * 2^-16 per product).
+ * Layout of `w` for these two dtypes (NP = 3 / 2 planes, x = x1 + x2 + x3 with x1 = bf16(x), x2 = bf16(x - x1), ...):
+ *   [CoutPad / 64][KH*KW*Cin / 32][NP][64][32] bf16,  K = (kh, kw, cin) walked in steps of 32
+ * i.e. the 64-channel x 32-k piece of one plane that a K-step reads is 4 KiB contiguous (whole 128-byte lines per
+ * wave load).  ABI version 3 (version 2 took row-major [NP][CoutPad][K] planes).  */
 typedef struct demia_conv_desc {
     const void* in;
     const void* w;

@@ -45,7 +45,7 @@ def nhwc(t):
 def test_library_is_the_hip_one(env):
     lib = env["eng"].lib
     assert lib.demia_build_arch().decode() == "gfx950"
-    assert lib.demia_abi_version() == 2
+    assert lib.demia_abi_version() == 3
 
 
 @pytest.mark.parametrize("hw", [(1024, 1024), (2048, 2048), (600, 600), (700, 1100), (1000, 2000)])
@@ -123,7 +123,7 @@ def test_conv_igemm_vs_torch(env, case, prec):
         # on the f32 kernel, exactly as the engine packs them
         if cout_pad % 64 or cin % 32:
             pytest.skip("shape stays on the exact-f32 kernel")
-        L.w3 = E.split3_bf16(wp).to(dev)[: 3 if prec == "f32x3" else 2].contiguous()
+        L.w3 = E.tile_weight_planes(E.split3_bf16(wp).to(dev)[: 3 if prec == "f32x3" else 2])
     rdev = None if residual is None else nhwc(residual).to(dev, eng.tdt)
     if prec == "bf16" and residual is not None:
         # the reference must see the rounded residual as well
