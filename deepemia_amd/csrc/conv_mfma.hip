@@ -488,6 +488,16 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(const ConvP p) {
     conv_epilogue<TO, BM, BN, TM, TN>(p, smem, acc, a_row0, b_row0, m0, n0);
 }
 
+// 128 x 128 or 64 x 128 tiles for the split kernels: the workgroups of a CU share its matrix pipes, so a launch lasts as
+// long as the CU with the most tiles -- balance = (tiles / 256) / ceil(tiles / 256).  The half tile re-reads the weight
+// planes twice as often per FLOP and measures 7 % slower per tile at equal balance (164 vs 172 TFLOP/s on the large
+// layers), so it is taken only where its better balance outweighs that (res4 / res5 at 16 tiles per batch).
+inline bool prefer_half_tile(long blocks128, long blocks64) {
+    auto balance = [](long b) { const double per_cu = (double)b / 256.0; return per_cu / (double)((b + 255) / 256); };
+    if (blocks128 < 512) return true;          // fewer than two tiles per CU: fill the chip first
+    return 0.93 * balance(blocks64) > balance(blocks128);
+}
+
 template <typename TO, int WM, int WN, int TM, int TN, int NP = 3>
 int launch_split_cfg(ConvP p, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -573,13 +583,15 @@ extern "C" int demia_conv2d_nhwc(const demia_conv_desc* d, void* stream) {
     if (d->dtype == DEMIA_BF16X2) {
         if (d->CoutPad % 128 != 0) return launch_split_cfg<float, 4, 1, 1, 2, 2>(p, st);
         const long blocks128 = (long)cdiv(p.M, 128) * cdiv(p.CoutPad, 128);
-        if (blocks128 < 1300) return launch_split_cfg<float, 2, 2, 1, 2, 2>(p, st);
+        if (prefer_half_tile(blocks128, (long)cdiv(p.M, 64) * cdiv(p.CoutPad, 128)))
+            return launch_split_cfg<float, 2, 2, 1, 2, 2>(p, st);
         return launch_split_cfg<float, 2, 2, 2, 2, 2>(p, st);
     }
     if (d->dtype == DEMIA_F32X3) {
         if (d->CoutPad % 128 != 0) return launch_split_cfg<float, 4, 1, 1, 2>(p, st);            // 128 x 64
         const long blocks128 = (long)cdiv(p.M, 128) * cdiv(p.CoutPad, 128);
-        if (blocks128 < 1300) return launch_split_cfg<float, 2, 2, 1, 2>(p, st);                  // 64 x 128
+        if (prefer_half_tile(blocks128, (long)cdiv(p.M, 64) * cdiv(p.CoutPad, 128)))
+            return launch_split_cfg<float, 2, 2, 1, 2>(p, st);                                    // 64 x 128
         return launch_split_cfg<float, 2, 2, 2, 2>(p, st);                                        // 128 x 128
     }
     if (d->dtype == DEMIA_BF16) {
