@@ -1,7 +1,10 @@
 """Dev script: per-conv-launch achieved TFLOP/s (R101, 2048^2, B tiles)."""
 import sys, numpy as np, torch
 sys.path.insert(0, '.')
-from deepemia_amd import synth, engine as E
+from deepemia_amd import synth, engine as E, _lib
+import os, pathlib
+if os.environ.get('AB_LIB'):
+    _lib.LIB_PATH = pathlib.Path(os.environ['AB_LIB']).resolve()
 prec = sys.argv[1]; B = int(sys.argv[2])
 sd = synth.random_d2_state_dict(101, 2, 0)
 eng = E.MaskRCNNEngine(sd, 101, 2, 0.3, 'cuda:0', prec)
