@@ -76,6 +76,9 @@ def main() -> None:
     ap.add_argument("--depth", type=int, default=101)
     ap.add_argument("--size", type=int, default=2048)
     ap.add_argument("--threshold", type=float, default=0.3)
+    ap.add_argument("--min-size-test", type=int, default=800, help="INPUT.MIN_SIZE_TEST; anything but 800 is the flagged NON-parity "
+                    "native-resolution mode (not BASELINE.json's workload)")
+    ap.add_argument("--max-size-test", type=int, default=1333)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="do not overlap batch i+1's network with batch i's post-processing")
     ap.add_argument("--forward-only", action="store_true", help="time predictor(tile) only, without the per-tile post-processing")
@@ -114,7 +117,7 @@ def main() -> None:
     from deepemia_amd.predictor import Predictor
 
     sd = synth.random_d2_state_dict(args.depth, 2, seed=0)
-    eng = MaskRCNNEngine(sd, args.depth, 2, args.threshold, dev, args.precision)
+    eng = MaskRCNNEngine(sd, args.depth, 2, args.threshold, dev, args.precision, args.min_size_test, args.max_size_test)
     pipe = InferencePipeline([Predictor(eng)], "bench", {}, {})
     tiles = np.stack([synth.em_tile(rank * args.batch + i, args.size) for i in range(args.batch)])
     x = torch.from_numpy(tiles).to(dev)
@@ -205,15 +208,19 @@ def main() -> None:
         # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this workload; FETCH_SIZE doubled per the gfx950 note)
         traffic = None
         tf = ROOT / "profiles" / f"r01_conv_{args.precision}_b{args.batch}_pmc_traffic.json"
-        if tf.exists() and args.depth == 101 and args.size == 2048:
+        native = (args.min_size_test, args.max_size_test) != (800, 1333)
+        if native:
+            args.no_cpu_baseline = True        # the oracle sample below is the 800-pixel workload
+        if tf.exists() and args.depth == 101 and args.size == 2048 and not native:
             traffic = json.loads(tf.read_text()).get("hbm_bytes_per_launch")
         line = {
             "metric": "EM tiles/s (2048x2048, R101-FPN)", "value": world * args.batch * args.steps / dt,
             "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": f"configs[1]: R{args.depth}-FPN, {args.size}x{args.size} synthetic EM tiles, "
-                                   f"{args.batch} tiles per GPU per step; per tile: resize 800 -> backbone/FPN/RPN/ROI heads -> mask paste to "
+            "config": {"workload": ("NON-PARITY native-resolution mode, not configs[1]: " if native else "configs[1]: ") +
+                                   f"R{args.depth}-FPN, {args.size}x{args.size} synthetic EM tiles, "
+                                   f"{args.batch} tiles per GPU per step; per tile: resize {args.min_size_test} -> backbone/FPN/RPN/ROI heads -> mask paste to "
                                    f"bit-packed {args.size}^2 masks" + ("" if args.forward_only else " -> class loop (fill holes, closing, overlap "
                                    "removal, component test, opening, greedy IoU dedup) -> cross-class dedup -> contour trace + 12 measurements") +
                                    f"; random-init Detectron2-layout weights, K=2, threshold {args.threshold}"

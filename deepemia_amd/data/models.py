@@ -25,6 +25,11 @@ from .datasets import MetadataCatalog
 #   f32    the exact-f32 MFMA (v_mfma_f32_32x32x2_f32)
 #   bf16   bf16 operands (fastest, mask IoU parity NOT met)
 DEFAULT_PRECISION = os.environ.get("DEEPEMIA_PRECISION", "f32x3")
+# INPUT.MIN_SIZE_TEST / MAX_SIZE_TEST: the reference never overrides the model-zoo 800 / 1333 (models.py:134-144), so
+# these are the parity values.  DEEPEMIA_MIN_SIZE_TEST / DEEPEMIA_MAX_SIZE_TEST select the flagged NON-parity
+# "native resolution" mode (e.g. 2048 / 2048: the net sees a 2048^2 tile unscaled; 5x the work per tile).
+MIN_SIZE_TEST = int(os.environ.get("DEEPEMIA_MIN_SIZE_TEST", "800"))
+MAX_SIZE_TEST = int(os.environ.get("DEEPEMIA_MAX_SIZE_TEST", "1333"))
 
 
 def get_trained_model_paths(base_dir: str, rcnn: int = 101) -> dict:
@@ -60,7 +65,10 @@ def load_model(cfg, model_path: str, dataset_name: str, is_quantized: bool = Fal
     sd = read_d2_checkpoint(model_path)
     device = f"cuda:{torch.cuda.current_device()}" if torch.cuda.is_available() else "cuda:0"
     eng = MaskRCNNEngine(sd, cfg.MODEL.DEPTH, cfg.MODEL.ROI_HEADS.NUM_CLASSES, cfg.MODEL.ROI_HEADS.SCORE_THRESH_TEST,
-                         device, DEFAULT_PRECISION)
+                         device, DEFAULT_PRECISION, MIN_SIZE_TEST, MAX_SIZE_TEST)
+    if (MIN_SIZE_TEST, MAX_SIZE_TEST) != (800, 1333):
+        system_logger.warning(f"INPUT.MIN_SIZE_TEST / MAX_SIZE_TEST = {MIN_SIZE_TEST} / {MAX_SIZE_TEST}: not the reference's "
+                              f"800 / 1333 -- results are NOT comparable with the reference's")
     if eng.unmatched_keys:
         system_logger.warning(f"{model_path}: {len(eng.unmatched_keys)} checkpoint keys were not consumed: "
                               f"{eng.unmatched_keys[:8]}{' ...' if len(eng.unmatched_keys) > 8 else ''}")

@@ -176,7 +176,7 @@ class RawDetections:
 
 class MaskRCNNEngine:
     def __init__(self, state_dict: Dict[str, torch.Tensor], depth: int, num_classes: int, score_thresh: float,
-                 device: str = "cuda:0", precision: str = "f32x3"):
+                 device: str = "cuda:0", precision: str = "f32x3", min_size_test: int = 800, max_size_test: int = 1333):
         if depth not in RES_BLOCKS:
             raise ValueError(f"unsupported ResNet depth {depth}")
         if not torch.cuda.is_available():
@@ -187,6 +187,11 @@ class MaskRCNNEngine:
         self.score_thresh = float(score_thresh)
         self.device = torch.device(device)
         self.precision = precision
+        # INPUT.MIN_SIZE_TEST / MAX_SIZE_TEST of the model-zoo config the reference loads (800 / 1333, never overridden
+        # there: models.py:134-144).  Other values are the flagged "native resolution" mode of SURVEY 8(f)4.
+        self.min_size_test, self.max_size_test = int(min_size_test), int(max_size_test)
+        if self.min_size_test < 32 or self.max_size_test < self.min_size_test:
+            raise ValueError(f"min_size_test / max_size_test = {min_size_test} / {max_size_test}")
         if precision not in ("f32", "f32x3", "bf16x2", "bf16"):
             raise ValueError("precision must be 'f32' (exact-f32 MFMA), 'f32x3' (f32 on the bf16 pipe, 3-way split), "
                              "'bf16x2' (16-bit operands on the bf16 pipe, 2-way split) or 'bf16'")
@@ -324,7 +329,7 @@ class MaskRCNNEngine:
     def _resize_tables(self, h: int, w: int):
         key = (h, w)
         if key not in self._tables:
-            newh, neww = resize_shape(h, w)
+            newh, neww = resize_shape(h, w, self.min_size_test, self.max_size_test)
             xm, xs, xk = pil_bilinear_tables(w, neww)
             ym, ys, yk = pil_bilinear_tables(h, newh)
             t = lambda a: torch.from_numpy(a).to(self.device)

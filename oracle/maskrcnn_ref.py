@@ -454,10 +454,10 @@ def paste_masks(masks: torch.Tensor, boxes: torch.Tensor, img_h: int, img_w: int
 # ----------------------------------------------------------------------------
 @torch.no_grad()
 def predict(image_bgr: np.ndarray, sd: Dict[str, torch.Tensor], depth: int, score_thresh: float,
-            return_intermediates: bool = False):
+            return_intermediates: bool = False, min_size_test: int = 800, max_size_test: int = 1333):
     """``DefaultPredictor.__call__`` -> dict(pred_boxes, scores, pred_classes, pred_masks)."""
     h, w = image_bgr.shape[:2]
-    resized = resize_shortest_edge(image_bgr)
+    resized = resize_shortest_edge(image_bgr, min_size_test, max_size_test)
     newh, neww = resized.shape[:2]
     x = torch.as_tensor(resized.astype("float32").transpose(2, 0, 1))
     mean = torch.tensor(PIXEL_MEAN, dtype=torch.float32).view(3, 1, 1)

@@ -366,3 +366,28 @@ def test_non_square_image_width_not_multiple_of_32(env):
     assert tuple(m.shape) == (n, 600, 700)
     iou = (m & r).sum((1, 2)).float() / (m | r).sum((1, 2)).float().clamp(min=1)
     assert float(iou.min()) >= 0.999
+
+
+def test_native_resolution_mode_matches_oracle_at_the_same_sizes(env):
+    """SURVEY 8(f)4, flagged non-parity mode: INPUT.MIN_SIZE_TEST / MAX_SIZE_TEST other than the reference's 800 / 1333
+    (here 1024 / 1024 on a 1024 x 1024 tile: the net sees the tile unscaled).  Not the reference's result -- but the HIP
+    path and the oracle must still agree with each other when both are given the same sizes."""
+    from deepemia_amd.engine import MaskRCNNEngine
+    from deepemia_amd.predictor import Predictor
+
+    R, synth = env["R"], env["synth"]
+    img = synth.em_tile(3, 1024)
+    ref = R.predict(img, env["sd"], 50, THR, min_size_test=1024, max_size_test=1024)
+    eng = MaskRCNNEngine(env["sd"], 50, K, THR, env["dev"], "f32x3", min_size_test=1024, max_size_test=1024)
+    assert eng._resize_tables(1024, 1024)["newh"] == 1024
+    inst = Predictor(eng)(img)["instances"].to("cpu")
+    n = ref["scores"].shape[0]
+    assert len(inst) == n and n > 10
+    np.testing.assert_array_equal(inst.pred_classes.numpy(), ref["pred_classes"].numpy())
+    np.testing.assert_allclose(inst.scores.numpy(), ref["scores"].numpy(), atol=2e-5)
+    m, r = inst.pred_masks, ref["pred_masks"]
+    iou = (m & r).sum((1, 2)).float() / (m | r).sum((1, 2)).float().clamp(min=1)
+    assert float(iou.min()) >= 0.999
+    # and it is a different answer from the 800-pixel parity mode
+    base = R.predict(img, env["sd"], 50, THR)
+    assert base["scores"].shape[0] != n or not np.allclose(base["scores"].numpy(), ref["scores"].numpy(), atol=1e-3)
