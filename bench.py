@@ -27,7 +27,7 @@ import torch
 
 # dense MFMA peaks, MI355X_MICROARCH.md.  f32x3 computes the f32 product with six bf16 MFMAs per tile (three-way
 # split operands): its roof in f32-equivalent FLOP/s is the bf16 peak / 6.
-PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f32x3": 2500.0 / 6, "bf16x2": 2500.0 / 3}
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f32x3": 2500.0 / 6, "bf16x2": 2500.0 / 3, "f16x2": 2500.0 / 3}
 
 
 CLASS_THRESHOLDS = {0: (0.3, 0.7), 1: (0.3, 0.5)}   # class -> (confidence, IoU) as in config.yaml class_0 / class_1
@@ -72,7 +72,7 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="tiles per GPU per step")
-    ap.add_argument("--precision", choices=["f32", "f32x3", "bf16x2", "bf16"], default="f32x3")
+    ap.add_argument("--precision", choices=["f32", "f32x3", "f16x2", "bf16x2", "bf16"], default="f32x3")
     ap.add_argument("--depth", type=int, default=101)
     ap.add_argument("--size", type=int, default=2048)
     ap.add_argument("--threshold", type=float, default=0.3)
@@ -230,6 +230,8 @@ def main() -> None:
                        "overlap": (not args.forward_only) and (not args.no_overlap)},
             "roofline": {"bound": "mfma", "kernel": ("conv_igemm_split_kernel (implicit-GEMM conv, f32 operands as 3 bf16 planes, 6 bf16 MFMAs "
                                                      "per product; peak = bf16 dense peak / 6)" if args.precision == "f32x3" else
+                                                     "conv_igemm_split_kernel (implicit-GEMM conv, f32 operands as 2 scaled fp16 planes, 3 fp16 "
+                                                     "MFMAs per product; peak = fp16 dense peak / 3)" if args.precision == "f16x2" else
                                                      "conv_igemm_kernel (implicit-GEMM conv)") + ", all tile configs",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "launches_per_step": launches // max(args.steps, 1),

@@ -13,7 +13,7 @@ from pathlib import Path
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "csrc" / "libdeepemia_hip.so"
 
-F32, BF16, F32X3, BF16X2 = 0, 1, 2, 3
+F32, BF16, F32X3, BF16X2, F16X2 = 0, 1, 2, 3, 4
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 RES_NONE, RES_SAME, RES_UP2 = 0, 1, 2
 # stage codes of demia_mask_program (DEMIA_MOP_*)
@@ -37,6 +37,7 @@ class ConvDesc(C.Structure):
         ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
         ("dtype", C.c_int32), ("out_dtype", C.c_int32), ("act", C.c_int32), ("res_mode", C.c_int32),
         ("out_ld", C.c_int32), ("tile_hint", C.c_int32),
+        ("amax_in", C.c_void_p), ("amax_out", C.c_void_p),
     ]
 
 

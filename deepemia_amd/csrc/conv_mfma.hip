@@ -34,6 +34,8 @@ struct ConvP {
     int N, H, W, Cin, Ho, Wo, Cout, CoutPad, KH, KW, stride, pad;
     int act, res_mode, out_ld;
     int M, HoWo, ntn, nwg, ksteps, csteps, vec_ok;
+    const float* amax_in;   // f16x2: upper bound of |in| (device scalar) -> power-of-two operand scale
+    float* amax_out;        // any dtype: atomic max of |out| is accumulated here when non-NULL
 };
 
 template <typename T> struct Mma;
@@ -87,7 +89,8 @@ constexpr int ROWB = 144;  // bytes per LDS tile row: 128 B of K + 16 B pad
 
 // Epilogue shared by the conv kernels: accumulators -> LDS (f32) -> scale/bias/residual/activation on 16-byte rows.
 template <typename TO, int BM, int BN, int TM, int TN>
-__device__ __forceinline__ void conv_epilogue(const ConvP& p, char* smem, f32x16 (&acc)[TM][TN], int a_row0, int b_row0, int m0, int n0) {
+__device__ __forceinline__ void conv_epilogue(const ConvP& p, char* smem, f32x16 (&acc)[TM][TN], int a_row0, int b_row0, int m0, int n0,
+                                              float post = 1.0f) {
     constexpr int EROW = BN * 4 + 16;          // epilogue LDS row (f32) + pad
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -134,10 +137,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, char* smem, f32x16
                 for (int r = 0; r < 16; ++r) {
                     const int row = a_row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     const int col = b_row0 + j * 32 + (lane & 31);
-                    e[row * EF + col] = acc[i][j][r];
+                    e[row * EF + col] = acc[i][j][r] * post;
                 }
     }
     __syncthreads();
+    float vmax = 0.f;
     {
         TO* __restrict__ out = reinterpret_cast<TO*>(p.out);
         if (co < p.Cout) {
@@ -177,7 +181,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, char* smem, f32x16
                             if (co + q < p.Cout) v[q] += to_f32<TO>(res[ridx + q]);
                     }
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = apply_act(v[q], p.act);
+                    for (int q = 0; q < 4; ++q) {
+                        v[q] = apply_act(v[q], p.act);
+                        if (co + q < p.Cout) vmax = fmaxf(vmax, fabsf(v[q]));
+                    }
                     TO* o = out + (long)m * p.out_ld + co;
                     if (p.vec_ok) {
                         store4<TO>(o, v);
@@ -189,6 +196,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, char* smem, f32x16
                 }
             }
         }
+    }
+    if (p.amax_out) {
+        // |out| bound for the next layer's operand scale: wave max, one atomic per wave (non-negative floats order
+        // like their bit patterns)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off));
+        if (lane == 0 && vmax > 0.f) atomicMax(reinterpret_cast<unsigned int*>(p.amax_out), __float_as_uint(vmax));
     }
 }
 
@@ -339,15 +353,24 @@ __device__ __forceinline__ void split3(float x, bf16_t& h, bf16_t& m, bf16_t& l)
     l = (bf16_t)r2;
 }
 
-__device__ __forceinline__ f32x16 mma_bf16(const uint4& a, const uint4& b, f32x16 c) {
+template <bool F16>
+__device__ __forceinline__ f32x16 mma_planes(const uint4& a, const uint4& b, f32x16 c) {
+    if (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(&a), *reinterpret_cast<const f16x8*>(&b), c, 0, 0, 0);
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&a), *reinterpret_cast<const bf16x8*>(&b), c, 0, 0, 0);
 }
 
+// F16 ("f16x2", NP = 2): the planes are fp16 -- x = x1 + x2 with x1 = half(x * s), x2 = half(x * s - x1): 2 x 11 = 22
+// significand bits, representation error <= 2^-22 |x| and the dropped x2 * y2 <= 2^-22 |xy|, i.e. an f32-sized error
+// from THREE MFMAs per product.  fp16 has 5 exponent bits, so both operands are brought into range by exact
+// power-of-two scales: the weights per output channel on the host (folded into `scale`), the activations per tensor
+// with s = 2^(13 - ilogb(amax_in)), amax_in being the |.| bound that the producing layer's epilogue accumulated
+// (elements below 2^-11 of the tensor maximum lose relative, not absolute, accuracy: <= 2^-38 of the maximum).
 // NP = 3: "f32x3" as above.  NP = 2 ("bf16x2"): two planes and the three products a1b1, a1b2, a2b1 -- 16 significand
 // bits per operand, dropped terms <= 3 * 2^-16 |ab|: 256 x less exact than f32, 256 x more exact than plain bf16, at half
 // the matrix work of f32x3 (an opt-in speed mode; the default stays f32x3).
-template <typename TO, int WM, int WN, int TM, int TN, int NP = 3>
+template <typename TO, int WM, int WN, int TM, int TN, int NP = 3, bool F16 = false>
 __global__ __launch_bounds__(256) void conv_igemm_split_kernel(const ConvP p) {
+    static_assert(!F16 || NP == 2, "fp16 planes come in pairs");
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
     constexpr int BK = 32;
@@ -365,6 +388,16 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(const ConvP p) {
     const float* __restrict__ in = reinterpret_cast<const float*>(p.in);
     const bf16_t* __restrict__ wt = reinterpret_cast<const bf16_t*>(p.w);
 
+    float a_scale = 1.f, post = 1.f;
+    if (F16 && p.amax_in) {
+        const float am = *p.amax_in;
+        if (am > 0.f && am < 3.0e38f) {
+            int e = 13 - ilogbf(am);
+            e = e < -60 ? -60 : (e > 60 ? 60 : e);
+            a_scale = ldexpf(1.f, e);
+            post = ldexpf(1.f, -e);
+        }
+    }
     const int chunk = tid & 7, lrow = tid >> 3;
     long a_base[AV];
     int a_hi0[AV], a_wi0[AV];
@@ -424,13 +457,25 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(const ConvP p) {
 #pragma unroll
         for (int i = 0; i < AV; ++i) {
             const float* f = reinterpret_cast<const float*>(&ra[i]);
-            bf16x4 h, m, l;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { bf16_t a, b, c; split3(f[q], a, b, c); h[q] = a; m[q] = b; l[q] = c; }
             char* dst = smem + (lrow + 32 * i) * ROWS3 + chunk * 8;
-            *reinterpret_cast<bf16x4*>(dst) = h;
-            *reinterpret_cast<bf16x4*>(dst + PLANE_A) = m;
-            if (NP == 3) *reinterpret_cast<bf16x4*>(dst + 2 * PLANE_A) = l;
+            if (F16) {
+                f16x4 h, l;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float x = f[q] * a_scale;
+                    h[q] = (_Float16)x;
+                    l[q] = (_Float16)(x - (float)h[q]);
+                }
+                *reinterpret_cast<f16x4*>(dst) = h;
+                *reinterpret_cast<f16x4*>(dst + PLANE_A) = l;
+            } else {
+                bf16x4 h, m, l;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { bf16_t a, b, c; split3(f[q], a, b, c); h[q] = a; m[q] = b; l[q] = c; }
+                *reinterpret_cast<bf16x4*>(dst) = h;
+                *reinterpret_cast<bf16x4*>(dst + PLANE_A) = m;
+                if (NP == 3) *reinterpret_cast<bf16x4*>(dst + 2 * PLANE_A) = l;
+            }
         }
 #pragma unroll
         for (int j = 0; j < BVT; ++j) *reinterpret_cast<uint4*>(smem + b_lds[j]) = rb[j];
@@ -471,13 +516,13 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(const ConvP p) {
                 for (int j = 0; j < TN; ++j) {
                     f32x16 c = acc[i][j];
                     if (NP == 3) {
-                        c = mma_bf16(fa[0][i], fb[NP - 1][j], c);   // smallest terms first
-                        c = mma_bf16(fa[1][i], fb[1][j], c);
-                        c = mma_bf16(fa[NP - 1][i], fb[0][j], c);
+                        c = mma_planes<F16>(fa[0][i], fb[NP - 1][j], c);   // smallest terms first
+                        c = mma_planes<F16>(fa[1][i], fb[1][j], c);
+                        c = mma_planes<F16>(fa[NP - 1][i], fb[0][j], c);
                     }
-                    c = mma_bf16(fa[0][i], fb[1][j], c);
-                    c = mma_bf16(fa[1][i], fb[0][j], c);
-                    c = mma_bf16(fa[0][i], fb[0][j], c);
+                    c = mma_planes<F16>(fa[0][i], fb[1][j], c);
+                    c = mma_planes<F16>(fa[1][i], fb[0][j], c);
+                    c = mma_planes<F16>(fa[0][i], fb[0][j], c);
                     acc[i][j] = c;
                 }
         }
@@ -485,7 +530,7 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(const ConvP p) {
         if (more) store_step();
         __syncthreads();
     }
-    conv_epilogue<TO, BM, BN, TM, TN>(p, smem, acc, a_row0, b_row0, m0, n0);
+    conv_epilogue<TO, BM, BN, TM, TN>(p, smem, acc, a_row0, b_row0, m0, n0, post);
 }
 
 // 128 x 128 or 64 x 128 tiles for the split kernels: the workgroups of a CU share its matrix pipes, so a launch lasts as
@@ -498,14 +543,14 @@ inline bool prefer_half_tile(long blocks128, long blocks64) {
     return 0.93 * balance(blocks64) > balance(blocks128);
 }
 
-template <typename TO, int WM, int WN, int TM, int TN, int NP = 3>
+template <typename TO, int WM, int WN, int TM, int TN, int NP = 3, bool F16 = false>
 int launch_split_cfg(ConvP p, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int stage = NP * (BM + BN) * ROWS3, epi = BM * (BN * 4 + 16);
     constexpr int smem = stage > epi ? stage : epi;      // one tile stage, re-used by the epilogue
     p.ntn = cdiv(p.CoutPad, BN);
     p.nwg = p.ntn * cdiv(p.M, BM);
-    auto k = conv_igemm_split_kernel<TO, WM, WN, TM, TN, NP>;
+    auto k = conv_igemm_split_kernel<TO, WM, WN, TM, TN, NP, F16>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -551,11 +596,12 @@ int launch_typed(ConvP p, int bn, hipStream_t st) {
 
 extern "C" int demia_conv2d_nhwc(const demia_conv_desc* d, void* stream) {
     DEMIA_REQUIRE(d && d->in && d->w && d->out, "null pointer");
-    DEMIA_REQUIRE(d->dtype == DEMIA_F32 || d->dtype == DEMIA_BF16 || d->dtype == DEMIA_F32X3 || d->dtype == DEMIA_BF16X2, "dtype");
+    DEMIA_REQUIRE(d->dtype == DEMIA_F32 || d->dtype == DEMIA_BF16 || d->dtype == DEMIA_F32X3 || d->dtype == DEMIA_BF16X2 ||
+                  d->dtype == DEMIA_F16X2, "dtype");
     DEMIA_REQUIRE(d->out_dtype == DEMIA_F32 || d->out_dtype == DEMIA_BF16, "out_dtype");
     const int bk = d->dtype == DEMIA_BF16 ? 64 : 32;
-    DEMIA_REQUIRE((d->dtype != DEMIA_F32X3 && d->dtype != DEMIA_BF16X2) || (d->CoutPad % 64 == 0 && d->out_dtype == DEMIA_F32),
-                  "f32x3 / bf16x2 need CoutPad % 64 == 0, f32 output");
+    DEMIA_REQUIRE((d->dtype != DEMIA_F32X3 && d->dtype != DEMIA_BF16X2 && d->dtype != DEMIA_F16X2) ||
+                  (d->CoutPad % 64 == 0 && d->out_dtype == DEMIA_F32), "f32x3 / bf16x2 / f16x2 need CoutPad % 64 == 0, f32 output");
     DEMIA_REQUIRE(d->Cin > 0 && d->Cin % bk == 0, "Cin must be a multiple of 64 (bf16) / 32 (f32)");
     DEMIA_REQUIRE(d->CoutPad >= d->Cout && d->CoutPad % 32 == 0, "CoutPad");
     DEMIA_REQUIRE(d->KH > 0 && d->KW > 0 && d->stride > 0 && d->pad >= 0, "kernel geometry");
@@ -580,6 +626,14 @@ extern "C" int demia_conv2d_nhwc(const demia_conv_desc* d, void* stream) {
     int bn = d->tile_hint;
     if (bn != 128 && bn != 64 && bn != 32) bn = d->CoutPad >= 128 ? 128 : (d->CoutPad >= 64 ? 64 : 32);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    p.amax_in = d->amax_in; p.amax_out = d->amax_out;
+    if (d->dtype == DEMIA_F16X2) {
+        if (d->CoutPad % 128 != 0) return launch_split_cfg<float, 4, 1, 1, 2, 2, true>(p, st);
+        const long blocks128 = (long)cdiv(p.M, 128) * cdiv(p.CoutPad, 128);
+        if (prefer_half_tile(blocks128, (long)cdiv(p.M, 64) * cdiv(p.CoutPad, 128)))
+            return launch_split_cfg<float, 2, 2, 1, 2, 2, true>(p, st);
+        return launch_split_cfg<float, 2, 2, 2, 2, 2, true>(p, st);
+    }
     if (d->dtype == DEMIA_BF16X2) {
         if (d->CoutPad % 128 != 0) return launch_split_cfg<float, 4, 1, 1, 2, 2>(p, st);
         const long blocks128 = (long)cdiv(p.M, 128) * cdiv(p.CoutPad, 128);

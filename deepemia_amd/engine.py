@@ -26,7 +26,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, BF16, BF16X2, F32, F32X3, RES_NONE, RES_SAME, RES_UP2
+from ._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, BF16, BF16X2, F16X2, F32, F32X3, RES_NONE, RES_SAME, RES_UP2
 
 RES_BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}
 PIXEL_MEAN = (103.530, 116.280, 123.675)
@@ -134,6 +134,20 @@ def tile_weight_planes(w3: torch.Tensor) -> torch.Tensor:
     return w3.reshape(npl, cout_pad // 64, 64, k // 32, 32).permute(1, 3, 0, 2, 4).contiguous()
 
 
+def split2_f16_scaled(w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """f16x2 weights: per output channel (dim 0) an exact power-of-two scale ``sw`` that brings max |w| into
+    [2^14, 2^15), then ``w * sw = h + l`` with h = half(w * sw), l = half(w * sw - h) (22 significand bits).
+    Returns (planes [2, ...] fp16, sw [Cout] f32); the caller divides the layer's output scale by ``sw``."""
+    w = w.to(torch.float32)
+    amax = w.abs().flatten(1).amax(dim=1)
+    _, ex = torch.frexp(amax)                       # amax = m * 2^ex, m in [0.5, 1)
+    sw = torch.ldexp(torch.ones_like(amax), 15 - ex)
+    ws = w * sw.view(-1, *([1] * (w.dim() - 1)))
+    h = ws.to(torch.float16)
+    l = (ws - h.to(torch.float32)).to(torch.float16)
+    return torch.stack([h, l], dim=0), sw
+
+
 def cell_anchor_table() -> np.ndarray:
     out = np.zeros((5, 3, 4), dtype=np.float32)
     for l, size in enumerate(ANCHOR_SIZES):
@@ -158,6 +172,7 @@ class ConvLayer:
     stride: int
     pad: int
     w3: Optional[torch.Tensor] = None   # f32x3 / bf16x2 mode: the three / two bf16 planes of w, tiled [CoutPad/64, ksteps, NP, 64, 32]
+    scale3: Optional[torch.Tensor] = None   # f16x2: the output scale divided by the per-channel weight scale
 
 
 @dataclass
@@ -192,9 +207,12 @@ class MaskRCNNEngine:
         self.min_size_test, self.max_size_test = int(min_size_test), int(max_size_test)
         if self.min_size_test < 32 or self.max_size_test < self.min_size_test:
             raise ValueError(f"min_size_test / max_size_test = {min_size_test} / {max_size_test}")
-        if precision not in ("f32", "f32x3", "bf16x2", "bf16"):
+        if precision not in ("f32", "f32x3", "f16x2", "bf16x2", "bf16"):
             raise ValueError("precision must be 'f32' (exact-f32 MFMA), 'f32x3' (f32 on the bf16 pipe, 3-way split), "
+                             "'f16x2' (f32 on the fp16 pipe, 2-way split with power-of-two operand scales), "
                              "'bf16x2' (16-bit operands on the bf16 pipe, 2-way split) or 'bf16'")
+        self._amax_buf: Optional[torch.Tensor] = None     # f16x2: per-forward pool of |activation| bounds
+        self._amax_i = 0
         self.dt = BF16 if precision == "bf16" else F32
         self.tdt = torch.bfloat16 if precision == "bf16" else torch.float32
         self._tables: Dict[Tuple[int, int], dict] = {}
@@ -232,9 +250,15 @@ class MaskRCNNEngine:
         if self.precision in ("f32x3", "bf16x2") and cout_pad % 64 == 0 and cin % 32 == 0:
             w3 = split3_bf16(wp.to(dev))                       # split on the device: same round-to-nearest casts
             w3 = tile_weight_planes(w3 if self.precision == "f32x3" else w3[:2])
+        scale3 = None
+        if self.precision == "f16x2" and cout_pad % 64 == 0 and cin % 32 == 0:
+            planes, sw = split2_f16_scaled(wp.to(dev))
+            w3 = tile_weight_planes(planes)
+            base = torch.ones(cout, dtype=torch.float32, device=dev) if scale is None else scale.to(dev)
+            scale3 = (base / sw[:cout]).contiguous()
         return ConvLayer(wp.to(dev, self.tdt).contiguous(),
                          None if scale is None else scale.to(dev).contiguous(),
-                         None if b is None else b.to(dev).contiguous(), cin, cout, cout_pad, kh, kw, stride, pad, w3)
+                         None if b is None else b.to(dev).contiguous(), cin, cout, cout_pad, kh, kw, stride, pad, w3, scale3)
 
     def _pack(self, sd):
         bu = "backbone.bottom_up."
@@ -307,10 +331,16 @@ class MaskRCNNEngine:
         if out is None:
             out = torch.empty((n, ho, wo, ld), dtype=odt, device=self.device)
         use3 = L.w3 is not None and odt == torch.float32
-        d = _lib.ConvDesc(_lib.ptr(x), _lib.ptr(L.w3 if use3 else L.w), _lib.ptr(L.scale), _lib.ptr(L.bias), _lib.ptr(residual),
-                          _lib.ptr(out), n, h, w, cin, ho, wo, L.cout, L.cout_pad, L.kh, L.kw, L.stride, L.pad,
-                          (F32X3 if L.w3.shape[2] == 3 else BF16X2) if use3 else self.dt, BF16 if odt == torch.bfloat16 else F32,
-                          act, res_mode, ld, tile_hint)
+        f16 = use3 and L.w3.dtype == torch.float16
+        kind = ("f16x2" if f16 else ("f32x3" if L.w3.shape[2] == 3 else "bf16x2")) if use3 else ("bf16" if self.dt == BF16 else "f32")
+        amax_in = self.amax_of(x) if f16 else None
+        amax_out = self._amax_slot() if self.precision == "f16x2" else None
+        d = _lib.ConvDesc(_lib.ptr(x), _lib.ptr(L.w3 if use3 else L.w), _lib.ptr(L.scale3 if f16 else L.scale), _lib.ptr(L.bias),
+                          _lib.ptr(residual), _lib.ptr(out), n, h, w, cin, ho, wo, L.cout, L.cout_pad, L.kh, L.kw, L.stride, L.pad,
+                          {"f16x2": F16X2, "f32x3": F32X3, "bf16x2": BF16X2}.get(kind, self.dt), BF16 if odt == torch.bfloat16 else F32,
+                          act, res_mode, ld, tile_hint, _lib.ptr(amax_in), _lib.ptr(amax_out))
+        if amax_out is not None:
+            out._amax = amax_out
         ev = self.conv_events
         if ev is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -322,9 +352,35 @@ class MaskRCNNEngine:
             osz = 2 if odt == torch.bfloat16 else 4
             nbytes = (n * h * w * cin * esz + L.cout_pad * L.kh * L.kw * cin * (2 * int(L.w3.shape[2]) if use3 else esz) + n * ho * wo * L.cout * osz +
                       (0 if residual is None else residual.numel() * osz))     # every operand once: the algorithmic traffic
-            ev.append((e0, e1, 2.0 * n * ho * wo * L.cout * L.kh * L.kw * cin,
-                       ("f32x3" if L.w3.shape[2] == 3 else "bf16x2") if use3 else ("bf16" if self.dt == BF16 else "f32"), nbytes))
+            ev.append((e0, e1, 2.0 * n * ho * wo * L.cout * L.kh * L.kw * cin, kind, nbytes))
         return out
+
+    # f16x2: every activation tensor carries a device scalar bounding |x| (``_amax``), accumulated by the producing conv's
+    # epilogue or derived from its inputs' bounds; the consuming conv turns it into a power-of-two operand scale.
+    def _amax_slot(self) -> torch.Tensor:
+        if self._amax_buf is None or self._amax_i >= self._amax_buf.numel():
+            self._amax_buf = torch.zeros(512, dtype=torch.float32, device=self.device)
+            self._amax_i = 0
+        slot = self._amax_buf[self._amax_i:self._amax_i + 1]
+        self._amax_i += 1
+        return slot
+
+    def amax_of(self, x: torch.Tensor) -> torch.Tensor:
+        am = getattr(x, "_amax", None)
+        if am is None:                                  # not produced by a tracked kernel: one reduction pass
+            mn, mx = torch.aminmax(x)
+            am = torch.maximum(mx, -mn).to(torch.float32).reshape(1)
+            x._amax = am
+        return am
+
+    @staticmethod
+    def view_as(x: torch.Tensor, *shape) -> torch.Tensor:
+        """``x.view(shape)`` that keeps the |x| bound attached."""
+        y = x.view(*shape)
+        am = getattr(x, "_amax", None)
+        if am is not None:
+            y._amax = am
+        return y
 
     def _resize_tables(self, h: int, w: int):
         key = (h, w)
@@ -436,11 +492,13 @@ class MaskRCNNEngine:
         d.N, d.R, d.C, d.P, d.dtype = b, r, 256, P, self.dt
         d.boxes, d.count, d.out = _lib.ptr(boxes), _lib.ptr(count), _lib.ptr(out)
         _lib.check(self.lib.demia_roi_align(C.byref(d), self._stream()), "demia_roi_align")
+        if self.precision == "f16x2":                  # bilinear taps and bin averages are convex combinations
+            out._amax = torch.cat([self.amax_of(feats[n]) for n in ("p2", "p3", "p4", "p5")]).amax().reshape(1)
         return out
 
     def box_head(self, pooled: torch.Tensor) -> torch.Tensor:
         b, r = pooled.shape[:2]
-        x = pooled.view(b * r, 1, 1, 12544)
+        x = self.view_as(pooled, b * r, 1, 1, 12544)
         x = self.conv(x, self.fc1, act=ACT_RELU)
         x = self.conv(x, self.fc2, act=ACT_RELU)
         ld = (5 * self.K + 1 + 3) // 4 * 4
@@ -461,10 +519,10 @@ class MaskRCNNEngine:
 
     def mask_head(self, mpooled: torch.Tensor) -> torch.Tensor:
         b, dd = mpooled.shape[:2]
-        x = mpooled.view(b * dd, 14, 14, 256)
+        x = self.view_as(mpooled, b * dd, 14, 14, 256)
         for L in self.mask_fcn:
             x = self.conv(x, L, act=ACT_RELU)
-        x = self.conv(x.view(b * dd * 196, 1, 1, 256), self.deconv, act=ACT_RELU)        # [.., 1024] = (dy,dx,co)
+        x = self.conv(self.view_as(x, b * dd * 196, 1, 1, 256), self.deconv, act=ACT_RELU)        # [.., 1024] = (dy,dx,co)
         x = self.conv(x.view(b * dd * 196 * 4, 1, 1, 256), self.mask_pred, act=ACT_SIGMOID,
                       out_dtype=torch.float32, out_ld=(self.K + 3) // 4 * 4)
         return x  # [(i*196 + cell)*4 + sub, 1, 1, ld] f32 probabilities
@@ -488,6 +546,7 @@ class MaskRCNNEngine:
         assert images.dtype == torch.uint8 and images.dim() == 4 and images.shape[3] == 3
         images = images.contiguous()
         b, h, w, _ = images.shape
+        self._amax_buf = None            # f16x2: a fresh (zeroed) pool of |activation| bounds per forward
         xin, newh, neww, ph, pw = self.preprocess(images)
         feats = self.backbone(xin, ph, pw)
         props, pscores, pcount = self.rpn(feats, newh, neww)

@@ -36,6 +36,7 @@ extern "C" {
 #define DEMIA_BF16 1
 #define DEMIA_F32X3 2   /* conv only: f32 activations, weights pre-split into 3 bf16 planes, tiled (see demia_conv2d_nhwc) */
 #define DEMIA_BF16X2 3  /* conv only: f32 activations, weights as 2 bf16 planes (same tiling): 16-bit operands */
+#define DEMIA_F16X2 4   /* conv only: f32 activations, weights as 2 fp16 planes (same tiling), power-of-two operand scales */
 
 #define DEMIA_ACT_NONE 0
 #define DEMIA_ACT_RELU 1
@@ -66,7 +67,14 @@ const char* demia_build_arch(void);   /* "gfx950" */
  * Layout of `w` for these two dtypes (NP = 3 / 2 planes, x = x1 + x2 + x3 with x1 = bf16(x), x2 = bf16(x - x1), ...):
  *   [CoutPad / 64][KH*KW*Cin / 32][NP][64][32] bf16,  K = (kh, kw, cin) walked in steps of 32
  * i.e. the 64-channel x 32-k piece of one plane that a K-step reads is 4 KiB contiguous (whole 128-byte lines per
- * wave load).  ABI version 3 (version 2 took row-major [NP][CoutPad][K] planes).  */
+ * wave load).  ABI version 3 (version 2 took row-major [NP][CoutPad][K] planes).
+ * DEMIA_F16X2: two fp16 planes per operand (x1 = half(x), x2 = half(x - x1): 22 significand bits, error <= 3 * 2^-22
+ * per product -- an f32-sized error from three MFMAs).  fp16 has five exponent bits, so the caller brings the weights
+ * into range with an exact power of two per output channel BEFORE splitting them (and divides `scale` by it), and
+ * the kernel scales the activations by 2^(13 - ilogb(*amax_in)); `amax_in` is a device scalar holding an upper bound
+ * of |in| (NULL: no scaling, |in| must stay below 6e4).  `amax_out` (any dtype, may be NULL): device scalar into
+ * which the kernel accumulates max |out| with an atomic max -- zero it before the launch; it is the next layer's
+ * `amax_in`.  */
 typedef struct demia_conv_desc {
     const void* in;
     const void* w;
@@ -81,6 +89,8 @@ typedef struct demia_conv_desc {
     int32_t act, res_mode;
     int32_t out_ld;          /* elements between consecutive output pixels (>= Cout); 0 -> Cout */
     int32_t tile_hint;       /* 0 = auto; else BN in {128, 64, 32} */
+    const float* amax_in;    /* DEMIA_F16X2: device scalar, upper bound of |in| (see above); else ignored */
+    float* amax_out;         /* NULL or device scalar: max |out| is accumulated (atomic max) */
 } demia_conv_desc;
 int demia_conv2d_nhwc(const demia_conv_desc* d, void* stream);
 

@@ -35,7 +35,8 @@ def env(gpu_device):
     ref = R.predict(img, sd, 50, THR, return_intermediates=True)
     eng = MaskRCNNEngine(sd, 50, K, THR, gpu_device, "f32")
     eng3 = MaskRCNNEngine(sd, 50, K, THR, gpu_device, "f32x3")   # f32 operands on the bf16 pipe: same parity bar
-    return dict(sd=sd, img=img, ref=ref, eng=eng, f32=eng, f32x3=eng3, R=R, synth=synth, dev=gpu_device)
+    eng2 = MaskRCNNEngine(sd, 50, K, THR, gpu_device, "f16x2")   # f32 operands on the fp16 pipe (2 scaled planes): same bar
+    return dict(sd=sd, img=img, ref=ref, eng=eng, f32=eng, f32x3=eng3, f16x2=eng2, R=R, synth=synth, dev=gpu_device)
 
 
 def nhwc(t):
@@ -83,7 +84,7 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("prec", ["f32", "f32x3", "bf16x2", "bf16"])
+@pytest.mark.parametrize("prec", ["f32", "f32x3", "f16x2", "bf16x2", "bf16"])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_igemm_vs_torch(env, case, prec):
     from deepemia_amd import engine as E
@@ -91,7 +92,7 @@ def test_conv_igemm_vs_torch(env, case, prec):
 
     cin, cout, k, stride, pad, h, w, n, relu, res = case
     g = torch.Generator().manual_seed(cin * 131 + cout * 7 + k)
-    eng = env["eng"] if prec != "bf16" else E.MaskRCNNEngine.__new__(E.MaskRCNNEngine)
+    eng = (env["f16x2"] if prec == "f16x2" else env["eng"]) if prec != "bf16" else E.MaskRCNNEngine.__new__(E.MaskRCNNEngine)
     if prec == "bf16":
         eng.__dict__.update(env["eng"].__dict__)
         eng.dt, eng.tdt, eng.precision = E.BF16, torch.bfloat16, "bf16"
@@ -124,6 +125,22 @@ def test_conv_igemm_vs_torch(env, case, prec):
         if cout_pad % 64 or cin % 32:
             pytest.skip("shape stays on the exact-f32 kernel")
         L.w3 = E.tile_weight_planes(E.split3_bf16(wp).to(dev)[: 3 if prec == "f32x3" else 2])
+    if prec == "f16x2":
+        # two fp16 planes per operand with exact power-of-two scales (weights per channel here, activations from the
+        # |x| bound inside the kernel), three MFMAs per product: same tolerance as the exact-f32 kernel
+        if cout_pad % 64 or cin % 32:
+            pytest.skip("shape stays on the exact-f32 kernel")
+        planes, sw = E.split2_f16_scaled(wp.to(dev))
+        L.w3 = E.tile_weight_planes(planes)
+        L.scale3 = (scale.to(dev) / sw[:cout]).contiguous()
+        x = x * float(10.0 ** ((cin % 7) - 3))          # exercise the activation scale: |x| from 1e-3 to 1e3
+        y = F.conv2d(x, wt, None, stride=stride, padding=pad) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)
+        if res == 1:
+            y = y + residual
+        elif res == 2:
+            y = y + F.interpolate(residual, scale_factor=2.0, mode="nearest")[:, :, :ho, :wo]
+        if relu:
+            y = F.relu(y)
     rdev = None if residual is None else nhwc(residual).to(dev, eng.tdt)
     if prec == "bf16" and residual is not None:
         # the reference must see the rounded residual as well
@@ -136,12 +153,15 @@ def test_conv_igemm_vs_torch(env, case, prec):
     out = eng.conv(nhwc(x).to(dev, eng.tdt), L, act=ACT_RELU if relu else ACT_NONE, residual=rdev,
                    res_mode=(RES_NONE, RES_SAME, RES_UP2)[res], out_dtype=odt)
     got = out.float().cpu().permute(0, 3, 1, 2)
-    tol = {"f32": 2e-5, "f32x3": 2e-5, "bf16x2": 2e-4, "bf16": 3e-2}[prec]
+    tol = {"f32": 2e-5, "f32x3": 2e-5, "f16x2": 2e-5, "bf16x2": 2e-4, "bf16": 3e-2}[prec]
+    if prec == "f16x2":
+        # the epilogue's |out| bound (the next layer's operand scale) is the exact maximum
+        assert float(out._amax.item()) == float(out.abs().max().item())
     err = float((got - y).abs().max() / y.abs().max())
     assert err <= tol, err
 
 
-@pytest.mark.parametrize("prec", ["f32", "f32x3"])
+@pytest.mark.parametrize("prec", ["f32", "f32x3", "f16x2"])
 def test_backbone_fpn_features_f32(env, prec):
     eng, d = env[prec], env["ref"]["dbg"]
     x = torch.from_numpy(env["img"])[None].to(env["dev"])
@@ -291,7 +311,7 @@ def test_unpack_and_area_bbox_bit_exact(env):
         assert bbox[i].cpu().tolist() == exp
 
 
-@pytest.mark.parametrize("prec", ["f32", "f32x3"])
+@pytest.mark.parametrize("prec", ["f32", "f32x3", "f16x2"])
 def test_end_to_end_f32_matches_oracle(env, prec):
     from deepemia_amd.predictor import Predictor
 
