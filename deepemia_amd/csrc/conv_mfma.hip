@@ -21,6 +21,9 @@
 // Detectron2 0.6 `GeneralizedRCNN.inference` under `predictor(image)`
 // (reference src/functions/inference.py:1395,1398,1507,1669; src/data/models.py:107).
 #include "common.h"
+#ifndef F16_BK
+#define F16_BK 64
+#endif
 
 namespace {
 
@@ -202,7 +205,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, char* smem, f32x16
         // like their bit patterns)
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off));
-        if (lane == 0 && vmax > 0.f) atomicMax(reinterpret_cast<unsigned int*>(p.amax_out), __float_as_uint(vmax));
+        // the bound only grows, so a (possibly stale) read that already covers this wave's maximum makes the atomic
+        // unnecessary: all but the first few waves of a launch skip it (40 000 atomics on one word cost more than a
+        // short-K layer's whole launch)
+        if (lane == 0 && vmax > *reinterpret_cast<volatile const float*>(p.amax_out))
+            atomicMax(reinterpret_cast<unsigned int*>(p.amax_out), __float_as_uint(vmax));
     }
 }
 
@@ -343,7 +350,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
 // is split in registers on its way to LDS; weights are split and tiled once on the host
 // ([CoutPad / 64][ksteps][3][64][32] bf16, see the B loads below).
 // K-step = 32 elements; LDS rows are 64 B + 16 B pad (80 B: conflict-free ds_read_b128); 2 stages x 3 planes.
-constexpr int ROWS3 = 80;
 
 __device__ __forceinline__ void split3(float x, bf16_t& h, bf16_t& m, bf16_t& l) {
     h = (bf16_t)x;
@@ -373,11 +379,15 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(const ConvP p) {
     static_assert(!F16 || NP == 2, "fp16 planes come in pairs");
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
-    constexpr int BK = 32;
-    constexpr int AV = BM / 32;                 // f32 vectors (4 elements) of A per thread per K-step
-    constexpr int BVT = NP * BN / 64;           // 16-B bf16 vectors (8 elements) of the B planes per thread per K-step
-    constexpr int PLANE_A = BM * ROWS3, PLANE_B = BN * ROWS3;
-    static_assert((NP * BN) % 64 == 0, "NP * BN must be a multiple of 64");
+    constexpr int BK = F16 ? F16_BK : 32;           // f16x2 has half the MFMAs per element: twice the K-step keeps 48 per barrier pair
+    constexpr int ROWS = BK * 2 + 16;           // LDS row: BK 2-byte elements + 16 B pad (80 / 144 B: conflict-free ds_read_b128)
+    constexpr int CH = BK / 4;                  // 16-B f32 chunks per A row
+    constexpr int RPP = 256 / CH;               // A rows per pass of the 256 threads
+    constexpr int AV = BM / RPP;                // f32 vectors (4 elements) of A per thread per K-step
+    constexpr int BVR = BK / 8;                 // 16-B plane vectors (8 elements) per B row
+    constexpr int BVT = NP * BN * BVR / 256;    // ... of the B planes per thread per K-step
+    constexpr int PLANE_A = BM * ROWS, PLANE_B = BN * ROWS;
+    static_assert((NP * BN * BVR) % 256 == 0, "B tile must divide over the 256 threads");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -398,13 +408,13 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(const ConvP p) {
             post = ldexpf(1.f, -e);
         }
     }
-    const int chunk = tid & 7, lrow = tid >> 3;
+    const int chunk = tid % CH, lrow = tid / CH;
     long a_base[AV];
     int a_hi0[AV], a_wi0[AV];
     bool a_vm[AV];
 #pragma unroll
     for (int i = 0; i < AV; ++i) {
-        const int m = m0 + lrow + 32 * i;
+        const int m = m0 + lrow + RPP * i;
         a_vm[i] = m < p.M;
         const int mm = a_vm[i] ? m : 0;
         const int n = mm / p.HoWo;
@@ -414,8 +424,8 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(const ConvP p) {
         a_wi0[i] = wo * p.stride - p.pad;
         a_base[i] = (((long)n * p.H + a_hi0[i]) * p.W + a_wi0[i]) * p.Cin + chunk * 4;
     }
-    // Weight planes arrive TILED: [CoutPad / 64][ksteps][NP][64 rows][32 k] bf16 -- the 64 x 32 piece of one plane that a
-    // K-step needs is 4 KiB contiguous, so the B loads of a wave are whole 128-byte lines (row-major [CoutPad][K]
+    // Weight planes arrive TILED: [CoutPad / 64][ksteps][NP][64 rows][BK k] 2-byte elements -- the 64 x BK piece of one
+    // plane that a K-step needs is 4 / 8 KiB contiguous, so the B loads of a wave are whole 128-byte lines (row-major [CoutPad][K]
     // planes made every 16-lane group touch four half-used lines).
     long b_off[BVT];
     int b_lds[BVT];
@@ -423,13 +433,13 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(const ConvP p) {
 #pragma unroll
     for (int j = 0; j < BVT; ++j) {
         const int v = tid + 256 * j;
-        const int plane = v / (BN * 4), rem = v - plane * (BN * 4);
-        const int row = rem >> 2, c8 = rem & 3;
+        const int plane = v / (BN * BVR), rem = v - plane * (BN * BVR);
+        const int row = rem / BVR, c8 = rem % BVR;
         const int co = n0 + row;
         b_vm[j] = co < p.CoutPad;
         const int n64 = (b_vm[j] ? co : 0) >> 6;
-        b_off[j] = ((long)n64 * p.ksteps * NP + plane) * 2048 + (co & 63) * 32 + c8 * 8;
-        b_lds[j] = NP * PLANE_A + plane * PLANE_B + row * ROWS3 + c8 * 16;
+        b_off[j] = ((long)n64 * p.ksteps * NP + plane) * (64 * BK) + (co & 63) * BK + c8 * 8;
+        b_lds[j] = NP * PLANE_A + plane * PLANE_B + row * ROWS + c8 * 16;
     }
     long b_step = 0;
 
@@ -449,7 +459,7 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(const ConvP p) {
 #pragma unroll
         for (int j = 0; j < BVT; ++j)
             rb[j] = b_vm[j] ? *reinterpret_cast<const uint4*>(wt + b_off[j] + b_step) : make_uint4(0, 0, 0, 0);
-        b_step += NP * 2048;
+        b_step += NP * 64 * BK;
         c0 += BK;
         if (c0 >= p.Cin) { c0 = 0; if (++kw == p.KW) { kw = 0; ++kh; } }
     };
@@ -457,7 +467,7 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(const ConvP p) {
 #pragma unroll
         for (int i = 0; i < AV; ++i) {
             const float* f = reinterpret_cast<const float*>(&ra[i]);
-            char* dst = smem + (lrow + 32 * i) * ROWS3 + chunk * 8;
+            char* dst = smem + (lrow + RPP * i) * ROWS + chunk * 8;
             if (F16) {
                 f16x4 h, l;
 #pragma unroll
@@ -489,10 +499,10 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(const ConvP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int frag_off = (lane & 31) * ROWS3 + (lane >> 5) * 16;
+    const int frag_off = (lane & 31) * ROWS + (lane >> 5) * 16;
     const int a_row0 = wm * TM * 32, b_row0 = wn * TN * 32;
-    const char* sA = smem + a_row0 * ROWS3 + frag_off;
-    const char* sB = smem + NP * PLANE_A + b_row0 * ROWS3 + frag_off;
+    const char* sA = smem + a_row0 * ROWS + frag_off;
+    const char* sB = smem + NP * PLANE_A + b_row0 * ROWS + frag_off;
 
     load_step();
     store_step();
@@ -501,14 +511,14 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(const ConvP p) {
         const bool more = (s + 1) < p.ksteps;
         if (more) load_step();
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < BK / 16; ++kk) {
             uint4 fa[NP][TM], fb[NP][TN];
 #pragma unroll
             for (int q = 0; q < NP; ++q) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) fa[q][i] = *reinterpret_cast<const uint4*>(sA + q * PLANE_A + i * 32 * ROWS3 + kk * 32);
+                for (int i = 0; i < TM; ++i) fa[q][i] = *reinterpret_cast<const uint4*>(sA + q * PLANE_A + i * 32 * ROWS + kk * 32);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) fb[q][j] = *reinterpret_cast<const uint4*>(sB + q * PLANE_B + j * 32 * ROWS3 + kk * 32);
+                for (int j = 0; j < TN; ++j) fb[q][j] = *reinterpret_cast<const uint4*>(sB + q * PLANE_B + j * 32 * ROWS + kk * 32);
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -546,7 +556,7 @@ inline bool prefer_half_tile(long blocks128, long blocks64) {
 template <typename TO, int WM, int WN, int TM, int TN, int NP = 3, bool F16 = false>
 int launch_split_cfg(ConvP p, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int stage = NP * (BM + BN) * ROWS3, epi = BM * (BN * 4 + 16);
+    constexpr int stage = NP * (BM + BN) * ((F16 ? F16_BK : 32) * 2 + 16), epi = BM * (BN * 4 + 16);
     constexpr int smem = stage > epi ? stage : epi;      // one tile stage, re-used by the epilogue
     p.ntn = cdiv(p.CoutPad, BN);
     p.nwg = p.ntn * cdiv(p.M, BM);
@@ -599,10 +609,10 @@ extern "C" int demia_conv2d_nhwc(const demia_conv_desc* d, void* stream) {
     DEMIA_REQUIRE(d->dtype == DEMIA_F32 || d->dtype == DEMIA_BF16 || d->dtype == DEMIA_F32X3 || d->dtype == DEMIA_BF16X2 ||
                   d->dtype == DEMIA_F16X2, "dtype");
     DEMIA_REQUIRE(d->out_dtype == DEMIA_F32 || d->out_dtype == DEMIA_BF16, "out_dtype");
-    const int bk = d->dtype == DEMIA_BF16 ? 64 : 32;
+    const int bk = d->dtype == DEMIA_BF16 ? 64 : (d->dtype == DEMIA_F16X2 ? F16_BK : 32);
     DEMIA_REQUIRE((d->dtype != DEMIA_F32X3 && d->dtype != DEMIA_BF16X2 && d->dtype != DEMIA_F16X2) ||
                   (d->CoutPad % 64 == 0 && d->out_dtype == DEMIA_F32), "f32x3 / bf16x2 / f16x2 need CoutPad % 64 == 0, f32 output");
-    DEMIA_REQUIRE(d->Cin > 0 && d->Cin % bk == 0, "Cin must be a multiple of 64 (bf16) / 32 (f32)");
+    DEMIA_REQUIRE(d->Cin > 0 && d->Cin % bk == 0, "Cin must be a multiple of 64 (bf16, f16x2) / 32 (f32, f32x3, bf16x2)");
     DEMIA_REQUIRE(d->CoutPad >= d->Cout && d->CoutPad % 32 == 0, "CoutPad");
     DEMIA_REQUIRE(d->KH > 0 && d->KW > 0 && d->stride > 0 && d->pad >= 0, "kernel geometry");
     DEMIA_REQUIRE(d->Ho == (d->H + 2 * d->pad - d->KH) / d->stride + 1, "Ho");

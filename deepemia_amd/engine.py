@@ -17,6 +17,8 @@ Layout in HBM (per batch of B equally sized images):
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 import math
 from dataclasses import dataclass
@@ -124,14 +126,14 @@ def split3_bf16(w: torch.Tensor) -> torch.Tensor:
     return torch.stack([h, m, l], dim=0)
 
 
-def tile_weight_planes(w3: torch.Tensor) -> torch.Tensor:
-    """[NP, CoutPad, KH, KW, Cin] bf16 planes -> the layout ``demia_conv2d_nhwc`` reads for DEMIA_F32X3 / DEMIA_BF16X2:
-    [CoutPad / 64, ksteps, NP, 64, 32] with K = (kh, kw, cin) walked in steps of 32, so that the 64 x 32 piece of one
-    plane that a K-step needs is 4 KiB contiguous (``include/deepemia_hip.h``)."""
+def tile_weight_planes(w3: torch.Tensor, bk: int = 32) -> torch.Tensor:
+    """[NP, CoutPad, KH, KW, Cin] 2-byte planes -> the layout ``demia_conv2d_nhwc`` reads for DEMIA_F32X3 / DEMIA_BF16X2
+    (bk = 32) and DEMIA_F16X2 (bk = 64): [CoutPad / 64, ksteps, NP, 64, bk] with K = (kh, kw, cin) walked in steps of
+    bk, so that the 64 x bk piece of one plane that a K-step needs is contiguous (``include/deepemia_hip.h``)."""
     npl, cout_pad = int(w3.shape[0]), int(w3.shape[1])
     k = w3[0, 0].numel()
-    assert cout_pad % 64 == 0 and k % 32 == 0, (cout_pad, k)
-    return w3.reshape(npl, cout_pad // 64, 64, k // 32, 32).permute(1, 3, 0, 2, 4).contiguous()
+    assert cout_pad % 64 == 0 and k % bk == 0, (cout_pad, k, bk)
+    return w3.reshape(npl, cout_pad // 64, 64, k // bk, bk).permute(1, 3, 0, 2, 4).contiguous()
 
 
 def split2_f16_scaled(w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -251,9 +253,10 @@ class MaskRCNNEngine:
             w3 = split3_bf16(wp.to(dev))                       # split on the device: same round-to-nearest casts
             w3 = tile_weight_planes(w3 if self.precision == "f32x3" else w3[:2])
         scale3 = None
-        if self.precision == "f16x2" and cout_pad % 64 == 0 and cin % 32 == 0:
+        f16_bk = int(os.environ.get("DEEPEMIA_F16_BK", "64"))
+        if self.precision == "f16x2" and cout_pad % 64 == 0 and cin % f16_bk == 0:
             planes, sw = split2_f16_scaled(wp.to(dev))
-            w3 = tile_weight_planes(planes)
+            w3 = tile_weight_planes(planes, f16_bk)
             base = torch.ones(cout, dtype=torch.float32, device=dev) if scale is None else scale.to(dev)
             scale3 = (base / sw[:cout]).contiguous()
         return ConvLayer(wp.to(dev, self.tdt).contiguous(),
