@@ -381,9 +381,10 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(const ConvP p) {
     constexpr int BN = WN * TN * 32;
     constexpr int BK = F16 ? F16_BK : 32;           // f16x2 has half the MFMAs per element: twice the K-step keeps 48 per barrier pair
     constexpr int ROWS = BK * 2 + 16;           // LDS row: BK 2-byte elements + 16 B pad (80 / 144 B: conflict-free ds_read_b128)
-    constexpr int CH = BK / 4;                  // 16-B f32 chunks per A row
+    constexpr int EPT = F16 ? 8 : 4;            // A elements per thread per row pass (f16x2: one 16-byte LDS write per plane)
+    constexpr int CH = BK / EPT;                // thread chunks per A row
     constexpr int RPP = 256 / CH;               // A rows per pass of the 256 threads
-    constexpr int AV = BM / RPP;                // f32 vectors (4 elements) of A per thread per K-step
+    constexpr int AV = BM / RPP;                // row passes per K-step (EPT / 4 f32 vectors each)
     constexpr int BVR = BK / 8;                 // 16-B plane vectors (8 elements) per B row
     constexpr int BVT = NP * BN * BVR / 256;    // ... of the B planes per thread per K-step
     constexpr int PLANE_A = BM * ROWS, PLANE_B = BN * ROWS;
@@ -422,7 +423,7 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(const ConvP p) {
         const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
         a_hi0[i] = ho * p.stride - p.pad;
         a_wi0[i] = wo * p.stride - p.pad;
-        a_base[i] = (((long)n * p.H + a_hi0[i]) * p.W + a_wi0[i]) * p.Cin + chunk * 4;
+        a_base[i] = (((long)n * p.H + a_hi0[i]) * p.W + a_wi0[i]) * p.Cin + chunk * EPT;
     }
     // Weight planes arrive TILED: [CoutPad / 64][ksteps][NP][64 rows][BK k] 2-byte elements -- the 64 x BK piece of one
     // plane that a K-step needs is 4 / 8 KiB contiguous, so the B loads of a wave are whole 128-byte lines (row-major [CoutPad][K]
@@ -446,7 +447,7 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(const ConvP p) {
     // ONE LDS stage (61 KiB for 128x128) so that TWO workgroups share a CU: while one is in its barrier / split /
     // store phase the other one's MFMAs keep the matrix pipe busy (a K-step is only 48 MFMAs, ~1.5k cycles, far
     // too short to hide an HBM round trip behind a single wave per SIMD).  The next tile waits in registers.
-    uint4 ra[AV], rb[BVT];
+    uint4 ra[AV][EPT / 4], rb[BVT];
     int kh = 0, kw = 0, c0 = 0;
     auto load_step = [&]() {
         const long tap = ((long)kh * p.W + kw) * p.Cin + c0;
@@ -454,7 +455,9 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(const ConvP p) {
         for (int i = 0; i < AV; ++i) {
             const int hi = a_hi0[i] + kh, wi = a_wi0[i] + kw;
             const bool ok = a_vm[i] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-            ra[i] = ok ? *reinterpret_cast<const uint4*>(in + a_base[i] + tap) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int v = 0; v < EPT / 4; ++v)
+                ra[i][v] = ok ? *reinterpret_cast<const uint4*>(in + a_base[i] + tap + 4 * v) : make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < BVT; ++j)
@@ -466,18 +469,18 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(const ConvP p) {
     auto store_step = [&]() {
 #pragma unroll
         for (int i = 0; i < AV; ++i) {
-            const float* f = reinterpret_cast<const float*>(&ra[i]);
-            char* dst = smem + (lrow + RPP * i) * ROWS + chunk * 8;
+            const float* f = reinterpret_cast<const float*>(&ra[i][0]);
+            char* dst = smem + (lrow + RPP * i) * ROWS + chunk * (EPT * 2);
             if (F16) {
-                f16x4 h, l;
+                f16x8 h, l;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < 8; ++q) {
                     const float x = f[q] * a_scale;
                     h[q] = (_Float16)x;
                     l[q] = (_Float16)(x - (float)h[q]);
                 }
-                *reinterpret_cast<f16x4*>(dst) = h;
-                *reinterpret_cast<f16x4*>(dst + PLANE_A) = l;
+                *reinterpret_cast<f16x8*>(dst) = h;
+                *reinterpret_cast<f16x8*>(dst + PLANE_A) = l;
             } else {
                 bf16x4 h, m, l;
 #pragma unroll
