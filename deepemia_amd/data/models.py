@@ -20,11 +20,12 @@ from ..utils.logger_utils import system_logger
 from .datasets import MetadataCatalog
 
 # BASELINE.json configs[1] runs bf16; parity (mask IoU >= 0.999 vs the fp32 CPU path) needs f32 arithmetic:
-#   f32x3  f32 operands split into three bf16 planes, six bf16 MFMAs per product, f32 accumulation (default;
-#          error of one f32 rounding per product, same parity results as f32, ~1.4x faster)
+#   f16x2  f32 operands as two fp16 planes with exact power-of-two scales, three fp16 MFMAs per product, f32
+#          accumulation (default: error <= 3 * 2^-22 per product, the same parity results as f32, ~1.8x faster)
+#   f32x3  f32 operands split into three bf16 planes, six bf16 MFMAs per product (no operand scales needed)
 #   f32    the exact-f32 MFMA (v_mfma_f32_32x32x2_f32)
-#   bf16   bf16 operands (fastest, mask IoU parity NOT met)
-DEFAULT_PRECISION = os.environ.get("DEEPEMIA_PRECISION", "f32x3")
+#   bf16x2 / bf16   16-bit / 8-bit significand operands (faster still, mask IoU parity NOT met)
+DEFAULT_PRECISION = os.environ.get("DEEPEMIA_PRECISION", "f16x2")
 # INPUT.MIN_SIZE_TEST / MAX_SIZE_TEST: the reference never overrides the model-zoo 800 / 1333 (models.py:134-144), so
 # these are the parity values.  DEEPEMIA_MIN_SIZE_TEST / DEEPEMIA_MAX_SIZE_TEST select the flagged NON-parity
 # "native resolution" mode (e.g. 2048 / 2048: the net sees a 2048^2 tile unscaled; 5x the work per tile).

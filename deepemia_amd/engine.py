@@ -193,7 +193,7 @@ class RawDetections:
 
 class MaskRCNNEngine:
     def __init__(self, state_dict: Dict[str, torch.Tensor], depth: int, num_classes: int, score_thresh: float,
-                 device: str = "cuda:0", precision: str = "f32x3", min_size_test: int = 800, max_size_test: int = 1333):
+                 device: str = "cuda:0", precision: str = "f16x2", min_size_test: int = 800, max_size_test: int = 1333):
         if depth not in RES_BLOCKS:
             raise ValueError(f"unsupported ResNet depth {depth}")
         if not torch.cuda.is_available():

@@ -398,7 +398,7 @@ def test_native_resolution_mode_matches_oracle_at_the_same_sizes(env):
     R, synth = env["R"], env["synth"]
     img = synth.em_tile(3, 1024)
     ref = R.predict(img, env["sd"], 50, THR, min_size_test=1024, max_size_test=1024)
-    eng = MaskRCNNEngine(env["sd"], 50, K, THR, env["dev"], "f32x3", min_size_test=1024, max_size_test=1024)
+    eng = MaskRCNNEngine(env["sd"], 50, K, THR, env["dev"], "f16x2", min_size_test=1024, max_size_test=1024)
     assert eng._resize_tables(1024, 1024)["newh"] == 1024
     inst = Predictor(eng)(img)["instances"].to("cpu")
     n = ref["scores"].shape[0]

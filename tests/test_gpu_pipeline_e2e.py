@@ -117,12 +117,14 @@ def _compare(split, images, ref_rows, ref_masks):
 @pytest.mark.parametrize("case", ["single_r50_blobby_upscale2", "ensemble_r50_r101_upscale1",
                                   "single_r50_blobby_upscale2_f32x3", "ensemble_r50_r101_upscale1_f32x3",
                                   "single_r50_tile200_upscale1p5_f32x3",
-                                  "single_r50_blobby_upscale2_f16x2", "ensemble_r50_r101_upscale1_f16x2"])
+                                  "single_r50_blobby_upscale2_f16x2", "ensemble_r50_r101_upscale1_f16x2",
+                                  "single_r50_tile200_upscale1p5_f16x2"])
 def test_cli_inference_matches_oracle_pipeline(case, tmp_path, monkeypatch, gpu_device):
     from oracle import pipeline_ref as PR
     from deepemia_amd.data import models as DM
 
-    # DEEPEMIA_PRECISION: exact-f32 MFMA, or f32 operands split over the bf16 pipe (f32x3) -- same parity bar
+    # DEEPEMIA_PRECISION: exact-f32 MFMA, f32 operands split over the bf16 pipe (f32x3) or over the fp16 pipe (f16x2, the
+    # default) -- same parity bar
     monkeypatch.setattr(DM, "DEFAULT_PRECISION", "f32x3" if case.endswith("_f32x3") else ("f16x2" if case.endswith("_f16x2") else "f32"))
 
     spatial = {"enabled": True, "containment_rules": {1: 0}, "containment_threshold": 0.5,
