@@ -22,7 +22,7 @@
 // (reference src/functions/inference.py:1395,1398,1507,1669; src/data/models.py:107).
 #include "common.h"
 #ifndef F16_BK
-#define F16_BK 64
+#define F16_BK 32      // K-step of the f16x2 kernel: 32 keeps a stage at 41 KiB and the kernel at <= 168 registers -> THREE workgroups per CU
 #endif
 
 namespace {
@@ -375,11 +375,11 @@ __device__ __forceinline__ f32x16 mma_planes(const uint4& a, const uint4& b, f32
 // bits per operand, dropped terms <= 3 * 2^-16 |ab|: 256 x less exact than f32, 256 x more exact than plain bf16, at half
 // the matrix work of f32x3 (an opt-in speed mode; the default stays f32x3).
 template <typename TO, int WM, int WN, int TM, int TN, int NP = 3, bool F16 = false>
-__global__ __launch_bounds__(256) void conv_igemm_split_kernel(const ConvP p) {
+__global__ __launch_bounds__(256, F16 ? 3 : 2) void conv_igemm_split_kernel(const ConvP p) {
     static_assert(!F16 || NP == 2, "fp16 planes come in pairs");
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
-    constexpr int BK = F16 ? F16_BK : 32;           // f16x2 has half the MFMAs per element: twice the K-step keeps 48 per barrier pair
+    constexpr int BK = F16 ? F16_BK : 32;
     constexpr int ROWS = BK * 2 + 16;           // LDS row: BK 2-byte elements + 16 B pad (80 / 144 B: conflict-free ds_read_b128)
     constexpr int EPT = F16 ? 8 : 4;            // A elements per thread per row pass (f16x2: one 16-byte LDS write per plane)
     constexpr int CH = BK / EPT;                // thread chunks per A row

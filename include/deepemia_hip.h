@@ -60,7 +60,7 @@ const char* demia_build_arch(void);   /* "gfx950" */
  *   scale/bias [Cout] f32 or NULL    y = acc * scale + bias   (FrozenBN folded / conv bias)
  *   residual  NULL or out-shaped (RES_SAME) / half-res (RES_UP2), dtype `out_dtype`
  *   out       [N, Ho, Wo, Cout]      dtype `out_dtype`
- * Cin must be a multiple of 64 (bf16, f16x2) / 32 (f32, f32x3, bf16x2).  dtype DEMIA_F32X3 computes the f32 product on the bf16
+ * Cin must be a multiple of 64 (bf16) / 32 (f32, f32x3, f16x2, bf16x2).  dtype DEMIA_F32X3 computes the f32 product on the bf16
  * matrix pipe from three-way split operands (six bf16 MFMAs per f32 FMA tile, error ~ one f32 rounding): `in` is
  * f32, `w` holds the three bf16 planes of the f32 weights, CoutPad % 64 == 0, output f32.  DEMIA_BF16X2 is the same
  * with two planes and three MFMAs (16 significand bits per operand, error <= 3 * 2^-16 per product).
@@ -74,7 +74,7 @@ const char* demia_build_arch(void);   /* "gfx950" */
  * the kernel scales the activations by 2^(13 - ilogb(*amax_in)); `amax_in` is a device scalar holding an upper bound
  * of |in| (NULL: no scaling, |in| must stay below 6e4).  `amax_out` (any dtype, may be NULL): device scalar into
  * which the kernel accumulates max |out| with an atomic max -- zero it before the launch; it is the next layer's
- * `amax_in`.  DEMIA_F16X2 walks K in steps of 64 (Cin % 64 == 0) and takes its planes as [CoutPad / 64][K / 64][2][64][64].  */
+ * `amax_in`.  DEMIA_F16X2 takes its planes in the same tiling, [CoutPad / 64][K / 32][2][64][32] fp16.  */
 typedef struct demia_conv_desc {
     const void* in;
     const void* w;

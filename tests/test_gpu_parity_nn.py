@@ -128,10 +128,10 @@ def test_conv_igemm_vs_torch(env, case, prec):
     if prec == "f16x2":
         # two fp16 planes per operand with exact power-of-two scales (weights per channel here, activations from the
         # |x| bound inside the kernel), three MFMAs per product: same tolerance as the exact-f32 kernel
-        if cout_pad % 64 or cin % 64:
+        if cout_pad % 64 or cin % 32:
             pytest.skip("shape stays on the exact-f32 kernel")
         planes, sw = E.split2_f16_scaled(wp.to(dev))
-        L.w3 = E.tile_weight_planes(planes, 64)
+        L.w3 = E.tile_weight_planes(planes, 32)
         L.scale3 = (scale.to(dev) / sw[:cout]).contiguous()
         x = x * float(10.0 ** ((cin % 7) - 3))          # exercise the activation scale: |x| from 1e-3 to 1e3
         y = F.conv2d(x, wt, None, stride=stride, padding=pad) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)
