@@ -39,6 +39,7 @@ struct ConvP {
     int M, HoWo, ntn, nwg, ksteps, csteps, vec_ok;
     const float* amax_in;   // f16x2: upper bound of |in| (device scalar) -> power-of-two operand scale
     float* amax_out;        // any dtype: atomic max of |out| is accumulated here when non-NULL
+    int w_bytes;            // split kernels: size of the tiled weight planes (buffer descriptor range)
 };
 
 template <typename T> struct Mma;
@@ -396,9 +397,6 @@ __global__ __launch_bounds__(256, F16 ? 3 : 2) void conv_igemm_split_kernel(cons
     const int swz = xcd_remap(blockIdx.x, p.nwg);
     const int tile_n = swz % p.ntn, tile_m = swz / p.ntn;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const float* __restrict__ in = reinterpret_cast<const float*>(p.in);
-    const bf16_t* __restrict__ wt = reinterpret_cast<const bf16_t*>(p.w);
-
     float a_scale = 1.f, post = 1.f;
     if (F16 && p.amax_in) {
         const float am = *p.amax_in;
@@ -409,40 +407,54 @@ __global__ __launch_bounds__(256, F16 ? 3 : 2) void conv_igemm_split_kernel(cons
             post = ldexpf(1.f, -e);
         }
     }
+    // Operands are fetched with buffer loads: a 32-bit byte offset per lane, the hardware range check returns zeros for
+    // OOB (= padding taps, rows beyond M, channels beyond CoutPad) -- no 64-bit address arithmetic and no exec-mask
+    // branches in the K loop.  The A descriptor starts at the first image this tile touches, so offsets stay small
+    // whatever the batch; bit t of a_mask says whether tap t = kh * KW + kw of that row lies inside the image.
+    constexpr int OOB = (int)0x80000000;
+    const int n_first = m0 / p.HoWo;
+    const long img_elems = (long)p.H * p.W * p.Cin;
+    long a_rec = ((long)p.N - n_first) * img_elems * 4;
+    a_rec = a_rec > 0x7fffffffL ? 0x7fffffffL : a_rec;
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(reinterpret_cast<const float*>(p.in) + n_first * img_elems), 0, (int)a_rec, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
     const int chunk = tid % CH, lrow = tid / CH;
-    long a_base[AV];
-    int a_hi0[AV], a_wi0[AV];
-    bool a_vm[AV];
+    int a_off[AV];
+    unsigned a_mask[AV];
 #pragma unroll
     for (int i = 0; i < AV; ++i) {
         const int m = m0 + lrow + RPP * i;
-        a_vm[i] = m < p.M;
-        const int mm = a_vm[i] ? m : 0;
+        const bool vm = m < p.M;
+        const int mm = vm ? m : 0;
         const int n = mm / p.HoWo;
         const int rem = mm - n * p.HoWo;
         const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-        a_hi0[i] = ho * p.stride - p.pad;
-        a_wi0[i] = wo * p.stride - p.pad;
-        a_base[i] = (((long)n * p.H + a_hi0[i]) * p.W + a_wi0[i]) * p.Cin + chunk * EPT;
+        const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+        a_off[i] = (int)(((((long)(n - n_first) * p.H + hi0) * p.W + wi0) * p.Cin + chunk * EPT) * 4);
+        unsigned mk = 0;
+        for (int t = 0; t < p.KH * p.KW; ++t) {
+            const int th = t / p.KW, tw = t - th * p.KW;
+            if (vm && (unsigned)(hi0 + th) < (unsigned)p.H && (unsigned)(wi0 + tw) < (unsigned)p.W) mk |= 1u << t;
+        }
+        a_mask[i] = mk;
     }
     // Weight planes arrive TILED: [CoutPad / 64][ksteps][NP][64 rows][BK k] 2-byte elements -- the 64 x BK piece of one
-    // plane that a K-step needs is 4 / 8 KiB contiguous, so the B loads of a wave are whole 128-byte lines (row-major [CoutPad][K]
-    // planes made every 16-lane group touch four half-used lines).
-    long b_off[BVT];
+    // plane that a K-step needs is 4 KiB contiguous, so the B loads of a wave are whole 128-byte lines (row-major
+    // [CoutPad][K] planes made every 16-lane group touch four half-used lines).
+    int b_voff[BVT];
     int b_lds[BVT];
-    bool b_vm[BVT];
 #pragma unroll
     for (int j = 0; j < BVT; ++j) {
         const int v = tid + 256 * j;
         const int plane = v / (BN * BVR), rem = v - plane * (BN * BVR);
         const int row = rem / BVR, c8 = rem % BVR;
         const int co = n0 + row;
-        b_vm[j] = co < p.CoutPad;
-        const int n64 = (b_vm[j] ? co : 0) >> 6;
-        b_off[j] = ((long)n64 * p.ksteps * NP + plane) * (64 * BK) + (co & 63) * BK + c8 * 8;
+        const int n64 = co >> 6;
+        b_voff[j] = co < p.CoutPad ? (int)((((long)n64 * p.ksteps * NP + plane) * (64 * BK) + (co & 63) * BK + c8 * 8) * 2) : OOB;
         b_lds[j] = NP * PLANE_A + plane * PLANE_B + row * ROWS + c8 * 16;
     }
-    long b_step = 0;
+    int b_soff = 0;
 
     // ONE LDS stage (61 KiB for 128x128) so that TWO workgroups share a CU: while one is in its barrier / split /
     // store phase the other one's MFMAs keep the matrix pipe busy (a K-step is only 48 MFMAs, ~1.5k cycles, far
@@ -450,19 +462,23 @@ __global__ __launch_bounds__(256, F16 ? 3 : 2) void conv_igemm_split_kernel(cons
     uint4 ra[AV][EPT / 4], rb[BVT];
     int kh = 0, kw = 0, c0 = 0;
     auto load_step = [&]() {
-        const long tap = ((long)kh * p.W + kw) * p.Cin + c0;
+        const int tap_b = ((kh * p.W + kw) * p.Cin + c0) * 4;
+        const unsigned bit = 1u << (kh * p.KW + kw);
 #pragma unroll
         for (int i = 0; i < AV; ++i) {
-            const int hi = a_hi0[i] + kh, wi = a_wi0[i] + kw;
-            const bool ok = a_vm[i] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            const int vo = (a_mask[i] & bit) ? a_off[i] + tap_b : OOB;
 #pragma unroll
-            for (int v = 0; v < EPT / 4; ++v)
-                ra[i][v] = ok ? *reinterpret_cast<const uint4*>(in + a_base[i] + tap + 4 * v) : make_uint4(0, 0, 0, 0);
+            for (int v = 0; v < EPT / 4; ++v) {
+                const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, vo + 16 * v, 0, 0);
+                ra[i][v] = make_uint4(t[0], t[1], t[2], t[3]);
+            }
         }
 #pragma unroll
-        for (int j = 0; j < BVT; ++j)
-            rb[j] = b_vm[j] ? *reinterpret_cast<const uint4*>(wt + b_off[j] + b_step) : make_uint4(0, 0, 0, 0);
-        b_step += NP * 64 * BK;
+        for (int j = 0; j < BVT; ++j) {
+            const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, b_voff[j], b_soff, 0);
+            rb[j] = make_uint4(t[0], t[1], t[2], t[3]);
+        }
+        b_soff += NP * 64 * BK * 2;
         c0 += BK;
         if (c0 >= p.Cin) { c0 = 0; if (++kw == p.KW) { kw = 0; ++kh; } }
     };
@@ -640,6 +656,15 @@ extern "C" int demia_conv2d_nhwc(const demia_conv_desc* d, void* stream) {
     if (bn != 128 && bn != 64 && bn != 32) bn = d->CoutPad >= 128 ? 128 : (d->CoutPad >= 64 ? 64 : 32);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     p.amax_in = d->amax_in; p.amax_out = d->amax_out;
+    p.w_bytes = 0;
+    if (d->dtype == DEMIA_F16X2 || d->dtype == DEMIA_BF16X2 || d->dtype == DEMIA_F32X3) {
+        const long np = d->dtype == DEMIA_F32X3 ? 3 : 2;
+        const long wb = np * d->CoutPad * (long)d->KH * d->KW * d->Cin * 2;
+        DEMIA_REQUIRE(wb < (1L << 31), "weight planes must stay below 2 GiB");
+        DEMIA_REQUIRE(d->KH * d->KW <= 32, "at most 32 taps");
+        DEMIA_REQUIRE((long)d->H * d->W * d->Cin * 4 * 2 < (1L << 30), "one image must stay below 512 MiB");
+        p.w_bytes = (int)wb;
+    }
     if (d->dtype == DEMIA_F16X2) {
         if (d->CoutPad % 128 != 0) return launch_split_cfg<float, 4, 1, 1, 2, 2, true>(p, st);
         const long blocks128 = (long)cdiv(p.M, 128) * cdiv(p.CoutPad, 128);
