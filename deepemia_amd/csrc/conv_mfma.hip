@@ -92,7 +92,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 constexpr int ROWB = 144;  // bytes per LDS tile row: 128 B of K + 16 B pad
 
 // Epilogue shared by the conv kernels: accumulators -> LDS (f32) -> scale/bias/residual/activation on 16-byte rows.
-template <typename TO, int BM, int BN, int TM, int TN>
+template <typename TO, int BM, int BN, int TM, int TN, int EH = 1>
 __device__ __forceinline__ void conv_epilogue(const ConvP& p, char* smem, f32x16 (&acc)[TM][TN], int a_row0, int b_row0, int m0, int n0,
                                               float post = 1.0f) {
     constexpr int EROW = BN * 4 + 16;          // epilogue LDS row (f32) + pad
@@ -127,42 +127,51 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, char* smem, f32x16
             load4<TO>(res + ridx, rv[k]);
         }
     }
-    __syncthreads();
-    // ---- epilogue: accumulators -> LDS (f32) -> 16-byte rows --------------------------
+    // ---- epilogue: accumulators -> LDS (f32) -> 16-byte rows, in EH passes of BM / EH rows (EH = 2 keeps the LDS
+    // footprint of a 128-row tile at 33 KiB, below its K-loop stage: the epilogue must not cost a workgroup per CU) ----
     // C layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-    {
-        float* e = reinterpret_cast<float*>(smem);
-        constexpr int EF = EROW / 4;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = a_row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    const int col = b_row0 + j * 32 + (lane & 31);
-                    e[row * EF + col] = acc[i][j][r] * post;
-                }
-    }
-    __syncthreads();
+    constexpr int HR = BM / EH, NRH = NR / EH;
+    static_assert(NR % EH == 0 && HR % 32 == 0, "epilogue halves");
     float vmax = 0.f;
-    {
-        TO* __restrict__ out = reinterpret_cast<TO*>(p.out);
-        if (co < p.Cout) {
-            float sc[4], bs[4];
+    TO* __restrict__ out = reinterpret_cast<TO*>(p.out);
+    float sc[4], bs[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const bool ok = (co + q) < p.Cout;
-                sc[q] = (p.scale && ok) ? p.scale[co + q] : 1.0f;
-                bs[q] = (p.bias && ok) ? p.bias[co + q] : 0.0f;
+    for (int q = 0; q < 4; ++q) {
+        const bool ok = (co + q) < p.Cout;
+        sc[q] = (p.scale && ok) ? p.scale[co + q] : 1.0f;
+        bs[q] = (p.bias && ok) ? p.bias[co + q] : 0.0f;
+    }
+#pragma unroll
+    for (int h = 0; h < EH; ++h) {
+        __syncthreads();
+        {
+            float* e = reinterpret_cast<float*>(smem);
+            constexpr int EF = EROW / 4;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int rb = a_row0 + i * 32 - h * HR;          // wave-uniform
+                if (rb >= 0 && rb < HR) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = rb + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                            const int col = b_row0 + j * 32 + (lane & 31);
+                            e[row * EF + col] = acc[i][j][r] * post;
+                        }
+                }
             }
+        }
+        __syncthreads();
+        if (co < p.Cout) {
             const char* e = smem;
 #pragma unroll
-            for (int k = 0; k < NR; ++k) {
+            for (int kk = 0; kk < NRH; ++kk) {
+                const int k = h * NRH + kk;
                 const int r = r0 + k * RPP;
                 const int m = m0 + r;
                 if (m < p.M) {
-                    const float4 a4 = *reinterpret_cast<const float4*>(e + r * EROW + g * 16);
+                    const float4 a4 = *reinterpret_cast<const float4*>(e + (r - h * HR) * EROW + g * 16);
                     float v[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = v[q] * sc[q] + bs[q];
@@ -559,7 +568,7 @@ __global__ __launch_bounds__(256, F16 ? 3 : 2) void conv_igemm_split_kernel(cons
         if (more) store_step();
         __syncthreads();
     }
-    conv_epilogue<TO, BM, BN, TM, TN>(p, smem, acc, a_row0, b_row0, m0, n0, post);
+    conv_epilogue<TO, BM, BN, TM, TN, (BM == 128 ? 2 : 1)>(p, smem, acc, a_row0, b_row0, m0, n0, post);
 }
 
 // 128 x 128 or 64 x 128 tiles for the split kernels: the workgroups of a CU share its matrix pipes, so a launch lasts as
@@ -575,7 +584,7 @@ inline bool prefer_half_tile(long blocks128, long blocks64) {
 template <typename TO, int WM, int WN, int TM, int TN, int NP = 3, bool F16 = false>
 int launch_split_cfg(ConvP p, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int stage = NP * (BM + BN) * ((F16 ? F16_BK : 32) * 2 + 16), epi = BM * (BN * 4 + 16);
+    constexpr int stage = NP * (BM + BN) * ((F16 ? F16_BK : 32) * 2 + 16), epi = (BM == 128 ? 64 : BM) * (BN * 4 + 16);
     constexpr int smem = stage > epi ? stage : epi;      // one tile stage, re-used by the epilogue
     p.ntn = cdiv(p.CoutPad, BN);
     p.nwg = p.ntn * cdiv(p.M, BM);
