@@ -575,10 +575,10 @@ __global__ __launch_bounds__(256, F16 ? 3 : 2) void conv_igemm_split_kernel(cons
 // long as the CU with the most tiles -- balance = (tiles / 256) / ceil(tiles / 256).  The half tile re-reads the weight
 // planes twice as often per FLOP and measures 7 % slower per tile at equal balance (164 vs 172 TFLOP/s on the large
 // layers), so it is taken only where its better balance outweighs that (res4 / res5 at 16 tiles per batch).
-inline bool prefer_half_tile(long blocks128, long blocks64) {
+inline bool prefer_half_tile(long blocks128, long blocks64, double half_tile_rate = 0.93) {
     auto balance = [](long b) { const double per_cu = (double)b / 256.0; return per_cu / (double)((b + 255) / 256); };
     if (blocks128 < 512) return true;          // fewer than two tiles per CU: fill the chip first
-    return 0.93 * balance(blocks64) > balance(blocks128);
+    return half_tile_rate * balance(blocks64) > balance(blocks128);
 }
 
 template <typename TO, int WM, int WN, int TM, int TN, int NP = 3, bool F16 = false>
@@ -677,7 +677,8 @@ extern "C" int demia_conv2d_nhwc(const demia_conv_desc* d, void* stream) {
     if (d->dtype == DEMIA_F16X2) {
         if (d->CoutPad % 128 != 0) return launch_split_cfg<float, 4, 1, 1, 2, 2, true>(p, st);
         const long blocks128 = (long)cdiv(p.M, 128) * cdiv(p.CoutPad, 128);
-        if (prefer_half_tile(blocks128, (long)cdiv(p.M, 64) * cdiv(p.CoutPad, 128)))
+        // f16x2: the 64 x 128 tile runs at 0.74 of the 128 x 128 tile's rate (233 vs 322 TFLOP/s at equal balance)
+        if (prefer_half_tile(blocks128, (long)cdiv(p.M, 64) * cdiv(p.CoutPad, 128), 0.75))
             return launch_split_cfg<float, 2, 2, 1, 2, 2, true>(p, st);
         return launch_split_cfg<float, 2, 2, 2, 2, 2, true>(p, st);
     }
