@@ -391,13 +391,15 @@ __global__ __launch_bounds__(256, F16 ? 3 : 2) void conv_igemm_split_kernel(cons
     constexpr int BN = WN * TN * 32;
     constexpr int BK = F16 ? F16_BK : 32;
     constexpr int ROWS = BK * 2 + 16;           // LDS row: BK 2-byte elements + 16 B pad (80 / 144 B: conflict-free ds_read_b128)
-    constexpr int EPT = F16 ? 8 : 4;            // A elements per thread per row pass (f16x2: one 16-byte LDS write per plane)
+    constexpr bool RING = F16 && BK == 16;      // two LDS stages of K-step 16, ONE barrier per step (see the loop below)
+    constexpr int EPT = F16 ? (BM * BK / 256 >= 8 ? 8 : 4) : 4;   // A elements per thread per row pass (f16x2: 16-byte LDS writes where the tile allows)
     constexpr int CH = BK / EPT;                // thread chunks per A row
     constexpr int RPP = 256 / CH;               // A rows per pass of the 256 threads
     constexpr int AV = BM / RPP;                // row passes per K-step (EPT / 4 f32 vectors each)
     constexpr int BVR = BK / 8;                 // 16-B plane vectors (8 elements) per B row
     constexpr int BVT = NP * BN * BVR / 256;    // ... of the B planes per thread per K-step
     constexpr int PLANE_A = BM * ROWS, PLANE_B = BN * ROWS;
+    constexpr int STAGE_BYTES = NP * (BM + BN) * ROWS;
     static_assert((NP * BN * BVR) % 256 == 0, "B tile must divide over the 256 threads");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -491,12 +493,13 @@ __global__ __launch_bounds__(256, F16 ? 3 : 2) void conv_igemm_split_kernel(cons
         c0 += BK;
         if (c0 >= p.Cin) { c0 = 0; if (++kw == p.KW) { kw = 0; ++kh; } }
     };
-    auto store_step = [&]() {
+    auto store_step = [&](int st) {
+        char* sbase = smem + st * STAGE_BYTES;
 #pragma unroll
         for (int i = 0; i < AV; ++i) {
             const float* f = reinterpret_cast<const float*>(&ra[i][0]);
-            char* dst = smem + (lrow + RPP * i) * ROWS + chunk * (EPT * 2);
-            if (F16) {
+            char* dst = sbase + (lrow + RPP * i) * ROWS + chunk * (EPT * 2);
+            if (F16 && EPT == 8) {
                 f16x8 h, l;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
@@ -506,6 +509,16 @@ __global__ __launch_bounds__(256, F16 ? 3 : 2) void conv_igemm_split_kernel(cons
                 }
                 *reinterpret_cast<f16x8*>(dst) = h;
                 *reinterpret_cast<f16x8*>(dst + PLANE_A) = l;
+            } else if (F16) {
+                f16x4 h, l;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float x = f[q] * a_scale;
+                    h[q] = (_Float16)x;
+                    l[q] = (_Float16)(x - (float)h[q]);
+                }
+                *reinterpret_cast<f16x4*>(dst) = h;
+                *reinterpret_cast<f16x4*>(dst + PLANE_A) = l;
             } else {
                 bf16x4 h, m, l;
 #pragma unroll
@@ -516,7 +529,7 @@ __global__ __launch_bounds__(256, F16 ? 3 : 2) void conv_igemm_split_kernel(cons
             }
         }
 #pragma unroll
-        for (int j = 0; j < BVT; ++j) *reinterpret_cast<uint4*>(smem + b_lds[j]) = rb[j];
+        for (int j = 0; j < BVT; ++j) *reinterpret_cast<uint4*>(sbase + b_lds[j]) = rb[j];
     };
 
     f32x16 acc[TM][TN];
@@ -532,21 +545,18 @@ __global__ __launch_bounds__(256, F16 ? 3 : 2) void conv_igemm_split_kernel(cons
     const char* sA = smem + a_row0 * ROWS + frag_off;
     const char* sB = smem + NP * PLANE_A + b_row0 * ROWS + frag_off;
 
-    load_step();
-    store_step();
-    __syncthreads();
-    for (int s = 0; s < p.ksteps; ++s) {
-        const bool more = (s + 1) < p.ksteps;
-        if (more) load_step();
+    auto mfma_step = [&](int st) {
+        const char* cA = sA + st * STAGE_BYTES;
+        const char* cB = sB + st * STAGE_BYTES;
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
             uint4 fa[NP][TM], fb[NP][TN];
 #pragma unroll
             for (int q = 0; q < NP; ++q) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) fa[q][i] = *reinterpret_cast<const uint4*>(sA + q * PLANE_A + i * 32 * ROWS + kk * 32);
+                for (int i = 0; i < TM; ++i) fa[q][i] = *reinterpret_cast<const uint4*>(cA + q * PLANE_A + i * 32 * ROWS + kk * 32);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) fb[q][j] = *reinterpret_cast<const uint4*>(sB + q * PLANE_B + j * 32 * ROWS + kk * 32);
+                for (int j = 0; j < TN; ++j) fb[q][j] = *reinterpret_cast<const uint4*>(cB + q * PLANE_B + j * 32 * ROWS + kk * 32);
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -564,9 +574,36 @@ __global__ __launch_bounds__(256, F16 ? 3 : 2) void conv_igemm_split_kernel(cons
                     acc[i][j] = c;
                 }
         }
-        __syncthreads();                 // every wave is done reading this K-step
-        if (more) store_step();
+    };
+    if (RING) {
+        // Two LDS stages of one MFMA K-step each.  Step s: write the registers (step s + 1) into the other stage, request
+        // step s + 2, then this wave's fragment reads + MFMAs on the current stage -- ONE barrier per step, and no phase
+        // in which every wave of the workgroup is outside its MFMAs: a wave that has written its share goes straight on
+        // to the matrix pipe while its neighbours are still converting.  (The stage being written was last read before
+        // the previous step's barrier; the stage being read was written before it.)
+        load_step();
+        store_step(0);
+        if (p.ksteps > 1) load_step();
         __syncthreads();
+        for (int s = 0; s < p.ksteps; ++s) {
+            const int cur = s & 1;
+            if (s + 1 < p.ksteps) store_step(cur ^ 1);
+            if (s + 2 < p.ksteps) load_step();
+            mfma_step(cur);
+            __syncthreads();
+        }
+    } else {
+        load_step();
+        store_step(0);
+        __syncthreads();
+        for (int s = 0; s < p.ksteps; ++s) {
+            const bool more = (s + 1) < p.ksteps;
+            if (more) load_step();
+            mfma_step(0);
+            __syncthreads();                 // every wave is done reading this K-step
+            if (more) store_step(0);
+            __syncthreads();
+        }
     }
     conv_epilogue<TO, BM, BN, TM, TN, (BM == 128 ? 2 : 1)>(p, smem, acc, a_row0, b_row0, m0, n0, post);
 }
@@ -584,7 +621,7 @@ inline bool prefer_half_tile(long blocks128, long blocks64, double half_tile_rat
 template <typename TO, int WM, int WN, int TM, int TN, int NP = 3, bool F16 = false>
 int launch_split_cfg(ConvP p, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int stage = NP * (BM + BN) * ((F16 ? F16_BK : 32) * 2 + 16), epi = (BM == 128 ? 64 : BM) * (BN * 4 + 16);
+    constexpr int stage = NP * (BM + BN) * ((F16 ? F16_BK : 32) * 2 + 16) * ((F16 && F16_BK == 16) ? 2 : 1), epi = (BM == 128 ? 64 : BM) * (BN * 4 + 16);
     constexpr int smem = stage > epi ? stage : epi;      // one tile stage, re-used by the epilogue
     p.ntn = cdiv(p.CoutPad, BN);
     p.nwg = p.ntn * cdiv(p.M, BM);
