@@ -81,6 +81,7 @@ CONV_CASES = [
     (512, 256, 1, 1, 0, 50, 50, 1, False, 2),
     (64, 256, 3, 1, 1, 300, 300, 1, True, 1),      # 1408 tiles of 128 x 128: the full tile of the split kernel
     (128, 192, 3, 2, 1, 61, 47, 2, True, 0),       # CoutPad % 128 != 0: the 128 x 64 tile
+    (64, 256, 1, 1, 0, 512, 512, 1, True, 1),      # 4096 tiles: the 128 x 128 tile in every split mode (two-pass epilogue, residual)
 ]
 
 
