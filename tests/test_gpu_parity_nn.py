@@ -412,3 +412,21 @@ def test_native_resolution_mode_matches_oracle_at_the_same_sizes(env):
     # and it is a different answer from the 800-pixel parity mode
     base = R.predict(img, env["sd"], 50, THR)
     assert base["scores"].shape[0] != n or not np.allclose(base["scores"].numpy(), ref["scores"].numpy(), atol=1e-3)
+
+
+def test_batch_whose_activations_exceed_2gib_is_consistent(env):
+    """64 tiles per forward: the p2-level activation tensors are 2.6 GB, beyond a 32-bit byte offset from the tensor
+    base -- the split conv kernel's buffer descriptors start at each tile's first image instead.  Every repeated tile
+    must come out exactly like its first copy."""
+    synth = env["synth"]
+    base = np.stack([synth.em_tile(i, 2048) for i in range(16)])
+    x = torch.from_numpy(np.concatenate([base] * 4)).to(env["dev"])
+    out = env["f16x2"].forward(x)
+    cnt = out.count.cpu().numpy()
+    assert (cnt > 10).all()
+    for g in range(1, 4):
+        assert (cnt[:16] == cnt[16 * g:16 * (g + 1)]).all()
+        for name in ("boxes", "scores", "classes"):
+            t = getattr(out, name)
+            assert torch.equal(t[:16], t[16 * g:16 * (g + 1)]), (name, g)
+    assert torch.equal(out.packed[:16], out.packed[48:])
