@@ -1,5 +1,6 @@
 """CPU-only tests: the oracle against what pins it, the host logic, and the C ABI surface
 (library loads and exports every symbol include/deepemia_hip.h declares; no compute calls)."""
+import math
 import re
 from pathlib import Path
 
@@ -268,3 +269,60 @@ def test_greedy_and_smart_dedup_loops_match_the_dense_oracle():
                     if P._calc_iou_literal(sub[idx], sub[other], bboxes[idx], bboxes[other]) > thr:
                         removed.add(other)
             assert keep == exp, (trial, thr)
+
+
+def test_f16x2_host_split_is_exact_and_the_tiling_is_the_documented_one():
+    """Host side of the default conv arithmetic (engine.py): w * 2^e(co) = h + l with both planes in fp16 range, exactly;
+    planes tiled [CoutPad/64][K/32][2][64][32] as include/deepemia_hip.h documents."""
+    import torch
+    from deepemia_amd import engine as E
+
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn((128, 3, 3, 64), generator=g) * torch.logspace(-6, 2, 128).view(-1, 1, 1, 1)   # channel maxima over 8 decades
+    w[7] = 0.0
+    planes, sw = E.split2_f16_scaled(w)
+    assert planes.dtype == torch.float16 and planes.shape == (2, 128, 3, 3, 64)
+    # exact powers of two, max |w * sw| in [2^14, 2^15] for every non-zero channel
+    m, ex = torch.frexp(sw)
+    assert torch.all(m == 0.5)
+    top = (w * sw.view(-1, 1, 1, 1)).abs().flatten(1).amax(1)
+    nz = top > 0
+    assert torch.all(top[nz] >= 2.0 ** 14) and torch.all(top[nz] < 2.0 ** 15)
+    # h + l reproduces w * sw to <= 2^-22 relative (elements far below the channel maximum: <= 2^-25 absolute of it)
+    rec = planes[0].double() + planes[1].double()
+    ws = (w * sw.view(-1, 1, 1, 1)).double()
+    err = (rec - ws).abs()
+    assert torch.all(err <= torch.maximum(ws.abs() * 2.0 ** -22, torch.full_like(ws, 2.0 ** -25)))
+    assert torch.isfinite(planes.float()).all()
+    # tiling: element (plane p, channel co, k) sits at [co // 64, k // 32, p, co % 64, k % 32]
+    t = E.tile_weight_planes(planes, 32)
+    flat = planes.reshape(2, 128, -1)
+    assert t.shape == (2, 3 * 3 * 64 // 32, 2, 64, 32)
+    for (p, co, k) in [(0, 0, 0), (1, 5, 31), (0, 64, 32), (1, 127, 575), (0, 70, 300)]:
+        assert t[co // 64, k // 32, p, co % 64, k % 32] == flat[p, co, k]
+
+
+def test_f16x2_three_product_scheme_has_f32_sized_error():
+    """The arithmetic claim of DESIGN.md: a . b from two scaled fp16 planes per operand and the three products
+    a1b1 + a1b2 + a2b1, f32 accumulation, is as close to the exact dot product as a plain f32 matmul is -- also for
+    tensors whose values sit far below 1 (that is what the power-of-two activation scale is for)."""
+    import torch
+    from deepemia_amd import engine as E
+
+    g = torch.Generator().manual_seed(1)
+    for amp in (3.0, 3.0e-4, 3.0e3):
+        a = torch.relu(torch.randn((256, 2304), generator=g)) * amp
+        a[:, ::7] *= 1e-3
+        w = torch.randn((64, 2304), generator=g) * 0.02
+        ref = a.double() @ w.double().t()
+        planes, sw = E.split2_f16_scaled(w)
+        amax = float(a.abs().max())
+        s = 2.0 ** (13 - math.floor(math.log2(amax)))                    # the kernel's 2^(13 - ilogb(amax))
+        ah = (a * s).to(torch.float16)
+        al = (a * s - ah.float()).to(torch.float16)
+        assert torch.isfinite(ah.float()).all()
+        bh, bl = planes[0].float(), planes[1].float()
+        y = ((ah.float() @ bl.t() + al.float() @ bh.t()) + ah.float() @ bh.t()) / (s * sw)
+        err = float((y.double() - ref).abs().max() / ref.abs().max())
+        f32 = float(((a @ w.t()).double() - ref).abs().max() / ref.abs().max())
+        assert err < 1e-6 and err < 4 * f32 + 1e-7, (amp, err, f32)
