@@ -81,6 +81,7 @@ class PasteDesc(C.Structure):
 # every symbol include/deepemia_hip.h declares (tests check the library exports all of them)
 EXPORTS = {
     "demia_abi_version": (C.c_int, []),
+    "demia_conv_f16x2_kstep": (C.c_int, []),
     "demia_last_error": (C.c_char_p, []),
     "demia_build_arch": (C.c_char_p, []),
     "demia_conv2d_nhwc": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),

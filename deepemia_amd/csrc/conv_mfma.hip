@@ -669,6 +669,8 @@ int launch_typed(ConvP p, int bn, hipStream_t st) {
 
 }  // namespace
 
+extern "C" int demia_conv_f16x2_kstep(void) { return F16_BK; }
+
 extern "C" int demia_conv2d_nhwc(const demia_conv_desc* d, void* stream) {
     DEMIA_REQUIRE(d && d->in && d->w && d->out, "null pointer");
     DEMIA_REQUIRE(d->dtype == DEMIA_F32 || d->dtype == DEMIA_BF16 || d->dtype == DEMIA_F32X3 || d->dtype == DEMIA_BF16X2 ||

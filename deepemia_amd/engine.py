@@ -253,7 +253,7 @@ class MaskRCNNEngine:
             w3 = split3_bf16(wp.to(dev))                       # split on the device: same round-to-nearest casts
             w3 = tile_weight_planes(w3 if self.precision == "f32x3" else w3[:2])
         scale3 = None
-        f16_bk = int(os.environ.get("DEEPEMIA_F16_BK", "32"))      # must match F16_BK of the library build
+        f16_bk = int(self.lib.demia_conv_f16x2_kstep())           # the tiling this build of the library reads
         if self.precision == "f16x2" and cout_pad % 64 == 0 and cin % f16_bk == 0:
             planes, sw = split2_f16_scaled(wp.to(dev))
             w3 = tile_weight_planes(planes, f16_bk)

@@ -93,6 +93,8 @@ typedef struct demia_conv_desc {
     float* amax_out;         /* NULL or device scalar: max |out| is accumulated (atomic max) */
 } demia_conv_desc;
 int demia_conv2d_nhwc(const demia_conv_desc* d, void* stream);
+/* K-step of this build's DEMIA_F16X2 kernel = innermost extent of its weight-plane tiling (32 unless built otherwise) */
+int demia_conv_f16x2_kstep(void);
 
 /* a3: Pillow-exact ResizeShortestEdge + (x - mean) + zero pad -------------------------
  * Replaces T.ResizeShortestEdge.get_transform(img).apply_image(img) +

@@ -1,11 +1,11 @@
-"""Dev script: one conv case of the parity suite against torch, for an A/B build of the library (AB_LIB, DEEPEMIA_F16_BK)."""
+"""Dev script: one conv case of the parity suite against torch, for an A/B build of the library (AB_LIB)."""
 import os, sys, pathlib, torch, torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from deepemia_amd import _lib, synth, engine as E
 if os.environ.get("AB_LIB"):
     _lib.LIB_PATH = pathlib.Path(os.environ["AB_LIB"]).resolve()
-bk = int(os.environ.get("DEEPEMIA_F16_BK", "32"))
 eng = E.MaskRCNNEngine(synth.random_d2_state_dict(50, 2, 0), 50, 2, 0.3, "cuda:0", "f16x2")
+bk = int(eng.lib.demia_conv_f16x2_kstep())
 worst = 0
 for (cin, cout, k, stride, pad, h, w, n) in [(64, 256, 3, 1, 1, 300, 300, 1), (256, 256, 3, 1, 1, 14, 14, 5), (128, 192, 3, 2, 1, 61, 47, 2),
                                             (64, 64, 1, 1, 0, 50, 50, 2), (512, 256, 1, 1, 0, 50, 50, 1), (32, 64, 3, 1, 1, 20, 20, 1)]:

@@ -132,7 +132,7 @@ def test_conv_igemm_vs_torch(env, case, prec):
         if cout_pad % 64 or cin % 32:
             pytest.skip("shape stays on the exact-f32 kernel")
         planes, sw = E.split2_f16_scaled(wp.to(dev))
-        L.w3 = E.tile_weight_planes(planes, 32)
+        L.w3 = E.tile_weight_planes(planes, eng.lib.demia_conv_f16x2_kstep())
         L.scale3 = (scale.to(dev) / sw[:cout]).contiguous()
         x = x * float(10.0 ** ((cin % 7) - 3))          # exercise the activation scale: |x| from 1e-3 to 1e3
         y = F.conv2d(x, wt, None, stride=stride, padding=pad) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)
