@@ -380,7 +380,7 @@ __device__ __forceinline__ f32x16 mma_planes(const uint4& a, const uint4& b, f32
 // from THREE MFMAs per product.  fp16 has 5 exponent bits, so both operands are brought into range by exact
 // power-of-two scales: the weights per output channel on the host (folded into `scale`), the activations per tensor
 // with s = 2^(13 - ilogb(amax_in)), amax_in being the |.| bound that the producing layer's epilogue accumulated
-// (elements below 2^-11 of the tensor maximum lose relative, not absolute, accuracy: <= 2^-38 of the maximum).
+// (elements below 2^-16 of the tensor maximum have a denormal low plane: absolute error <= 2^-38 of the maximum).
 // NP = 3: "f32x3" as above.  NP = 2 ("bf16x2"): two planes and the three products a1b1, a1b2, a2b1 -- 16 significand
 // bits per operand, dropped terms <= 3 * 2^-16 |ab|: 256 x less exact than f32, 256 x more exact than plain bf16, at half
 // the matrix work of f32x3 (an opt-in speed mode; the default stays f32x3).
