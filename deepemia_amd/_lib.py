@@ -41,6 +41,18 @@ class ConvDesc(C.Structure):
     ]
 
 
+class ConvP32Desc(C.Structure):
+    _fields_ = [
+        ("in_", C.c_void_p), ("in_meta", C.c_void_p), ("w", C.c_void_p), ("scale", C.c_void_p), ("bias", C.c_void_p),
+        ("residual", C.c_void_p), ("res_meta", C.c_void_p), ("out", C.c_void_p), ("out_meta", C.c_void_p),
+        ("wbound", C.c_float), ("bbound", C.c_float),
+        ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32),
+        ("Ho", C.c_int32), ("Wo", C.c_int32), ("Cout", C.c_int32), ("CoutPad", C.c_int32),
+        ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+        ("act", C.c_int32), ("res_mode", C.c_int32), ("out_f32", C.c_int32), ("out_ld", C.c_int32), ("tile_hint", C.c_int32),
+    ]
+
+
 class RpnDesc(C.Structure):
     _fields_ = [
         ("head", C.c_void_p * 5), ("H", C.c_int32 * 5), ("W", C.c_int32 * 5), ("stride", C.c_int32 * 5),
@@ -85,6 +97,7 @@ EXPORTS = {
     "demia_last_error": (C.c_char_p, []),
     "demia_build_arch": (C.c_char_p, []),
     "demia_conv2d_nhwc": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "demia_conv2d_p32": (C.c_int, [C.POINTER(ConvP32Desc), C.c_void_p]),
     "demia_resize_h_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "demia_resize_v_norm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -113,6 +126,7 @@ EXPORTS = {
                                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "demia_mask_crop_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "demia_mask_crop_unpack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "demia_mask_gray_histogram": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "demia_contour_work_ints": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "demia_contour_work_floats": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "demia_contour_work_doubles": (C.c_int64, [C.c_int, C.c_int, C.c_int]),

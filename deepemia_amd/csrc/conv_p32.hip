@@ -1,0 +1,398 @@
+// f32-accurate convolution on the fp16 matrix pipe with BOTH operands pre-split in HBM ("P32" activations).
+//
+//   out[m, co] = act( (sum_k in[pixel(m, tap), ci] * w[co, tap, ci]) * scale[co] + bias[co] + residual[m, co] )
+//
+// Same arithmetic as the f16x2 mode of conv_mfma.hip -- every f32 value x travels as two fp16 planes of x * s
+// (s an exact power of two), x * s = h + l, h = half(x s), l = half(x s - h): 22 significand bits; a product is the
+// three MFMAs a_h b_l + a_l b_h + a_h b_h in the f32 accumulator of v_mfma_f32_32x32x16_f16, error <= 3 * 2^-22 |ab| --
+// but the split happens ONCE, in the epilogue of the layer that produces the tensor, not in every consumer's K loop:
+//
+//   P32 activation buffer = 128 zero bytes, then pixels [M][C / 32][2][32] fp16: per pixel and 32-channel group one
+//   128-byte line = 32 high halves, 32 low halves.  A K-step (32 channels of one tap) of one GEMM row is exactly one
+//   line, so the A tile is a pure row gather.  Padding taps and rows beyond M gather the zero header.
+//   meta = {amax, s} per tensor (device floats): `amax` is the measured max |x| (atomic max in the producer's
+//   epilogue, zeroed by the host before the forward), `s` the power of two the planes were scaled with.  The producer
+//   cannot know its own amax before it has written the tensor, so s comes from an a-priori bound instead:
+//   |out| <= amax_in * max_co(|scale_co| * sum_k |w_co,k|) + max |bias| (+ amax_residual), s = 2^(14 - ilogb(bound)),
+//   i.e. |x s| < 2^15.  The bound is loose by the usual sqrt(K)-ish factor, which only moves the point where the LOW
+//   plane goes denormal (absolute error <= 2^-39 of the bound); it never compounds because every layer starts again
+//   from the MEASURED amax of its input.
+//
+// Kernel shape (CDNA4, 64-wide waves): one workgroup of 8 waves (512 threads, <= 256 VGPRs) per CU computes a
+// BM x BN tile, BM = WM * TM * 32, BN = WN * TN * 32 (256 x 256 for the big layers), accumulators in registers.
+// Both operands go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds, 1 KiB per wave instruction, no staging
+// registers, no ds_write); the LDS image is linear (DMA writes lane-linear) and bank conflicts of the ds_read_b128
+// fragment reads are removed by an XOR swizzle applied to the SOURCE address of the DMA and to the read address
+// (chunk ^= (row >> 1) & 7).  Two LDS stages of one K-step (32 k, (BM + BN) * 128 B) each: the DMA of step t + 1 is
+// in flight while the MFMAs of step t run; one barrier per K-step.  K is walked channel-group outer, tap inner, so
+// the nine taps of a 3x3 layer re-read the same few lines from L2 while they are still there.
+//
+// Reference call sites replaced: every Conv2d / Linear / ConvTranspose2d executed by Detectron2 0.6
+// `GeneralizedRCNN.inference` under `predictor(image)` (reference src/functions/inference.py:1395,1398,1507,1669;
+// src/data/models.py:107).
+#include "common.h"
+
+namespace {
+
+struct ConvQ {
+    const void* in;
+    const float* in_meta;
+    const void* w;
+    const float* scale;
+    const float* bias;
+    const void* res;
+    const float* res_meta;
+    void* out;
+    float* out_meta;
+    float wbound, bbound;
+    int N, H, W, Cin, Ho, Wo, Cout, CoutPad, KH, KW, stride, pad;
+    int act, res_mode, out_f32, out_ld;
+    int M, HoWo, ntn, nwg, ksteps, taps;
+    unsigned in_bytes, w_bytes;
+};
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// One LDS-DMA piece: 64 lanes x 16 B from `rsrc` at byte offset voff (per lane) + soff (scalar) to LDS bytes
+// [lds_addr, lds_addr + 1024).  Inline asm on purpose: hipcc orders every later ds_read behind a builtin LDS-DMA with
+// s_waitcnt vmcnt(0) (it cannot prove the two stages disjoint), which would serialise the DMA of step t + 1 with the
+// MFMAs of step t.  The kernel counts these loads itself (s_waitcnt vmcnt(0) before the barrier that publishes a stage).
+__device__ __forceinline__ void dma16(const i32x4 rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+__device__ __forceinline__ i32x4 make_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+    i32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));      // stride 0
+    r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+    r[3] = 0x00020000;
+    return r;
+}
+
+__device__ __forceinline__ float apply_act_q(float v, int act) {
+    if (act == DEMIA_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == DEMIA_ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+    return v;
+}
+
+// power of two that brings |x| <= bound below 2^15
+__device__ __forceinline__ float plane_scale(float bound) {
+    if (!(bound > 0.f) || !(bound < 3.0e38f)) return 1.f;
+    int e = 14 - ilogbf(bound);
+    e = e < -100 ? -100 : (e > 100 ? 100 : e);
+    return ldexpf(1.f, e);
+}
+
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(512, 2) void conv_p32_kernel(const ConvQ p) {
+    static_assert(WM * WN == 8, "eight waves");
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int STAGE = (BM + BN) * 128;
+    constexpr int NIA = BM / 8, NIB = BN / 8;                     // 1-KiB DMA pieces (8 rows) per K-step
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int swz = xcd_remap(blockIdx.x, p.nwg);
+    const int tile_n = swz % p.ntn, tile_m = swz / p.ntn;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const i32x4 rsrc_a = make_rsrc(p.in, p.in_bytes), rsrc_b = make_rsrc(p.w, p.w_bytes);
+    const unsigned lds0 = (unsigned)(__SIZE_TYPE__)((lds_void*)smem);
+
+    // ---- DMA bookkeeping: wave w moves pieces w, w + 8, ... (8 rows = 1 KiB each) of the A tile and of the B tile ----
+    constexpr int QA = NIA / 8, QB = NIB / 8;
+    static_assert(NIA % 8 == 0 && NIB % 8 == 0, "tile sides are multiples of 64");
+    unsigned a_off[QA], a_msk[QA], b_off[QB];
+#pragma unroll
+    for (int q = 0; q < QA; ++q) {
+        const int row = (wave + 8 * q) * 8 + (lane >> 3);
+        const int csw = (lane & 7) ^ ((row >> 1) & 7);
+        const int m = m0 + row;
+        const bool vm = m < p.M;
+        const int mm = vm ? m : 0;
+        const int n = mm / p.HoWo;
+        const int rem = mm - n * p.HoWo;
+        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+        const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+        const long pix = ((long)n * p.H + hi0) * p.W + wi0;
+        a_off[q] = (unsigned)(128 + pix * (long)(p.Cin * 4) + csw * 16);
+        unsigned mk = 0;
+        for (int t = 0; t < p.taps; ++t) {
+            const int th = t / p.KW, tw = t - th * p.KW;
+            if (vm && (unsigned)(hi0 + th) < (unsigned)p.H && (unsigned)(wi0 + tw) < (unsigned)p.W) mk |= 1u << t;
+        }
+        a_msk[q] = mk;
+    }
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {
+        const int row = (wave + 8 * q) * 8 + (lane >> 3);
+        const int csw = (lane & 7) ^ ((row >> 1) & 7);
+        const int co = n0 + row;
+        b_off[q] = (unsigned)(((co >> 6) * p.ksteps) * 8192 + (co & 63) * 128 + csw * 16);
+    }
+    // K-step being REQUESTED: tap index, A byte offset of (tap, channel group), B byte offset -- all scalar
+    int tap = 0, kw = 0, tstep = 0;
+    unsigned sdelta = 0, srow = 0, sgrp = 0;
+    auto issue = [&](int st, int tp, unsigned sd, unsigned bd) {
+        const unsigned sbase = __builtin_amdgcn_readfirstlane(lds0 + st * STAGE + wave * 1024);
+#pragma unroll
+        for (int q = 0; q < QA; ++q) {
+            const bool ok = (a_msk[q] >> tp) & 1u;
+            const unsigned vo = ok ? a_off[q] + sd : (a_off[q] & 0x70u);     // padding taps / rows beyond M: the zero header
+            dma16(rsrc_a, sbase + q * 8192, vo, 0u);
+        }
+#pragma unroll
+        for (int q = 0; q < QB; ++q) dma16(rsrc_b, sbase + BM * 128 + q * 8192, b_off[q], bd);
+    };
+    const unsigned pixb = (unsigned)(p.Cin * 4), rowb = (unsigned)(p.W * p.Cin * 4);
+#define P32_ADVANCE()                                                                   \
+    do {                                                                                \
+        ++tstep;                                                                        \
+        if (++tap == p.taps) { tap = 0; kw = 0; srow = 0; sgrp += 128u; sdelta = sgrp; } \
+        else if (++kw == p.KW) { kw = 0; srow += rowb; sdelta = srow + sgrp; }          \
+        else sdelta += pixb;                                                            \
+    } while (0)
+
+    // ---- fragment read addresses: row r of a tile at r * 128, 16-byte chunk c of it at (c ^ ((r >> 1) & 7)) * 16;
+    //      chunk = plane * 4 + kk * 2 + (lane >> 5) ----
+    const int fsw = (lane >> 1) & 7, hh = lane >> 5;
+    int fa[4], fb[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int ch = (((c >> 1) * 4 + (c & 1) * 2 + hh) ^ fsw) * 16;
+        fa[c] = (wm * TM * 32 + (lane & 31)) * 128 + ch;
+        fb[c] = BM * 128 + (wn * TN * 32 + (lane & 31)) * 128 + ch;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto compute = [&](int st) {
+        const char* sb = smem + st * STAGE;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            uint4 bh[TN], bl[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                bh[j] = *reinterpret_cast<const uint4*>(sb + fb[kk] + j * 4096);
+                bl[j] = *reinterpret_cast<const uint4*>(sb + fb[2 + kk] + j * 4096);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const uint4 ah = *reinterpret_cast<const uint4*>(sb + fa[kk] + i * 4096);
+                const uint4 al = *reinterpret_cast<const uint4*>(sb + fa[2 + kk] + i * 4096);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    f32x16 c = acc[i][j];     // smallest terms first
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(&ah), *reinterpret_cast<const f16x8*>(&bl[j]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(&al), *reinterpret_cast<const f16x8*>(&bh[j]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(&ah), *reinterpret_cast<const f16x8*>(&bh[j]), c, 0, 0, 0);
+                    acc[i][j] = c;
+                }
+            }
+        }
+    };
+
+    // ---- K loop: DMA of step t + 1 in flight under the MFMAs of step t; one barrier per step ----
+    issue(0, tap, sdelta, 0u);
+    P32_ADVANCE();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int t = 0; t < p.ksteps; ++t) {
+        const int st = t & 1;
+        if (t + 1 < p.ksteps) {                   // that stage was last read before the previous barrier
+            issue(st ^ 1, tap, sdelta, (unsigned)tstep * 8192u);
+            P32_ADVANCE();
+        }
+        compute(st);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+#undef P32_ADVANCE
+
+    // ---- epilogue: TM passes; in pass i every wave hands tile-row i of its accumulators to LDS, then the 512 threads
+    //      walk the WM * 32 rows x BN columns in 8-channel groups: scale / bias / residual / activation, split, 16-byte stores
+    constexpr int EROW = BN * 4 + 16;
+    constexpr int GPR = BN / 8, RSTEP = 512 / GPR, ITEMS = WM * 32 / RSTEP;
+    static_assert(WM * 32 * EROW <= 2 * STAGE, "epilogue image fits the stages");
+    static_assert(512 % GPR == 0 && (WM * 32) % RSTEP == 0, "epilogue split");
+    const float s_in = p.in_meta[1];
+    const float post = 1.0f / s_in;
+    float s_out = 1.f, res_inv = 0.f;
+    if (p.res_mode != DEMIA_RES_NONE) res_inv = 1.0f / p.res_meta[1];
+    if (!p.out_f32) {
+        const float bound = p.in_meta[0] * p.wbound + p.bbound + (p.res_mode != DEMIA_RES_NONE ? p.res_meta[0] : 0.f);
+        s_out = plane_scale(bound);
+        if (blockIdx.x == 0 && tid == 0) p.out_meta[1] = s_out;
+    }
+    const int g = tid % GPR, r_first = tid / GPR;
+    const int co = n0 + g * 8;
+    float sc[8], bs[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const bool ok = (co + q) < p.Cout;
+        sc[q] = (p.scale && ok) ? p.scale[co + q] * post : post;
+        bs[q] = (p.bias && ok) ? p.bias[co + q] : 0.0f;
+    }
+    float vmax = 0.f;
+    const char* resb = reinterpret_cast<const char*>(p.res) + 128;
+    char* outb = reinterpret_cast<char*>(p.out) + 128;
+    const long cbytes = (long)p.Cout * 4;                       // bytes per P32 pixel of the output / residual
+    const int gofs = (co >> 5) * 128 + ((co & 31) >> 3) * 16;   // this thread's 8 channels inside a pixel (high plane)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        if (i > 0) __syncthreads();
+        {
+            float* e = reinterpret_cast<float*>(smem);
+            constexpr int EF = EROW / 4;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const int col = wn * TN * 32 + j * 32 + (lane & 31);
+                    e[row * EF + col] = acc[i][j][r];
+                }
+        }
+        __syncthreads();
+        if (co < p.Cout) {
+#pragma unroll
+            for (int k = 0; k < ITEMS; ++k) {
+                const int lr = r_first + k * RSTEP;
+                const int m = m0 + (lr >> 5) * (TM * 32) + i * 32 + (lr & 31);
+                if (m >= p.M) continue;
+                const float4 x0 = *reinterpret_cast<const float4*>(smem + lr * EROW + g * 32);
+                const float4 x1 = *reinterpret_cast<const float4*>(smem + lr * EROW + g * 32 + 16);
+                float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = v[q] * sc[q] + bs[q];
+                if (p.res_mode != DEMIA_RES_NONE) {
+                    long rp;
+                    if (p.res_mode == DEMIA_RES_SAME) {
+                        rp = m;
+                    } else {
+                        const int n = m / p.HoWo;
+                        const int rem = m - n * p.HoWo;
+                        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+                        const int Hr = (p.Ho + 1) >> 1, Wr = (p.Wo + 1) >> 1;
+                        rp = ((long)n * Hr + (ho >> 1)) * Wr + (wo >> 1);
+                    }
+                    const f16x8 rh = *reinterpret_cast<const f16x8*>(resb + rp * cbytes + gofs);
+                    const f16x8 rl = *reinterpret_cast<const f16x8*>(resb + rp * cbytes + gofs + 64);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] += ((float)rh[q] + (float)rl[q]) * res_inv;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = apply_act_q(v[q], p.act);
+                if (p.out_f32) {
+                    float* o = reinterpret_cast<float*>(p.out) + (long)m * p.out_ld + co;
+                    if (co + 8 <= p.Cout && (p.out_ld & 3) == 0) {
+                        *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+                        *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q)
+                            if (co + q < p.Cout) o[q] = v[q];
+                    }
+                } else {
+                    f16x8 h, l;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        vmax = fmaxf(vmax, fabsf(v[q]));
+                        const float y = v[q] * s_out;
+                        h[q] = (_Float16)y;
+                        l[q] = (_Float16)(y - (float)h[q]);
+                    }
+                    char* o = outb + (long)m * cbytes + gofs;
+                    *reinterpret_cast<f16x8*>(o) = h;
+                    *reinterpret_cast<f16x8*>(o + 64) = l;
+                }
+            }
+        }
+    }
+    if (!p.out_f32) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+        // the bound only grows: a (possibly stale) read that already covers this wave's maximum makes the atomic unnecessary
+        if (lane == 0 && vmax > *reinterpret_cast<volatile const float*>(p.out_meta))
+            atomicMax(reinterpret_cast<unsigned int*>(p.out_meta), __float_as_uint(vmax));
+    }
+}
+
+template <int WM, int WN, int TM, int TN>
+int launch_q(ConvQ p, hipStream_t st) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int smem = 2 * (BM + BN) * 128;
+    p.ntn = p.CoutPad / BN;
+    p.nwg = p.ntn * cdiv(p.M, BM);
+    auto k = conv_p32_kernel<WM, WN, TM, TN>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k, dim3(p.nwg), dim3(512), smem, st, p);
+    DEMIA_CHECK_LAUNCH("conv_p32_kernel");
+    return DEMIA_OK;
+}
+
+// a launch lasts as long as the CU with the most tiles: efficiency of a tile height = (tiles / 256) / ceil(tiles / 256),
+// weighted by what the taller tile saves in weight-plane re-reads (rate)
+inline double balance(long tiles) { return ((double)tiles / 256.0) / (double)((tiles + 255) / 256); }
+
+}  // namespace
+
+extern "C" int demia_conv2d_p32(const demia_conv_p32_desc* d, void* stream) {
+    DEMIA_REQUIRE(d && d->in && d->in_meta && d->w && d->out, "null pointer");
+    DEMIA_REQUIRE(d->out_f32 || d->out_meta, "P32 output needs out_meta");
+    DEMIA_REQUIRE(d->Cin > 0 && d->Cin % 32 == 0, "Cin must be a multiple of 32");
+    DEMIA_REQUIRE(d->CoutPad >= d->Cout && d->CoutPad % 64 == 0, "CoutPad must be a multiple of 64");
+    DEMIA_REQUIRE(d->out_f32 || d->Cout % 32 == 0, "P32 output needs Cout % 32 == 0");
+    DEMIA_REQUIRE(d->KH > 0 && d->KW > 0 && d->KH * d->KW <= 32 && d->stride > 0 && d->pad >= 0, "kernel geometry");
+    DEMIA_REQUIRE(d->Ho == (d->H + 2 * d->pad - d->KH) / d->stride + 1, "Ho");
+    DEMIA_REQUIRE(d->Wo == (d->W + 2 * d->pad - d->KW) / d->stride + 1, "Wo");
+    DEMIA_REQUIRE(d->res_mode == DEMIA_RES_NONE || (d->residual && d->res_meta), "residual pointer");
+    DEMIA_REQUIRE((long)d->N * d->Ho * d->Wo < (1L << 31), "M overflow");
+    const long in_bytes = 128 + (long)d->N * d->H * d->W * d->Cin * 4;
+    DEMIA_REQUIRE(in_bytes < (1L << 32), "input planes must stay below 4 GiB");
+    const long w_bytes = (long)d->CoutPad * d->KH * d->KW * d->Cin * 4;
+    DEMIA_REQUIRE(w_bytes < (1L << 31), "weight planes must stay below 2 GiB");
+    ConvQ p;
+    p.in = d->in; p.in_meta = d->in_meta; p.w = d->w; p.scale = d->scale; p.bias = d->bias;
+    p.res = d->residual; p.res_meta = d->res_meta; p.out = d->out; p.out_meta = d->out_meta;
+    p.wbound = d->wbound; p.bbound = d->bbound;
+    p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout; p.CoutPad = d->CoutPad;
+    p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad;
+    p.act = d->act; p.res_mode = d->res_mode; p.out_f32 = d->out_f32;
+    p.out_ld = d->out_ld > 0 ? d->out_ld : d->Cout;
+    DEMIA_REQUIRE(p.out_ld >= d->Cout, "out_ld");
+    p.M = d->N * d->Ho * d->Wo;
+    p.HoWo = d->Ho * d->Wo;
+    p.taps = d->KH * d->KW;
+    p.ksteps = p.taps * (d->Cin / 32);
+    p.in_bytes = (unsigned)in_bytes; p.w_bytes = (unsigned)w_bytes;
+    p.ntn = p.nwg = 0;
+    if (p.M == 0) return DEMIA_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int th = d->tile_hint;        // 0 = auto, else BM * 1000 + BN
+    if (d->CoutPad % 256 == 0) {
+        const long nt = d->CoutPad / 256;
+        const long t256 = nt * cdiv(p.M, 256), t128 = nt * cdiv(p.M, 128);
+        const bool half = th ? th == 128256 : (t256 < 256 || 0.85 * balance(t128) > balance(t256));
+        if (half) return launch_q<2, 4, 2, 2>(p, st);     // 128 x 256
+        return launch_q<2, 4, 4, 2>(p, st);               // 256 x 256
+    }
+    if (d->CoutPad % 128 == 0) return launch_q<4, 2, 2, 2>(p, st);      // 256 x 128
+    return launch_q<8, 1, 1, 2>(p, st);                                  // 256 x 64
+}

@@ -303,6 +303,45 @@ inline int grid_for(long total, int block) {
     return (int)(g > 32768 ? 32768 : (g < 1 ? 1 : g));
 }
 
+// 256-bin histogram of the gray image under one mask (measurements.py:197-205: cv2.cvtColor(BGR2GRAY) then
+// np.histogram(gray[mask > 0], bins=256, range=(0, 255)): with integer data bin i holds the pixels of value i).
+// One workgroup per mask over its bbox words; BGR -> gray is OpenCV's 8-bit fixed point (B 1868, G 9617, R 4899, >> 14).
+__global__ __launch_bounds__(256) void gray_hist_kernel(const uint32_t* __restrict__ masks, const int* __restrict__ bbox,
+                                                        const uint8_t* __restrict__ img, int channels, int H, int W,
+                                                        int* __restrict__ hist) {
+    __shared__ int s_h[256];
+    const long m = blockIdx.x;
+    const int wpr = (W + 31) >> 5;
+    s_h[threadIdx.x] = 0;
+    __syncthreads();
+    const int y0 = bbox[m * 4 + 0], x0 = bbox[m * 4 + 1], y1 = bbox[m * 4 + 2], x1 = bbox[m * 4 + 3];
+    if (y0 >= 0) {
+        const int ry0 = max(y0, 0), rh = min(y1, H - 1) - ry0 + 1;
+        const int wx0 = max(x0, 0) >> 5, rw = (min(x1, W - 1) >> 5) - wx0 + 1;
+        const uint32_t* src = masks + m * (long)H * wpr;
+        for (int i = threadIdx.x; i < rh * rw; i += blockDim.x) {
+            const int ly = i / rw, lx = i - ly * rw;
+            const int y = ry0 + ly;
+            uint32_t b = src[(long)y * wpr + wx0 + lx];
+            while (b) {
+                const int bit = __ffs((int)b) - 1;
+                b &= b - 1;
+                const long px = (long)y * W + ((wx0 + lx) << 5) + bit;
+                int g;
+                if (channels == 3) {
+                    const uint8_t* q = img + px * 3;
+                    g = (q[0] * 1868 + q[1] * 9617 + q[2] * 4899 + (1 << 13)) >> 14;
+                } else {
+                    g = img[px];
+                }
+                atomicAdd(&s_h[g], 1);
+            }
+        }
+    }
+    __syncthreads();
+    hist[m * 256 + threadIdx.x] = s_h[threadIdx.x];
+}
+
 }  // namespace
 
 extern "C" int demia_mask_program(uint32_t* masks, uint32_t* scratch, const int32_t* bbox, const uint8_t* active, uint32_t program,
@@ -385,5 +424,14 @@ extern "C" int demia_mask_crop_unpack(const uint32_t* payload, const int32_t* bb
     hipLaunchKernelGGL(crop_copy_kernel<false>, dim3((int)M), dim3(256), 0, (hipStream_t)stream, masks, bbox,
                        reinterpret_cast<const long*>(offsets), H, W, const_cast<uint32_t*>(payload));
     DEMIA_CHECK_LAUNCH("crop_copy_kernel<unpack>");
+    return DEMIA_OK;
+}
+
+extern "C" int demia_mask_gray_histogram(const uint32_t* masks, const int32_t* bbox, const uint8_t* image, int channels,
+                                         int64_t M, int H, int W, int32_t* hist, void* stream) {
+    DEMIA_REQUIRE(masks && bbox && image && hist && W > 0 && (channels == 1 || channels == 3), "args");
+    if (M == 0) return DEMIA_OK;
+    hipLaunchKernelGGL(gray_hist_kernel, dim3((int)M), dim3(256), 0, (hipStream_t)stream, masks, bbox, image, channels, H, W, hist);
+    DEMIA_CHECK_LAUNCH("gray_hist_kernel");
     return DEMIA_OK;
 }

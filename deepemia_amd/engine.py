@@ -136,6 +136,16 @@ def tile_weight_planes(w3: torch.Tensor, bk: int = 32) -> torch.Tensor:
     return w3.reshape(npl, cout_pad // 64, 64, k // bk, bk).permute(1, 3, 0, 2, 4).contiguous()
 
 
+def tile_weight_planes_p32(planes: torch.Tensor) -> torch.Tensor:
+    """[2, CoutPad, KH, KW, Cin] fp16 planes -> the layout ``demia_conv2d_p32`` streams by LDS-DMA:
+    [CoutPad / 64, ksteps, 64, 2, 32] with K walked channel-group OUTER, tap inner (``include/deepemia_hip.h``): the 64
+    rows x (32 high + 32 low halves) of one K-step are 8 KiB contiguous, one 128-byte line per output channel."""
+    _, cout_pad, kh, kw, cin = (int(d) for d in planes.shape)
+    assert cout_pad % 64 == 0 and cin % 32 == 0, (cout_pad, cin)
+    t = planes.reshape(2, cout_pad // 64, 64, kh * kw, cin // 32, 32)
+    return t.permute(1, 4, 3, 2, 0, 5).contiguous()        # [n64, cg, tap, 64, plane, 32]
+
+
 def split2_f16_scaled(w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """f16x2 weights: per output channel (dim 0) an exact power-of-two scale ``sw`` that brings max |w| into
     [2^14, 2^15), then ``w * sw = h + l`` with h = half(w * sw), l = half(w * sw - h) (22 significand bits).

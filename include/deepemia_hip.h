@@ -96,6 +96,41 @@ int demia_conv2d_nhwc(const demia_conv_desc* d, void* stream);
 /* K-step of this build's DEMIA_F16X2 kernel = innermost extent of its weight-plane tiling (32 unless built otherwise) */
 int demia_conv_f16x2_kstep(void);
 
+/* a3: the same convolution with BOTH operands pre-split into fp16 planes ("P32" activations) -------------------
+ * The default arithmetic of the product path (precision "f16x2"): f32-sized error from three fp16 MFMAs per
+ * product, operands moved global -> LDS by LDS-DMA.  Replaces the same Detectron2 layers as demia_conv2d_nhwc.
+ *   P32 activation buffer: 128 zero bytes, then [pixels][C / 32][2][32] fp16 -- per pixel and 32-channel group one
+ *       128-byte line of 32 high halves + 32 low halves of x * s (s = meta[1], an exact power of two; x = (h + l) / s).
+ *       The caller zeroes the 128-byte header once; padding taps read it.
+ *   meta: 2 device floats per tensor: [0] = max |x| (atomic max, accumulated by the producing kernel; the caller zeroes
+ *       it before every forward), [1] = s (written by the producing kernel).
+ *   w: [CoutPad / 64][ksteps][64][2][32] fp16, ksteps = (Cin / 32) * KH * KW walked channel-group OUTER, tap inner;
+ *       planes of w * 2^e(co) (max |.| in [2^14, 2^15) per output channel, the caller divides `scale` by 2^e(co)).
+ *   wbound = max_co(|scale_co| * sum_k |w_co,k|) (true weights), bbound = max |bias|: the kernel scales its P32 output
+ *       with s = 2^(14 - ilogb(in_meta[0] * wbound + bbound + res_meta[0])), so that |out * s| < 2^15.
+ *   out: P32 (out_f32 = 0; Cout % 32 == 0; out_meta required) or plain f32 [M, out_ld] (out_f32 = 1).
+ *   residual: P32 of the output's shape (RES_SAME) or half resolution (RES_UP2), with its meta.               */
+typedef struct demia_conv_p32_desc {
+    const void* in;
+    const float* in_meta;
+    const void* w;
+    const float* scale;
+    const float* bias;
+    const void* residual;
+    const float* res_meta;
+    void* out;
+    float* out_meta;
+    float wbound, bbound;
+    int32_t N, H, W, Cin;
+    int32_t Ho, Wo, Cout, CoutPad;
+    int32_t KH, KW, stride, pad;
+    int32_t act, res_mode;
+    int32_t out_f32;
+    int32_t out_ld;          /* f32 output: elements between consecutive output pixels (>= Cout); 0 -> Cout */
+    int32_t tile_hint;       /* 0 = auto; else BM * 1000 + BN of an instantiated tile */
+} demia_conv_p32_desc;
+int demia_conv2d_p32(const demia_conv_p32_desc* d, void* stream);
+
 /* a3: Pillow-exact ResizeShortestEdge + (x - mean) + zero pad -------------------------
  * Replaces T.ResizeShortestEdge.get_transform(img).apply_image(img) +
  * normalisation + ImageList.from_tensors inside DefaultPredictor.__call__ /
@@ -276,6 +311,15 @@ int demia_mask_crop_pack(const uint32_t* masks, const int32_t* bbox, const int64
                          uint32_t* payload, void* stream);
 int demia_mask_crop_unpack(const uint32_t* payload, const int32_t* bbox, const int64_t* offsets, int64_t M, int H, int W,
                            uint32_t* masks, void* stream);
+
+/* a18: contrast distribution (measurements.py:195-215, switched by `measure_contrast_distribution`, inference.py:58,1198):
+ * per mask the 256-bin histogram of gray = cv2.cvtColor(image, COLOR_BGR2GRAY) over the mask's pixels -- what
+ * np.histogram(gray[mask > 0], bins=256, range=(0, 255)) counts (integer data: bin i = pixels of value i).  The CDF and the
+ * three np.interp calls on 256 numbers stay on the host.
+ *   image [H, W, channels] u8 (channels 3 = BGR, 1 = already gray); bbox [M, 4] a superset of each mask's tight box (-1: empty);
+ *   hist [M, 256] i32 (written, not accumulated).                                                                        */
+int demia_mask_gray_histogram(const uint32_t* masks, const int32_t* bbox, const uint8_t* image, int channels,
+                              int64_t M, int H, int W, int32_t* hist, void* stream);
 
 /* a17/a18: contours and morphometrics ---------------------------------------------------------
  * demia_mask_contours = cv2.findContours(mask, RETR_EXTERNAL, CHAIN_APPROX_SIMPLE) per mask

@@ -1,0 +1,200 @@
+"""Dev script (GPU): demia_conv2d_p32 against an f64 convolution on a set of shapes, then its rate on the R101 layers
+beside the register-staged f16x2 kernel (demia_conv2d_nhwc) on the same shapes.  usage: gpu_conv_p32_check.py [check|time|all]"""
+import ctypes as C
+import sys
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, '.')
+from deepemia_amd import _lib, p32, engine as E        # noqa: E402
+from deepemia_amd._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, RES_NONE, RES_SAME, RES_UP2, F16X2, F32   # noqa: E402
+
+dev = torch.device('cuda:0')
+lib = _lib.load()
+st = lambda: int(torch.cuda.current_stream(dev).cuda_stream)
+
+
+class Layer:
+    def __init__(self, cout, cin, kh, kw, seed=0, bn=True):
+        g = torch.Generator().manual_seed(seed)
+        w = torch.randn(cout, cin, kh, kw, generator=g) * (2.0 / (cin * kh * kw)) ** 0.5
+        self.w = w
+        self.cout, self.cin, self.kh, self.kw = cout, cin, kh, kw
+        self.cout_pad = (cout + 63) // 64 * 64
+        wp = torch.zeros(self.cout_pad, kh, kw, cin)
+        wp[:cout] = w.permute(0, 2, 3, 1)
+        self.scale = (0.5 + torch.rand(cout, generator=g)) if bn else torch.ones(cout)
+        self.bias = torch.randn(cout, generator=g) * 0.1
+        planes, sw = E.split2_f16_scaled(wp.to(dev))
+        self.planes, self.sw = planes, sw
+        self.w_p32 = E.tile_weight_planes_p32(planes)
+        self.w_old = E.tile_weight_planes(planes, int(lib.demia_conv_f16x2_kstep()))
+        self.scale3 = (self.scale.to(dev) / sw[:cout]).contiguous()
+        self.bias_d = self.bias.to(dev).contiguous()
+        self.wq = ((planes[0].double() + planes[1].double()) / sw.double().view(-1, 1, 1, 1))[:cout].permute(0, 3, 1, 2).contiguous()
+        self.wbound = float((self.scale.abs() * w.abs().flatten(1).sum(1)).max())
+        self.bbound = float(self.bias.abs().max())
+
+
+def conv_p32(x: p32.P32, L: Layer, stride=1, pad=0, act=ACT_NONE, res=None, res_mode=RES_NONE, out_f32=False, out_ld=0, hint=0):
+    n, h, w, cin = x.shape
+    ho = (h + 2 * pad - L.kh) // stride + 1
+    wo = (w + 2 * pad - L.kw) // stride + 1
+    if out_f32:
+        ld = out_ld or L.cout
+        out = torch.zeros((n, ho, wo, ld), dtype=torch.float32, device=dev)
+        optr, ometa = _lib.ptr(out), 0
+    else:
+        out = p32.alloc((n, ho, wo, L.cout), dev)
+        optr, ometa = _lib.ptr(out.buf), _lib.ptr(out.meta)
+    d = _lib.ConvP32Desc(_lib.ptr(x.buf), _lib.ptr(x.meta), _lib.ptr(L.w_p32), _lib.ptr(L.scale3), _lib.ptr(L.bias_d),
+                         _lib.ptr(res.buf) if res is not None else 0, _lib.ptr(res.meta) if res is not None else 0, optr, ometa,
+                         L.wbound, L.bbound, n, h, w, cin, ho, wo, L.cout, L.cout_pad, L.kh, L.kw, stride, pad, act, res_mode,
+                         1 if out_f32 else 0, out_ld, hint)
+    _lib.check(lib.demia_conv2d_p32(C.byref(d), st()), 'demia_conv2d_p32')
+    return out
+
+
+def conv_old(x: torch.Tensor, amax: torch.Tensor, L: Layer, stride=1, pad=0, act=ACT_NONE):
+    n, h, w, cin = x.shape
+    ho = (h + 2 * pad - L.kh) // stride + 1
+    wo = (w + 2 * pad - L.kw) // stride + 1
+    out = torch.empty((n, ho, wo, L.cout), dtype=torch.float32, device=dev)
+    am = torch.zeros(1, dtype=torch.float32, device=dev)
+    d = _lib.ConvDesc(_lib.ptr(x), _lib.ptr(L.w_old), _lib.ptr(L.scale3), _lib.ptr(L.bias_d), 0, _lib.ptr(out), n, h, w, cin, ho, wo,
+                      L.cout, L.cout_pad, L.kh, L.kw, stride, pad, F16X2, F32, act, RES_NONE, L.cout, 0, _lib.ptr(amax), _lib.ptr(am))
+    _lib.check(lib.demia_conv2d_nhwc(C.byref(d), st()), 'demia_conv2d_nhwc')
+    return out
+
+
+def reference(xq, L, stride, pad, act, res=None, res_mode=RES_NONE):
+    y = F.conv2d(xq.double().permute(0, 3, 1, 2), L.wq, None, stride, pad).permute(0, 2, 3, 1)
+    y = y * L.scale.double().to(dev) + L.bias.double().to(dev)
+    if res is not None:
+        r = res.double()
+        if res_mode == RES_UP2:
+            r = r.repeat_interleave(2, 1).repeat_interleave(2, 2)[:, :y.shape[1], :y.shape[2]]
+        y = y + r
+    if act == ACT_RELU:
+        y = y.clamp(min=0)
+    if act == ACT_SIGMOID:
+        y = torch.sigmoid(y)
+    return y
+
+
+def check():
+    cases = [
+        # n, h, w, cin, cout, k, stride, pad, act, res_mode, out_f32, hint
+        (2, 50, 50, 256, 256, 3, 1, 1, ACT_RELU, RES_NONE, False, 0),
+        (2, 50, 50, 256, 256, 3, 1, 1, ACT_RELU, RES_NONE, False, 128256),
+        (1, 37, 29, 64, 64, 3, 1, 1, ACT_RELU, RES_NONE, False, 0),
+        (3, 40, 40, 256, 128, 1, 2, 0, ACT_RELU, RES_NONE, False, 0),
+        (2, 25, 25, 256, 1024, 1, 1, 0, ACT_RELU, RES_SAME, False, 0),
+        (2, 26, 25, 512, 256, 1, 1, 0, ACT_NONE, RES_UP2, False, 0),
+        (2, 50, 50, 256, 15, 1, 1, 0, ACT_NONE, RES_NONE, True, 0),
+        (1, 1, 1000, 12544, 1024, 1, 1, 0, ACT_RELU, RES_NONE, False, 0),
+        (1, 1, 300, 1024, 11, 1, 1, 0, ACT_NONE, RES_NONE, True, 0),
+        (4, 14, 14, 256, 256, 3, 1, 1, ACT_RELU, RES_NONE, False, 0),
+        (1, 20, 784, 256, 2, 1, 1, 0, ACT_SIGMOID, RES_NONE, True, 0),
+        (1, 200, 200, 64, 256, 1, 1, 0, ACT_NONE, RES_NONE, False, 0),
+    ]
+    worst = 0.0
+    for ci, (n, h, w, cin, cout, k, s, pd, act, rm, of32, hint) in enumerate(cases):
+        g = torch.Generator().manual_seed(100 + ci)
+        x = (torch.randn(n, h, w, cin, generator=g) * 3.0).to(dev)
+        x[..., :7] *= 1e-3                                     # small channels beside large ones
+        L = Layer(cout, cin, k, k, seed=ci)
+        xp = p32.from_f32(x)
+        xq = p32.to_f32(xp)
+        ho = (h + 2 * pd - k) // s + 1
+        wo = (w + 2 * pd - k) // s + 1
+        res = resq = None
+        if rm == RES_SAME:
+            res = p32.from_f32((torch.randn(n, ho, wo, cout, generator=g) * 2.0).to(dev))
+        elif rm == RES_UP2:
+            res = p32.from_f32((torch.randn(n, (ho + 1) // 2, (wo + 1) // 2, cout, generator=g) * 2.0).to(dev))
+        if res is not None:
+            resq = p32.to_f32(res)
+        ld = (cout + 3) // 4 * 4 if of32 else 0
+        out = conv_p32(xp, L, s, pd, act, res, rm, of32, ld, hint)
+        torch.cuda.synchronize()
+        ref = reference(xq, L, s, pd, act, resq, rm)
+        if of32:
+            got = out[..., :cout].double()
+        else:
+            got = p32.to_f32(out).double()
+            amax, sc = float(out.meta[0]), float(out.meta[1])
+            true_max = float(ref.abs().max())
+            assert abs(amax - true_max) <= 1e-5 * true_max, (amax, true_max)
+            assert true_max * sc < 32768.0, (true_max, sc)
+        err = float((got - ref).abs().max() / ref.abs().max())
+        worst = max(worst, err)
+        print(f'case {ci}: n{n} {h}x{w} cin{cin} cout{cout} k{k} s{s} act{act} res{rm} f32out{int(of32)} hint{hint}: rel err {err:.2e}', flush=True)
+        assert err < 3e-6, err
+    print(f'check ok, worst {worst:.2e}')
+
+
+R101_B16 = [
+    # (count, M-shape n h w, cin, cout, k, stride)
+    (2, (16, 200, 200), 256, 256, 3, 1),
+    (4, (1600, 14, 14), 256, 256, 3, 1),
+    (25, (16, 50, 50), 256, 256, 3, 1),
+    (23, (16, 50, 50), 256, 1024, 1, 1),
+    (23, (16, 50, 50), 1024, 256, 1, 1),
+    (1, (1, 1, 16000), 12544, 1024, 1, 1),
+    (4, (16, 200, 200), 64, 256, 1, 1),
+    (2, (16, 100, 100), 256, 256, 3, 1),
+    (1, (1, 1, 313600), 256, 1024, 1, 1),
+    (4, (16, 100, 100), 128, 512, 1, 1),
+    (4, (16, 100, 100), 128, 128, 3, 1),
+    (3, (16, 200, 200), 64, 64, 3, 1),
+    (3, (16, 25, 25), 512, 512, 3, 1),
+    (1, (16, 200, 200), 256, 256, 1, 1),
+    (2, (16, 200, 200), 256, 64, 1, 1),
+    (3, (16, 100, 100), 512, 128, 1, 1),
+    (3, (16, 25, 25), 512, 2048, 1, 1),
+]
+
+
+def timeit(fn, reps=5):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def time_layers():
+    tot_new = tot_old = tot_fl = 0.0
+    for cnt, (n, h, w), cin, cout, k, s in R101_B16:
+        L = Layer(cout, cin, k, k, seed=1)
+        x = torch.randn(n, h, w, cin, device=dev)
+        xp = p32.from_f32(x)
+        amax = x.abs().max().reshape(1)
+        pd = k // 2
+        fl = 2.0 * n * (h // s) * (w // s) * cout * cin * k * k
+        hints = [0] if cout % 256 else [256256, 128256]
+        res = []
+        for hint in hints:
+            res.append(timeit(lambda: conv_p32(xp, L, s, pd, ACT_RELU, hint=hint)))
+        t_old = timeit(lambda: conv_old(x, amax, L, s, pd, ACT_RELU))
+        t_new = min(res)
+        tot_new += cnt * t_new
+        tot_old += cnt * t_old
+        tot_fl += cnt * fl
+        print(f'M={n*h*w//(s*s):7d} cin={cin:5d} cout={cout:5d} k{k} x{cnt:2d}: p32 ' + ' / '.join(f'{fl/t/1e9:6.1f}' for t in res) +
+              f' TF/s ({t_new*1e3:7.1f} us)   old f16x2 {fl/t_old/1e9:6.1f} TF/s ({t_old*1e3:7.1f} us)', flush=True)
+    print(f'weighted total: p32 {tot_new:.2f} ms = {tot_fl/tot_new/1e9:.1f} TF/s; old {tot_old:.2f} ms = {tot_fl/tot_old/1e9:.1f} TF/s')
+
+
+if __name__ == '__main__':
+    mode = sys.argv[1] if len(sys.argv) > 1 else 'all'
+    if mode in ('check', 'all'):
+        check()
+    if mode in ('time', 'all'):
+        time_layers()
