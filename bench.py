@@ -28,7 +28,7 @@ import torch
 # dense MFMA peaks, MI355X_MICROARCH.md.  f16x2 (default) computes the f32 product with three fp16 MFMAs per tile (two
 # scaled fp16 planes per operand): its roof in f32-equivalent FLOP/s is the fp16 peak / 3; f32x3 = six bf16 MFMAs per
 # tile (three bf16 planes): bf16 peak / 6.
-PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f32x3": 2500.0 / 6, "bf16x2": 2500.0 / 3, "f16x2": 2500.0 / 3}
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f32x3": 2500.0 / 6, "bf16x2": 2500.0 / 3, "f16x2": 2500.0 / 3, "f16x2r": 2500.0 / 3}
 
 
 CLASS_THRESHOLDS = {0: (0.3, 0.7), 1: (0.3, 0.5)}   # class -> (confidence, IoU) as in config.yaml class_0 / class_1
@@ -73,7 +73,7 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="tiles per GPU per step")
-    ap.add_argument("--precision", choices=["f32", "f32x3", "f16x2", "bf16x2", "bf16"], default="f16x2")
+    ap.add_argument("--precision", choices=["f32", "f32x3", "f16x2", "f16x2r", "bf16x2", "bf16"], default="f16x2")
     ap.add_argument("--depth", type=int, default=101)
     ap.add_argument("--size", type=int, default=2048)
     ap.add_argument("--threshold", type=float, default=0.3)

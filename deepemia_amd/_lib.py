@@ -13,7 +13,7 @@ from pathlib import Path
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "csrc" / "libdeepemia_hip.so"
 
-F32, BF16, F32X3, BF16X2, F16X2 = 0, 1, 2, 3, 4
+F32, BF16, F32X3, BF16X2, F16X2, P32 = 0, 1, 2, 3, 4, 5
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 RES_NONE, RES_SAME, RES_UP2 = 0, 1, 2
 # stage codes of demia_mask_program (DEMIA_MOP_*)
@@ -68,6 +68,7 @@ class RoiAlignDesc(C.Structure):
         ("feat", C.c_void_p * 4), ("H", C.c_int32 * 4), ("W", C.c_int32 * 4),
         ("N", C.c_int32), ("R", C.c_int32), ("C", C.c_int32), ("P", C.c_int32), ("dtype", C.c_int32),
         ("boxes", C.c_void_p), ("count", C.c_void_p), ("out", C.c_void_p),
+        ("meta", C.c_void_p * 4), ("out_meta", C.c_void_p),
     ]
 
 
@@ -108,6 +109,7 @@ EXPORTS = {
     "demia_stem_conv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                    C.c_int, C.c_int, C.c_void_p]),
     "demia_maxpool3x3s2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "demia_maxpool3x3s2_p32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "demia_subsample2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "demia_rpn_workspace_bytes": (C.c_int64, [C.c_int]),
     "demia_rpn_proposals": (C.c_int, [C.POINTER(RpnDesc), C.c_void_p]),

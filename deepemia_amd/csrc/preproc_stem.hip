@@ -221,6 +221,54 @@ __global__ void maxpool3x3s2_kernel(const T* __restrict__ in, T* __restrict__ ou
     }
 }
 
+// maxpool 3x3 s2 p1 from f32 into P32 planes (conv_p32.hip): 8 channels per thread, 16-byte stores per plane
+__global__ void maxpool3x3s2_p32_kernel(const float* __restrict__ in, char* __restrict__ out, float* __restrict__ meta, float s,
+                                        long total, int H, int W, int C, int Ho, int Wo) {
+    const int C8 = C / 8;
+    float vmax = 0.f;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % C8);
+        long t = i / C8;
+        const int wo = (int)(t % Wo);
+        t /= Wo;
+        const int ho = (int)(t % Ho);
+        const long n = t / Ho;
+        float m[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) m[q] = -INFINITY;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int y = 2 * ho - 1 + dy;
+            if ((unsigned)y >= (unsigned)H) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int x = 2 * wo - 1 + dx;
+                if ((unsigned)x >= (unsigned)W) continue;
+                const float4* p = reinterpret_cast<const float4*>(in + ((n * H + y) * (long)W + x) * C + c8 * 8);
+                const float4 a = p[0], b = p[1];
+                m[0] = fmaxf(m[0], a.x); m[1] = fmaxf(m[1], a.y); m[2] = fmaxf(m[2], a.z); m[3] = fmaxf(m[3], a.w);
+                m[4] = fmaxf(m[4], b.x); m[5] = fmaxf(m[5], b.y); m[6] = fmaxf(m[6], b.z); m[7] = fmaxf(m[7], b.w);
+            }
+        }
+        f16x8 h, l;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            vmax = fmaxf(vmax, fabsf(m[q]));
+            const float y = m[q] * s;
+            h[q] = (_Float16)y;
+            l[q] = (_Float16)(y - (float)h[q]);
+        }
+        char* o = out + 128 + ((n * Ho + ho) * (long)Wo + wo) * (C * 4L) + (c8 >> 2) * 128 + (c8 & 3) * 16;
+        *reinterpret_cast<f16x8*>(o) = h;
+        *reinterpret_cast<f16x8*>(o + 64) = l;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+    if ((threadIdx.x & 63) == 0 && vmax > *reinterpret_cast<volatile const float*>(meta))
+        atomicMax(reinterpret_cast<unsigned int*>(meta), __float_as_uint(vmax));
+    if (blockIdx.x == 0 && threadIdx.x == 0) meta[1] = s;
+}
+
 template <typename T>
 __global__ void subsample2_kernel(const T* __restrict__ in, T* __restrict__ out, long total, int H, int W, int C, int Ho,
                                   int Wo) {
@@ -303,6 +351,17 @@ extern "C" int demia_maxpool3x3s2(const void* in, void* out, int N, int H, int W
         hipLaunchKernelGGL(maxpool3x3s2_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
                            (const float*)in, (float*)out, total, H, W, C, Ho, Wo);
     DEMIA_CHECK_LAUNCH("maxpool3x3s2_kernel");
+    return DEMIA_OK;
+}
+
+extern "C" int demia_maxpool3x3s2_p32(const float* in, void* out, float* out_meta, float s, int N, int H, int W, int C, void* stream) {
+    DEMIA_REQUIRE(in && out && out_meta && C % 32 == 0 && s > 0.f, "args");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const long total = (long)N * Ho * Wo * (C / 8);
+    if (total == 0) return DEMIA_OK;
+    hipLaunchKernelGGL(maxpool3x3s2_p32_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, in, (char*)out, out_meta, s,
+                       total, H, W, C, Ho, Wo);
+    DEMIA_CHECK_LAUNCH("maxpool3x3s2_p32_kernel");
     return DEMIA_OK;
 }
 

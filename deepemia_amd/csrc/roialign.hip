@@ -18,25 +18,59 @@ struct RoiP {
     const float* boxes;
     const int* count;
     void* out;
+    const float* meta[4];   // P32 only: {amax, s} of each level
+    float* out_meta;        // P32 only
 };
 
-template <typename T> struct Vec4;
-template <> struct Vec4<float> {
-    static __device__ __forceinline__ void load(const float* p, float v[4]) {
+// Element access policies: bytes per pixel, a lane's byte offset inside a pixel (four channels per lane), load / store
+// of those four channels.  P32 (conv_p32.hip): 4 high halves at p, 4 low halves 64 bytes on, value = (h + l) * inv_s; a
+// lane's channels 4 l .. 4 l + 3 sit in group l / 8 at (l % 8) * 8 bytes; the buffer starts with a 128-byte zero header.
+template <typename T> struct Acc;
+template <> struct Acc<float> {
+    static constexpr int HEADER = 0;
+    static __device__ __forceinline__ long pix_bytes(int C) { return (long)C * 4; }
+    static __device__ __forceinline__ int lane_off(int lane) { return lane * 16; }
+    static __device__ __forceinline__ void load(const char* p, float, float v[4]) {
         const float4 t = *reinterpret_cast<const float4*>(p);
         v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
     }
-    static __device__ __forceinline__ void store(float* p, const float v[4]) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+    static __device__ __forceinline__ void store(char* p, float, const float v[4]) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
 };
-template <> struct Vec4<bf16_t> {
-    static __device__ __forceinline__ void load(const bf16_t* p, float v[4]) {
+template <> struct Acc<bf16_t> {
+    static constexpr int HEADER = 0;
+    static __device__ __forceinline__ long pix_bytes(int C) { return (long)C * 2; }
+    static __device__ __forceinline__ int lane_off(int lane) { return lane * 8; }
+    static __device__ __forceinline__ void load(const char* p, float, float v[4]) {
         const bf16x4 t = *reinterpret_cast<const bf16x4*>(p);
         v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
     }
-    static __device__ __forceinline__ void store(bf16_t* p, const float v[4]) {
+    static __device__ __forceinline__ void store(char* p, float, const float v[4]) {
         bf16x4 o;
         o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
         *reinterpret_cast<bf16x4*>(p) = o;
+    }
+};
+struct P32Tag {};
+template <> struct Acc<P32Tag> {
+    static constexpr int HEADER = 128;
+    static __device__ __forceinline__ long pix_bytes(int C) { return (long)C * 4; }
+    static __device__ __forceinline__ int lane_off(int lane) { return (lane >> 3) * 128 + (lane & 7) * 8; }
+    static __device__ __forceinline__ void load(const char* p, float inv_s, float v[4]) {
+        const f16x4 h = *reinterpret_cast<const f16x4*>(p);
+        const f16x4 l = *reinterpret_cast<const f16x4*>(p + 64);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = ((float)h[c] + (float)l[c]) * inv_s;
+    }
+    static __device__ __forceinline__ void store(char* p, float s, const float v[4]) {
+        f16x4 h, l;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float y = v[c] * s;
+            h[c] = (_Float16)y;
+            l[c] = (_Float16)(y - (float)h[c]);
+        }
+        *reinterpret_cast<f16x4*>(p) = h;
+        *reinterpret_cast<f16x4*>(p + 64) = l;
     }
 };
 
@@ -45,17 +79,28 @@ template <> struct Vec4<bf16_t> {
 // bilinear tap is one 16-byte load per lane = one coalesced 1 KiB row read per wave (C = 256).
 template <typename T>
 __global__ __launch_bounds__(256) void roi_align_kernel(const RoiP p) {
+    typedef Acc<T> A;
+    constexpr bool P32 = A::HEADER != 0;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long roi = blockIdx.x;  // n*R + r
     const int PP = p.P * p.P;
     const int n = (int)(roi / p.R), r = (int)(roi % p.R);
-    const int cpl = p.C / 64;     // channels per lane group: lanes with lane * 4 >= C idle (C = 256 -> all busy)
     const bool lane_on = lane * 4 < p.C;
-    (void)cpl;
-    T* out0 = reinterpret_cast<T*>(p.out) + roi * PP * p.C + lane * 4;
+    const long pixb = A::pix_bytes(p.C);
+    float s_out = 1.f;
+    if (P32) {
+        // bilinear taps and bin averages are convex combinations: the output shares the coarsest scale of the four levels
+        // and their largest |x|
+        s_out = fminf(fminf(p.meta[0][1], p.meta[1][1]), fminf(p.meta[2][1], p.meta[3][1]));
+        if (roi == 0 && threadIdx.x == 0) {
+            p.out_meta[0] = fmaxf(fmaxf(p.meta[0][0], p.meta[1][0]), fmaxf(p.meta[2][0], p.meta[3][0]));
+            p.out_meta[1] = s_out;
+        }
+    }
+    char* out0 = reinterpret_cast<char*>(p.out) + A::HEADER + roi * PP * pixb + A::lane_off(lane);
     if (r >= p.count[n]) {
         const float z[4] = {0.f, 0.f, 0.f, 0.f};
-        if (lane_on) for (int bin = wave; bin < PP; bin += 4) Vec4<T>::store(out0 + (long)bin * p.C, z);
+        if (lane_on) for (int bin = wave; bin < PP; bin += 4) A::store(out0 + (long)bin * pixb, s_out, z);
         return;
     }
     const float4 b = reinterpret_cast<const float4*>(p.boxes)[roi];
@@ -66,7 +111,8 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiP p) {
     const int lv = (int)lvf - 2;
     const int H = p.H[lv], W = p.W[lv];
     const float scale = 1.0f / (float)(4 << lv);
-    const T* feat = reinterpret_cast<const T*>(p.feat[lv]) + (long)n * H * W * p.C + lane * 4;
+    const char* feat = reinterpret_cast<const char*>(p.feat[lv]) + A::HEADER + (long)n * H * W * pixb + A::lane_off(lane);
+    const float inv_s = P32 ? 1.0f / p.meta[lv][1] : 1.f;
 
     const float rsw = b.x * scale - 0.5f, rsh = b.y * scale - 0.5f;
     const float rew = b.z * scale - 0.5f, reh = b.w * scale - 0.5f;
@@ -96,10 +142,10 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiP p) {
                 const float lx = x - (float)xl, hx = 1.0f - lx;
                 const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
                 float v1[4], v2[4], v3[4], v4[4];
-                Vec4<T>::load(feat + ((long)yl * W + xl) * p.C, v1);
-                Vec4<T>::load(feat + ((long)yl * W + xh) * p.C, v2);
-                Vec4<T>::load(feat + ((long)yh * W + xl) * p.C, v3);
-                Vec4<T>::load(feat + ((long)yh * W + xh) * p.C, v4);
+                A::load(feat + ((long)yl * W + xl) * pixb, inv_s, v1);
+                A::load(feat + ((long)yl * W + xh) * pixb, inv_s, v2);
+                A::load(feat + ((long)yh * W + xl) * pixb, inv_s, v3);
+                A::load(feat + ((long)yh * W + xh) * pixb, inv_s, v4);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const float v = w1 * v1[c] + w2 * v2[c] + w3 * v3[c] + w4 * v4[c];
@@ -110,7 +156,7 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiP p) {
         float o[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) o[c] = acc[c] / cnt;
-        Vec4<T>::store(out0 + (long)bin * p.C, o);
+        A::store(out0 + (long)bin * pixb, s_out, o);
     }
 }
 
@@ -126,10 +172,17 @@ extern "C" int demia_roi_align(const demia_roialign_desc* d, void* stream) {
         p.feat[l] = d->feat[l]; p.H[l] = d->H[l]; p.W[l] = d->W[l];
     }
     p.N = d->N; p.R = d->R; p.C = d->C; p.P = d->P; p.boxes = d->boxes; p.count = d->count; p.out = d->out;
+    for (int l = 0; l < 4; ++l) p.meta[l] = d->meta[l];
+    p.out_meta = d->out_meta;
+    if (d->dtype == DEMIA_P32) {
+        DEMIA_REQUIRE(d->C % 32 == 0 && d->out_meta && d->meta[0] && d->meta[1] && d->meta[2] && d->meta[3], "P32 needs C % 32 == 0 and the meta pointers");
+    }
     const long total = (long)d->N * d->R;
     if (total == 0 || d->P == 0) return DEMIA_OK;
     const int grid = (int)total;
-    if (d->dtype == DEMIA_BF16)
+    if (d->dtype == DEMIA_P32)
+        hipLaunchKernelGGL(roi_align_kernel<P32Tag>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    else if (d->dtype == DEMIA_BF16)
         hipLaunchKernelGGL(roi_align_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     else
         hipLaunchKernelGGL(roi_align_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);

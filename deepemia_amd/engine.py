@@ -27,7 +27,7 @@ from typing import Dict, List, Optional, Tuple
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, p32
 from ._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, BF16, BF16X2, F16X2, F32, F32X3, RES_NONE, RES_SAME, RES_UP2
 
 RES_BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}
@@ -185,6 +185,8 @@ class ConvLayer:
     pad: int
     w3: Optional[torch.Tensor] = None   # f32x3 / bf16x2 mode: the three / two bf16 planes of w, tiled [CoutPad/64, ksteps, NP, 64, 32]
     scale3: Optional[torch.Tensor] = None   # f16x2: the output scale divided by the per-channel weight scale
+    wbound: float = 0.0                 # f16x2: max_co(|scale_co| * sum_k |w_co,k|) and max |bias| -- the a-priori bound of
+    bbound: float = 0.0                 #        |out| from which the epilogue derives the scale of its P32 output
 
 
 @dataclass
@@ -219,12 +221,19 @@ class MaskRCNNEngine:
         self.min_size_test, self.max_size_test = int(min_size_test), int(max_size_test)
         if self.min_size_test < 32 or self.max_size_test < self.min_size_test:
             raise ValueError(f"min_size_test / max_size_test = {min_size_test} / {max_size_test}")
-        if precision not in ("f32", "f32x3", "f16x2", "bf16x2", "bf16"):
-            raise ValueError("precision must be 'f32' (exact-f32 MFMA), 'f32x3' (f32 on the bf16 pipe, 3-way split), "
-                             "'f16x2' (f32 on the fp16 pipe, 2-way split with power-of-two operand scales), "
-                             "'bf16x2' (16-bit operands on the bf16 pipe, 2-way split) or 'bf16'")
-        self._amax_buf: Optional[torch.Tensor] = None     # f16x2: per-forward pool of |activation| bounds
+        if precision not in ("f32", "f32x3", "f16x2", "f16x2r", "bf16x2", "bf16"):
+            raise ValueError("precision must be 'f16x2' (default: f32-sized error on the fp16 pipe, activations kept as two "
+                             "pre-scaled fp16 planes in HBM, LDS-DMA fed kernel), 'f16x2r' (the same arithmetic with f32 "
+                             "activations split in the K loop: round 1's kernel), 'f32' (exact-f32 MFMA), 'f32x3' (f32 on the "
+                             "bf16 pipe, 3-way split), 'bf16x2' (16-bit operands on the bf16 pipe) or 'bf16'")
+        self.p32 = precision == "f16x2"                   # activations travel as P32 planes (deepemia_amd/p32.py)
+        self._amax_buf: Optional[torch.Tensor] = None     # f16x2r: per-forward pool of |activation| bounds
         self._amax_i = 0
+        self._meta_pool: Optional[torch.Tensor] = None    # f16x2: {max |x|, s} per activation tensor, zeroed once per forward
+        self._meta_i = 0
+        self._arena: Dict[tuple, list] = {}               # intermediate buffers per input shape, reused by later forwards
+        self._arena_key: Optional[tuple] = None
+        self._arena_i = 0
         self.dt = BF16 if precision == "bf16" else F32
         self.tdt = torch.bfloat16 if precision == "bf16" else torch.float32
         self._tables: Dict[Tuple[int, int], dict] = {}
@@ -244,7 +253,7 @@ class MaskRCNNEngine:
     def _conv(self, sd, prefix, stride=1, pad=0, norm=False, bias=False, weight=None, bias_t=None) -> ConvLayer:
         w = self._get(sd, prefix + ".weight") if weight is None else weight
         cout, cin, kh, kw = w.shape
-        cout_pad = (cout + 31) // 32 * 32
+        cout_pad = (cout + 63) // 64 * 64 if self.p32 else (cout + 31) // 32 * 32
         wp = torch.zeros((cout_pad, kh, kw, cin), dtype=torch.float32)
         wp[:cout] = w.permute(0, 2, 3, 1)
         scale = b = None
@@ -258,13 +267,25 @@ class MaskRCNNEngine:
         elif bias:
             b = self._get(sd, prefix + ".bias") if bias_t is None else bias_t
         dev = self.device
+        if self.p32:
+            # f16x2: every layer runs on demia_conv2d_p32 -- two fp16 planes of w * 2^e(co), tiled for the LDS-DMA stream;
+            # the per-channel power of two is divided out of the epilogue scale; wbound / bbound = the a-priori bound of |out|
+            if cin % 32:
+                raise ValueError(f"{prefix or 'layer'}: Cin = {cin} is not a multiple of 32")
+            planes, sw = split2_f16_scaled(wp.to(dev))
+            base = torch.ones(cout, dtype=torch.float32) if scale is None else scale
+            l1 = w.abs().flatten(1).sum(1)
+            return ConvLayer(None, None if scale is None else scale.to(dev).contiguous(), None if b is None else b.to(dev).contiguous(),
+                             cin, cout, cout_pad, kh, kw, stride, pad, tile_weight_planes_p32(planes),
+                             (base.to(dev) / sw[:cout]).contiguous(), float((base.abs() * l1).max()),
+                             0.0 if b is None else float(b.abs().max()))
         w3 = None
         if self.precision in ("f32x3", "bf16x2") and cout_pad % 64 == 0 and cin % 32 == 0:
             w3 = split3_bf16(wp.to(dev))                       # split on the device: same round-to-nearest casts
             w3 = tile_weight_planes(w3 if self.precision == "f32x3" else w3[:2])
         scale3 = None
         f16_bk = int(self.lib.demia_conv_f16x2_kstep())           # the tiling this build of the library reads
-        if self.precision == "f16x2" and cout_pad % 64 == 0 and cin % f16_bk == 0:
+        if self.precision == "f16x2r" and cout_pad % 64 == 0 and cin % f16_bk == 0:
             planes, sw = split2_f16_scaled(wp.to(dev))
             w3 = tile_weight_planes(planes, f16_bk)
             base = torch.ones(cout, dtype=torch.float32, device=dev) if scale is None else scale.to(dev)
@@ -286,6 +307,9 @@ class MaskRCNNEngine:
         self.stem_w = ws.to(self.device).contiguous()
         self.stem_scale = sc.to(self.device).contiguous()
         self.stem_bias = (beta - rm * sc).to(self.device).contiguous()
+        # |pixel - mean| <= 255 - min(mean): the a-priori bound of the stem's (pooled) output, from which the P32 scale of the
+        # first activation tensor is derived on the host
+        self.stem_bound = float(((255.0 - min(PIXEL_MEAN)) * sc.abs() * w.abs().flatten(1).sum(1) + (beta - rm * sc).abs()).max())
         self.blocks = []
         for stage, nblk in zip((2, 3, 4, 5), RES_BLOCKS[self.depth]):
             stage_blocks = []
@@ -333,8 +357,110 @@ class MaskRCNNEngine:
     def _stream(self) -> int:
         return int(torch.cuda.current_stream(self.device).cuda_stream)
 
-    def conv(self, x: torch.Tensor, L: ConvLayer, act=ACT_NONE, residual=None, res_mode=RES_NONE,
-             out_dtype=None, out: Optional[torch.Tensor] = None, out_ld: int = 0, tile_hint: int = 0) -> torch.Tensor:
+    # ---- f16x2 bookkeeping: intermediate buffers and {max |x|, s} slots -------------------------------------------
+    def _begin_forward(self, key: tuple) -> None:
+        """Intermediates of one forward come from an arena keyed by the input shape: the first forward of a shape
+        allocates them (P32 headers zeroed once), later ones reuse them in call order -- no allocation, no memset but the
+        one that clears the meta pool."""
+        self._arena_key, self._arena_i = key, 0
+        if self._meta_pool is None:
+            self._meta_pool = torch.zeros((1024, 2), dtype=torch.float32, device=self.device)
+        else:
+            self._meta_pool.zero_()
+        self._meta_i = 0
+
+    def _scratch(self, numel: int, dtype, zero: bool = False, zero_head: int = 0) -> torch.Tensor:
+        """Flat intermediate buffer number ``_arena_i`` of the current forward.  ``zero`` / ``zero_head``: zeroed (whole /
+        first elements) when it is first allocated -- for buffers whose zero regions no kernel ever writes."""
+        if self._arena_key is None:                    # a stage called on its own (tests): plain allocation
+            t = torch.zeros(numel, dtype=dtype, device=self.device) if zero else torch.empty(numel, dtype=dtype, device=self.device)
+            if zero_head and not zero:
+                t[:zero_head].zero_()
+            return t
+        slots = self._arena.setdefault(self._arena_key, [])
+        i = self._arena_i
+        self._arena_i += 1
+        if i < len(slots) and slots[i].numel() == numel and slots[i].dtype == dtype:
+            return slots[i]
+        t = torch.zeros(numel, dtype=dtype, device=self.device) if zero else torch.empty(numel, dtype=dtype, device=self.device)
+        if zero_head and not zero:
+            t[:zero_head].zero_()
+        if i < len(slots):
+            slots[i] = t
+        else:
+            slots.append(t)
+        return t
+
+    def _meta_slot(self) -> torch.Tensor:
+        if self._meta_pool is None or self._meta_i >= self._meta_pool.shape[0]:
+            if self._arena_key is not None and self._meta_pool is not None:
+                raise RuntimeError("activation meta pool exhausted inside one forward")
+            self._meta_pool = torch.zeros((1024, 2), dtype=torch.float32, device=self.device)
+            self._meta_i = 0
+        m = self._meta_pool[self._meta_i]
+        self._meta_i += 1
+        return m
+
+    def new_p32(self, shape) -> p32.P32:
+        n = 1
+        for d in shape:
+            n *= int(d)
+        buf = self._scratch(p32.HEADER_HALFS + 2 * n, torch.float16, zero_head=p32.HEADER_HALFS)
+        return p32.P32(buf, self._meta_slot(), tuple(int(d) for d in shape))
+
+    def dense(self, x) -> torch.Tensor:
+        """An activation as a plain f32 tensor (tests / debug dumps; the product path never converts)."""
+        return p32.to_f32(x) if isinstance(x, p32.P32) else x.float()
+
+    def conv_p32(self, x: p32.P32, L: ConvLayer, act=ACT_NONE, residual: Optional[p32.P32] = None, res_mode=RES_NONE,
+                 out_f32: bool = False, out_ld: int = 0, tile_hint: int = 0):
+        """``demia_conv2d_p32``: P32 in, P32 out (or plain f32 [.., out_ld] for the prediction heads)."""
+        n, h, w, cin = x.shape
+        assert cin == L.cin, (cin, L.cin)
+        ho = (h + 2 * L.pad - L.kh) // L.stride + 1
+        wo = (w + 2 * L.pad - L.kw) // L.stride + 1
+        if out_f32:
+            ld = out_ld if out_ld > 0 else L.cout
+            out = self._scratch(n * ho * wo * ld, torch.float32).view(n, ho, wo, ld)
+            optr, ometa = _lib.ptr(out), 0
+        else:
+            out = self.new_p32((n, ho, wo, L.cout))
+            optr, ometa = _lib.ptr(out.buf), _lib.ptr(out.meta)
+        # the kernel addresses its input with 32-bit byte offsets: a pointwise layer over more than 4 GiB of planes (the mask
+        # head's last two layers at 64 tiles per forward) goes in pixel chunks -- rows are independent, and without
+        # padding taps the only rows that gather the 128 bytes in front of a chunk are the tail tile's rows >= M, whose
+        # results are never stored
+        pix_bytes = cin * 4
+        limit = (1 << 32) - (1 << 20)
+        chunks = [(0, n)]
+        if 128 + n * h * w * pix_bytes >= limit:
+            if not (h == 1 and w == 1 and L.kh == 1 and L.kw == 1 and L.pad == 0 and L.stride == 1 and res_mode != RES_UP2):
+                raise ValueError(f"{n}x{h}x{w}x{cin} planes exceed 4 GiB: lower the batch size")
+            step = (limit - 128) // pix_bytes // 256 * 256
+            chunks = [(i, min(step, n - i)) for i in range(0, n, step)]
+        ev = self.conv_events
+        if ev is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(self.device))
+        for c0, cn in chunks:
+            d = _lib.ConvP32Desc(_lib.ptr(x.buf) + c0 * pix_bytes, _lib.ptr(x.meta), _lib.ptr(L.w3), _lib.ptr(L.scale3), _lib.ptr(L.bias),
+                                 0 if residual is None else _lib.ptr(residual.buf) + c0 * L.cout * 4,
+                                 0 if residual is None else _lib.ptr(residual.meta),
+                                 optr + c0 * (ld if out_f32 else L.cout) * 4, ometa, L.wbound, L.bbound, cn, h, w, cin, ho, wo, L.cout,
+                                 L.cout_pad, L.kh, L.kw, L.stride, L.pad, act, res_mode, 1 if out_f32 else 0, out_ld, tile_hint)
+            _lib.check(self.lib.demia_conv2d_p32(C.byref(d), self._stream()), "demia_conv2d_p32")
+        if ev is not None:
+            e1.record(torch.cuda.current_stream(self.device))
+            # every operand once (planes are 4 bytes per element, like f32): the algorithmic traffic
+            nbytes = (n * h * w * cin * 4 + L.cout_pad * L.kh * L.kw * cin * 4 + n * ho * wo * L.cout * 4 +
+                      (0 if residual is None else residual.pixels * residual.channels * 4))
+            ev.append((e0, e1, 2.0 * n * ho * wo * L.cout * L.kh * L.kw * cin, "f16x2", nbytes))
+        return out
+
+    def conv(self, x, L: ConvLayer, act=ACT_NONE, residual=None, res_mode=RES_NONE,
+             out_dtype=None, out: Optional[torch.Tensor] = None, out_ld: int = 0, tile_hint: int = 0):
+        if self.p32:
+            return self.conv_p32(x, L, act, residual, res_mode, out_f32=out_dtype is not None, out_ld=out_ld, tile_hint=tile_hint)
         n, h, w, cin = x.shape
         assert cin == L.cin, (cin, L.cin)
         ho = (h + 2 * L.pad - L.kh) // L.stride + 1
@@ -345,12 +471,12 @@ class MaskRCNNEngine:
             out = torch.empty((n, ho, wo, ld), dtype=odt, device=self.device)
         use3 = L.w3 is not None and odt == torch.float32
         f16 = use3 and L.w3.dtype == torch.float16
-        kind = ("f16x2" if f16 else ("f32x3" if L.w3.shape[2] == 3 else "bf16x2")) if use3 else ("bf16" if self.dt == BF16 else "f32")
+        kind = ("f16x2r" if f16 else ("f32x3" if L.w3.shape[2] == 3 else "bf16x2")) if use3 else ("bf16" if self.dt == BF16 else "f32")
         amax_in = self.amax_of(x) if f16 else None
-        amax_out = self._amax_slot() if self.precision == "f16x2" else None
+        amax_out = self._amax_slot() if self.precision == "f16x2r" else None
         d = _lib.ConvDesc(_lib.ptr(x), _lib.ptr(L.w3 if use3 else L.w), _lib.ptr(L.scale3 if f16 else L.scale), _lib.ptr(L.bias),
                           _lib.ptr(residual), _lib.ptr(out), n, h, w, cin, ho, wo, L.cout, L.cout_pad, L.kh, L.kw, L.stride, L.pad,
-                          {"f16x2": F16X2, "f32x3": F32X3, "bf16x2": BF16X2}.get(kind, self.dt), BF16 if odt == torch.bfloat16 else F32,
+                          {"f16x2r": F16X2, "f32x3": F32X3, "bf16x2": BF16X2}.get(kind, self.dt), BF16 if odt == torch.bfloat16 else F32,
                           act, res_mode, ld, tile_hint, _lib.ptr(amax_in), _lib.ptr(amax_out))
         if amax_out is not None:
             out._amax = amax_out
@@ -387,8 +513,10 @@ class MaskRCNNEngine:
         return am
 
     @staticmethod
-    def view_as(x: torch.Tensor, *shape) -> torch.Tensor:
+    def view_as(x, *shape):
         """``x.view(shape)`` that keeps the |x| bound attached."""
+        if isinstance(x, p32.P32):
+            return x.view(*shape)
         y = x.view(*shape)
         am = getattr(x, "_amax", None)
         if am is not None:
@@ -423,17 +551,22 @@ class MaskRCNNEngine:
     def preprocess(self, images: torch.Tensor):
         """[B, H, W, 3] u8 BGR (device) -> zero-bordered f32 stem input, (newh, neww, PH, PW)."""
         b, h, w, _ = images.shape
+        if self.p32:
+            self._begin_forward((b, h, w))          # the first stage of every forward
         t = self._resize_tables(h, w)
         newh, neww = t["newh"], t["neww"]
         ph, pw = (newh + 31) // 32 * 32, (neww + 31) // 32 * 32
         st = self._stream()
         if t["need_h"]:
-            tmp = torch.empty((b, h, neww, 3), dtype=torch.uint8, device=self.device)
+            tmp = (self._scratch(b * h * neww * 3, torch.uint8).view(b, h, neww, 3) if self.p32 else
+                   torch.empty((b, h, neww, 3), dtype=torch.uint8, device=self.device))
             _lib.check(self.lib.demia_resize_h_u8(_lib.ptr(images), _lib.ptr(tmp), b, h, w, neww, _lib.ptr(t["xm"]),
                                                   _lib.ptr(t["xs"]), _lib.ptr(t["xk"]), t["ksx"], st), "demia_resize_h_u8")
         else:
             tmp = images
-        dst = torch.zeros((b, ph + 6, pw + 8, 4), dtype=torch.float32, device=self.device)
+        # border, padding and the fourth channel are zero and never written: zeroed once when the buffer is first allocated
+        dst = (self._scratch(b * (ph + 6) * (pw + 8) * 4, torch.float32, zero=True).view(b, ph + 6, pw + 8, 4) if self.p32 else
+               torch.zeros((b, ph + 6, pw + 8, 4), dtype=torch.float32, device=self.device))
         mean = (C.c_float * 3)(*PIXEL_MEAN)
         _lib.check(self.lib.demia_resize_v_norm(_lib.ptr(tmp), _lib.ptr(dst), b, h, neww, newh, ph, pw, _lib.ptr(t["ym"]),
                                                 _lib.ptr(t["ys"]), _lib.ptr(t["yk"]), t["ksy"], mean, F32, st),
@@ -443,12 +576,20 @@ class MaskRCNNEngine:
     def backbone(self, xin: torch.Tensor, ph: int, pw: int) -> Dict[str, torch.Tensor]:
         b = xin.shape[0]
         st = self._stream()
-        mid = torch.empty((b, ph // 2, pw // 2, 64), dtype=self.tdt, device=self.device)
-        _lib.check(self.lib.demia_stem_conv(_lib.ptr(xin), _lib.ptr(self.stem_w), _lib.ptr(self.stem_scale),
-                                            _lib.ptr(self.stem_bias), _lib.ptr(mid), b, ph, pw, self.dt, st), "demia_stem_conv")
-        x = torch.empty((b, ph // 4, pw // 4, 64), dtype=self.tdt, device=self.device)
-        _lib.check(self.lib.demia_maxpool3x3s2(_lib.ptr(mid), _lib.ptr(x), b, ph // 2, pw // 2, 64, self.dt, st),
-                   "demia_maxpool3x3s2")
+        if self.p32:
+            mid = self._scratch(b * (ph // 2) * (pw // 2) * 64, torch.float32)
+            _lib.check(self.lib.demia_stem_conv(_lib.ptr(xin), _lib.ptr(self.stem_w), _lib.ptr(self.stem_scale),
+                                                _lib.ptr(self.stem_bias), _lib.ptr(mid), b, ph, pw, F32, st), "demia_stem_conv")
+            x = self.new_p32((b, ph // 4, pw // 4, 64))
+            _lib.check(self.lib.demia_maxpool3x3s2_p32(_lib.ptr(mid), _lib.ptr(x.buf), _lib.ptr(x.meta), p32.plane_scale(self.stem_bound),
+                                                       b, ph // 2, pw // 2, 64, st), "demia_maxpool3x3s2_p32")
+        else:
+            mid = torch.empty((b, ph // 2, pw // 2, 64), dtype=self.tdt, device=self.device)
+            _lib.check(self.lib.demia_stem_conv(_lib.ptr(xin), _lib.ptr(self.stem_w), _lib.ptr(self.stem_scale),
+                                                _lib.ptr(self.stem_bias), _lib.ptr(mid), b, ph, pw, self.dt, st), "demia_stem_conv")
+            x = torch.empty((b, ph // 4, pw // 4, 64), dtype=self.tdt, device=self.device)
+            _lib.check(self.lib.demia_maxpool3x3s2(_lib.ptr(mid), _lib.ptr(x), b, ph // 2, pw // 2, 64, self.dt, st),
+                       "demia_maxpool3x3s2")
         feats = {"stem": x}
         for si, stage_blocks in enumerate(self.blocks):
             for blk in stage_blocks:
@@ -467,6 +608,13 @@ class MaskRCNNEngine:
             feats[f"p{lvl}"] = self.conv(lat, self.fpn_output[lvl])
         p5 = feats["p5"]
         h5, w5 = p5.shape[1], p5.shape[2]
+        if self.p32:
+            # a P32 pixel of C channels is C 4-byte words: the plain strided copy moves whole pixels; same scale, |x| no larger
+            p6 = self.new_p32((b, (h5 - 1) // 2 + 1, (w5 - 1) // 2 + 1, 256))
+            p6 = p32.P32(p6.buf, p5.meta, p6.shape)
+            _lib.check(self.lib.demia_subsample2(_lib.ptr(p5.buf) + 128, _lib.ptr(p6.buf) + 128, b, h5, w5, 256, F32, st), "demia_subsample2")
+            feats["p6"] = p6
+            return feats
         p6 = torch.empty((b, (h5 - 1) // 2 + 1, (w5 - 1) // 2 + 1, 256), dtype=self.tdt, device=self.device)
         _lib.check(self.lib.demia_subsample2(_lib.ptr(p5), _lib.ptr(p6), b, h5, w5, 256, self.dt, st), "demia_subsample2")
         feats["p6"] = p6
@@ -496,8 +644,18 @@ class MaskRCNNEngine:
 
     def roi_align(self, feats, boxes: torch.Tensor, count: torch.Tensor, P: int) -> torch.Tensor:
         b, r, _ = boxes.shape
-        out = torch.empty((b, r, P, P, 256), dtype=self.tdt, device=self.device)
         d = _lib.RoiAlignDesc()
+        if isinstance(feats["p2"], p32.P32):
+            out = self.new_p32((b, r, P, P, 256))
+            for i, name in enumerate(("p2", "p3", "p4", "p5")):
+                f = feats[name]
+                d.feat[i], d.meta[i] = _lib.ptr(f.buf), _lib.ptr(f.meta)
+                d.H[i], d.W[i] = f.shape[1], f.shape[2]
+            d.N, d.R, d.C, d.P, d.dtype = b, r, 256, P, _lib.P32
+            d.boxes, d.count, d.out, d.out_meta = _lib.ptr(boxes), _lib.ptr(count), _lib.ptr(out.buf), _lib.ptr(out.meta)
+            _lib.check(self.lib.demia_roi_align(C.byref(d), self._stream()), "demia_roi_align")
+            return out
+        out = torch.empty((b, r, P, P, 256), dtype=self.tdt, device=self.device)
         for i, name in enumerate(("p2", "p3", "p4", "p5")):
             f = feats[name]
             d.feat[i] = _lib.ptr(f)
@@ -505,7 +663,7 @@ class MaskRCNNEngine:
         d.N, d.R, d.C, d.P, d.dtype = b, r, 256, P, self.dt
         d.boxes, d.count, d.out = _lib.ptr(boxes), _lib.ptr(count), _lib.ptr(out)
         _lib.check(self.lib.demia_roi_align(C.byref(d), self._stream()), "demia_roi_align")
-        if self.precision == "f16x2":                  # bilinear taps and bin averages are convex combinations
+        if self.precision == "f16x2r":                 # bilinear taps and bin averages are convex combinations
             out._amax = torch.cat([self.amax_of(feats[n]) for n in ("p2", "p3", "p4", "p5")]).amax().reshape(1)
         return out
 
@@ -536,7 +694,7 @@ class MaskRCNNEngine:
         for L in self.mask_fcn:
             x = self.conv(x, L, act=ACT_RELU)
         x = self.conv(self.view_as(x, b * dd * 196, 1, 1, 256), self.deconv, act=ACT_RELU)        # [.., 1024] = (dy,dx,co)
-        x = self.conv(x.view(b * dd * 196 * 4, 1, 1, 256), self.mask_pred, act=ACT_SIGMOID,
+        x = self.conv(self.view_as(x, b * dd * 196 * 4, 1, 1, 256), self.mask_pred, act=ACT_SIGMOID,
                       out_dtype=torch.float32, out_ld=(self.K + 3) // 4 * 4)
         return x  # [(i*196 + cell)*4 + sub, 1, 1, ld] f32 probabilities
 
@@ -559,7 +717,7 @@ class MaskRCNNEngine:
         assert images.dtype == torch.uint8 and images.dim() == 4 and images.shape[3] == 3
         images = images.contiguous()
         b, h, w, _ = images.shape
-        self._amax_buf = None            # f16x2: a fresh (zeroed) pool of |activation| bounds per forward
+        self._amax_buf = None            # f16x2r: a fresh (zeroed) pool of |activation| bounds per forward
         xin, newh, neww, ph, pw = self.preprocess(images)
         feats = self.backbone(xin, ph, pw)
         props, pscores, pcount = self.rpn(feats, newh, neww)

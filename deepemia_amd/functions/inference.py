@@ -33,6 +33,7 @@ from ..maskset import MaskOps
 from ..utils.config import get_config
 from ..utils.logger_utils import log_memory_usage, system_logger
 from ..utils.mask_algebra import DeviceMaskAlgebra
+from ..utils.measurements import contrast_percentiles
 from ..utils.mask_utils import (mask_crops, postprocess_masks_device, postprocess_masks_universal_device,
                                 process_masks_device, rle_encoding_packed)
 from ..utils.spatial_constraints import apply_spatial_constraints_indices, load_spatial_constraints
@@ -85,10 +86,35 @@ def imread_bgr(path: str) -> Optional[np.ndarray]:
     return np.ascontiguousarray(rgb[:, :, ::-1])
 
 
+_scale_bar_warned = False
+
+
 def detect_scale_bar(image, roi_config=None, dataset_name=None, draw_debug=False) -> Tuple[str, float]:
     """The OCR scale-bar reader (``src/utils/scalebar_ocr.py``, EasyOCR) is out of scope
     (SURVEY.md section 2 row 8); this is its documented fallback contract: ``("0", 1.0)``
-    (``scalebar_ocr.py:362-364``, ``inference.py:768-773``)."""
+    (``scalebar_ocr.py:362-364``, ``inference.py:768-773``) -- unless the operator supplies the calibration:
+    ``scale_bar.um_per_pixel`` (+ optional ``scale_bar.label``) in the dataset / global config or
+    ``DEEPEMIA_UM_PER_PIXEL``.  Logged once per run either way, because every length / area column is in these units."""
+    global _scale_bar_warned
+    cfg = {}
+    try:
+        cfg = (get_config(dataset_name=dataset_name) if dataset_name else get_config()).get("scale_bar", {}) or {}
+    except Exception:
+        cfg = {}
+    um = os.environ.get("DEEPEMIA_UM_PER_PIXEL", cfg.get("um_per_pixel"))
+    if um is not None:
+        um = float(um)
+        if not (um > 0.0 and math.isfinite(um)):
+            raise ValueError(f"um_per_pixel must be a positive number, got {um!r}")
+        psum = str(cfg.get("label", "0"))
+        if not _scale_bar_warned:
+            system_logger.info(f"Scale bar: using the configured calibration {um} um/pixel (label {psum!r}); no OCR")
+            _scale_bar_warned = True
+        return psum, um
+    if not _scale_bar_warned:
+        system_logger.warning("Scale bar not read (EasyOCR is out of scope): um_pix = 1.0, every length / area column of "
+                              "measurements_results.csv is in PIXELS; set scale_bar.um_per_pixel or DEEPEMIA_UM_PER_PIXEL")
+        _scale_bar_warned = True
     return "0", 1.0
 
 
@@ -1011,6 +1037,8 @@ def write_measurements(ops: MaskOps, dedup_results: Dict[str, dict], test_img_pa
     """Measurement phase (``inference.py:983-1291``): one CSV row per external contour that passes
     the area gate, 20 columns, ``None`` -> empty field, floats through ``csv.writer``."""
     csv_filename = os.path.join(output_dir, "measurements_results.csv")
+    # inference.py:58: read from the GLOBAL config at import time
+    measure_contrast = bool(get_config().get("measure_contrast_distribution", False))
     with open(csv_filename, "w", newline="") as csvfile:
         w = csv.writer(csvfile)
         w.writerow(CSV_HEADER)
@@ -1026,14 +1054,20 @@ def write_measurements(ops: MaskOps, dedup_results: Dict[str, dict], test_img_pa
             ops.set_frame_width(wd)
             min_area = max(5, h * wd * 0.000005 * 0.05)
             recs = ops.contours(packed, max_contours=256, um_pix=um_pix)
+            im = imread_bgr(os.path.join(test_img_path, test_img)) if (visualize or measure_contrast) else None
+            contrast = [(None, None, None)] * int(packed.shape[0])
+            if measure_contrast and im is not None:
+                # measurements.py:195-215: gray levels under the whole instance mask; the histogram is a device reduction
+                hist = ops.gray_histogram(packed, torch.from_numpy(im).to(ops.device))
+                contrast = [contrast_percentiles(hh) for hh in hist]
             if visualize:
-                im = imread_bgr(os.path.join(test_img_path, test_img))
                 if im is not None:
                     write_predictions_png(os.path.join(output_dir, f"{test_img}_predictions.png"), im, mask_crops(ops, packed),
                                           classes, recs, metadata.thing_classes)
             rows = []
             for instance_id, (cls, contours) in enumerate(zip(classes, recs), 1):
                 cls = int(cls)
+                d10, d50, d90 = contrast[instance_id - 1]
                 cname = metadata.thing_classes[cls] if cls < len(metadata.thing_classes) else f"class_{cls}"
                 for c in contours:
                     if c["area"] < min_area:
@@ -1041,7 +1075,7 @@ def write_measurements(ops: MaskOps, dedup_results: Dict[str, dict], test_img_pa
                     v = c["values"]
                     rows.append([f"{test_img}_{instance_id}", cls, cname, float(v[0]), float(v[1]), float(v[2]), float(v[3]),
                                  float(v[4]), float(v[5]), float(v[6]), float(v[7]), float(v[8]), float(v[9]), float(v[10]),
-                                 float(v[11]), None, None, None, psum, test_img])
+                                 float(v[11]), d10, d50, d90, psum, test_img])
             for r in rows:
                 w.writerow(r)
             csvfile.flush()

@@ -95,6 +95,23 @@ class MaskOps:
                    "demia_mask_pair_intersections")
         return out.cpu().numpy().astype(np.int64)
 
+    def gray_histogram(self, packed: torch.Tensor, image: torch.Tensor, bbox: Optional[torch.Tensor] = None) -> np.ndarray:
+        """[M, 256] gray-level counts of ``image`` ([H, W, 3] BGR or [H, W] gray, uint8, on the device) under each mask:
+        what ``np.histogram(cv2.cvtColor(image, BGR2GRAY)[mask > 0], bins=256, range=(0, 255))`` counts
+        (measurements.py:197-205)."""
+        M, H, wpr = packed.shape
+        if M == 0:
+            return np.zeros((0, 256), dtype=np.int64)
+        W = self._w(packed)
+        assert image.dtype == torch.uint8 and image.is_contiguous() and tuple(image.shape[:2]) == (H, W), (image.shape, H, W)
+        ch = 1 if image.dim() == 2 else int(image.shape[2])
+        if bbox is None:
+            _, bbox = self.area_bbox(packed)
+        hist = torch.empty((M, 256), dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.demia_mask_gray_histogram(_lib.ptr(packed), _lib.ptr(bbox), _lib.ptr(image), ch, M, H, W,
+                                                      _lib.ptr(hist), self._stream()), "demia_mask_gray_histogram")
+        return hist.cpu().numpy().astype(np.int64)
+
     # -- morphology -----------------------------------------------------------------------------
     def program_(self, packed: torch.Tensor, stages: Sequence[str], bbox: Optional[torch.Tensor] = None,
                  active: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:

@@ -37,6 +37,8 @@ extern "C" {
 #define DEMIA_F32X3 2   /* conv only: f32 activations, weights pre-split into 3 bf16 planes, tiled (see demia_conv2d_nhwc) */
 #define DEMIA_BF16X2 3  /* conv only: f32 activations, weights as 2 bf16 planes (same tiling): 16-bit operands */
 #define DEMIA_F16X2 4   /* conv only: f32 activations, weights as 2 fp16 planes (same tiling), power-of-two operand scales */
+#define DEMIA_P32 5     /* activations as two pre-scaled fp16 planes, [pixels][C / 32][2][32] behind a 128-byte zero header
+                           (demia_conv2d_p32 below); taken by demia_roi_align and demia_maxpool3x3s2_p32 */
 
 #define DEMIA_ACT_NONE 0
 #define DEMIA_ACT_RELU 1
@@ -160,6 +162,9 @@ int demia_resize_linear_u8(const uint8_t* src, uint8_t* dst, int N, int H, int W
 int demia_stem_conv(const void* in, const void* w, const float* scale, const float* bias, void* mid,
                     int N, int PH, int PW, int dtype, void* stream);
 int demia_maxpool3x3s2(const void* in, void* out, int N, int H, int W, int C, int dtype, void* stream);
+/* the same pool from an f32 input into a P32 buffer scaled with the power of two `s` (the caller derives it from the
+ * stem's a-priori bound); out_meta receives {max |out| (atomic max; zero it first), s}.  C % 32 == 0. */
+int demia_maxpool3x3s2_p32(const float* in, void* out, float* out_meta, float s, int N, int H, int W, int C, void* stream);
 /* LastLevelMaxPool (kernel 1, stride 2): p6 = p5[:, ::2, ::2, :] */
 int demia_subsample2(const void* in, void* out, int N, int H, int W, int C, int dtype, void* stream);
 
@@ -194,7 +199,9 @@ int demia_rpn_proposals(const demia_rpn_desc* d, void* stream);
  * Replaces ROIPooler.forward -> torchvision.ops.roi_align(aligned=True) incl. the
  * FPN level assignment floor(4 + log2(sqrt(area)/224 + 1e-8)) clamped to [2, 5].
  *   feat[l] [N, H_l, W_l, C] `dtype`; boxes [N, R, 4] f32 (network-input coords);
- *   count [N] i32 (rows >= count[n] are written as zeros); out [N, R, P, P, C] `dtype` */
+ *   count [N] i32 (rows >= count[n] are written as zeros); out [N, R, P, P, C] `dtype`
+ * dtype DEMIA_P32: feat[l] / out are P32 buffers (pointers to their 128-byte headers); taps and averages are convex
+ * combinations, so the output takes the coarsest of the levels' scales and the largest of their max |x|. */
 typedef struct demia_roialign_desc {
     const void* feat[4];
     int32_t H[4], W[4];
@@ -202,6 +209,8 @@ typedef struct demia_roialign_desc {
     const float* boxes;
     const int32_t* count;
     void* out;
+    const float* meta[4];    /* dtype DEMIA_P32: {max |x|, s} of each level (device floats); else ignored */
+    float* out_meta;         /* dtype DEMIA_P32: receives {max over the levels' max |x|, min over the levels' s} */
 } demia_roialign_desc;
 int demia_roi_align(const demia_roialign_desc* d, void* stream);
 

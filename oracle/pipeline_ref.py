@@ -58,6 +58,7 @@ class RefPipeline:
         self.weights = list(global_inf_settings.get("ensemble_settings", {}).get("weights", {"R50": 0.6, "R101": 0.4}).values())
         self.class_settings = inf_settings.get("class_specific_settings", {})
         self.parallel = parallel_mask_processing
+        self.global_config = {"inference_settings": global_inf_settings}     # what get_confidence_threshold reads (inference.py:302, 352)
         self._cache = {}
         self.forward_calls = 0
 
@@ -147,8 +148,10 @@ class RefPipeline:
         for tc in range(self.K):
             is_small = tc in small_classes
             ccfg = self.class_settings.get(f"class_{tc}", {})
-            assert confidence_mode == "manual", "oracle pipeline covers manual confidence mode"
-            conf = ccfg.get("confidence_threshold", 0.3 if is_small else 0.5)
+            if confidence_mode == "manual":
+                conf = ccfg.get("confidence_threshold", 0.3 if is_small else 0.5)
+            else:      # inference.py:809: the adaptive path reads the GLOBAL config, not the dataset override
+                conf = P.get_confidence_threshold(image, tc, small_classes, self.global_config)
             iou_t = ccfg.get("iou_threshold", 0.5 if is_small else 0.7)
             use_ens = ensemble_enabled and (not ensemble_small_only or is_small)
             mids = list(range(len(self.models))) if (use_ens and len(self.models) > 1) else [0]
@@ -162,14 +165,15 @@ class RefPipeline:
         return masks, scores, classes
 
 
-def measurement_rows(name: str, masks, classes, thing_classes, um_pix=1.0, psum="0"):
+def measurement_rows(name: str, masks, classes, thing_classes, um_pix=1.0, psum="0", image=None,
+                     measure_contrast_distribution=False):
     """inference.py:1148-1230 -> list of 20-column rows (+ a trailing flag: ellipse fit numerically unstable)."""
     rows = []
     for iid, (mask, cls) in enumerate(zip(masks, classes), 1):
         cls = int(cls)
-        for r in P.measure_mask(np.asarray(mask) > 0, um_pix):
+        for r in P.measure_mask(np.asarray(mask) > 0, um_pix, image, measure_contrast_distribution):
             rows.append([f"{name}_{iid}", cls, thing_classes[cls], r["major_axis_length"], r["minor_axis_length"], r["eccentricity"],
                          r["Length"], r["Width"], r["CircularED"], r["Aspect_Ratio"], r["Circularity"], r["Chords"],
-                         r["Feret_diam"], r["Roundness"], r["Sphericity"], None, None, None, psum, name,
-                         r["_ellipse_unstable"]])
+                         r["Feret_diam"], r["Roundness"], r["Sphericity"], r["contrast_d10"], r["contrast_d50"], r["contrast_d90"],
+                         psum, name, r["_ellipse_unstable"]])
     return rows

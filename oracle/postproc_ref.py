@@ -644,15 +644,84 @@ def calculate_measurements(c: np.ndarray, um_pix: float = 1.0, pixels_per_metric
             "contrast_d10": None, "contrast_d50": None, "contrast_d90": None, "_ellipse_unstable": unstable}
 
 
-def measure_mask(mask: np.ndarray, um_pix: float = 1.0) -> List[Dict[str, float]]:
-    """inference.py:1148-1230 for one instance: contours, area gate, measurements per contour."""
+def bgr_to_gray(image: np.ndarray) -> np.ndarray:
+    """cv2.cvtColor(image, COLOR_BGR2GRAY) on uint8 [3P, OpenCV 4.11 color_yuv / RGB2Gray<uchar>]: fixed point with
+    B 1868, G 9617, R 4899 (sum 2^14) and round-half-up descale by 14 bits; 2-D input is returned as is
+    (measurements.py:198-203, inference.py:267-271)."""
+    if image.ndim == 2:
+        return image
+    b, g, r = (image[:, :, i].astype(np.int64) for i in range(3))
+    return ((b * 1868 + g * 9617 + r * 4899 + (1 << 13)) >> 14).astype(np.uint8)
+
+
+def contrast_distribution(gray: np.ndarray, mask: np.ndarray):
+    """measurements.py:195-215: d10 / d50 / d90 of the gray levels under the WHOLE instance mask (``single_im_mask``, not
+    the contour): density histogram over 256 bins on [0, 255], cumulative sum normalised by its last value, np.interp
+    over the left bin edges.  Returns (d10, d50, d90) or (None, None, None) for an empty mask."""
+    particle_pixels = gray[mask > 0]
+    if len(particle_pixels) == 0:
+        return None, None, None
+    hist, bin_edges = np.histogram(particle_pixels, bins=256, range=(0, 255), density=True)
+    cdf = np.cumsum(hist)
+    cdf /= cdf[-1]
+    return tuple(np.interp(q, cdf, bin_edges[:-1]) for q in (0.10, 0.50, 0.90))
+
+
+def contrast_from_counts(counts: np.ndarray):
+    """The same three values from the INTEGER histogram (bin i = pixels of gray level i, which is what np.histogram
+    counts for integer data on these edges) through numpy's own density / cumsum / interp arithmetic -- the host half of
+    the product path, restated here so that the tests can pin it against :func:`contrast_distribution`."""
+    counts = np.asarray(counts, dtype=np.int64)
+    if counts.sum() == 0:
+        return None, None, None
+    bin_edges = np.linspace(0, 255, 257)
+    db = np.array(np.diff(bin_edges), float)
+    hist = counts / db / counts.sum()
+    cdf = np.cumsum(hist)
+    cdf /= cdf[-1]
+    return tuple(np.interp(q, cdf, bin_edges[:-1]) for q in (0.10, 0.50, 0.90))
+
+
+def calculate_image_quality_score(image: np.ndarray) -> float:
+    """inference.py:256-285."""
+    gray = bgr_to_gray(image)
+    brightness = np.mean(gray) / 255.0
+    contrast = np.std(gray) / 128.0
+    return float(np.clip(0.4 * brightness + 0.6 * contrast, 0.0, 1.0))
+
+
+def get_confidence_threshold(image: np.ndarray, target_class: int, small_classes, global_config: dict) -> float:
+    """inference.py:288-362 (get_confidence_threshold -> adaptive_confidence_threshold): base threshold AND the mode are
+    read from the GLOBAL config (302, 352-359); quality < 0.3 -> x 0.7, < 0.5 -> x 0.85."""
+    inf = global_config.get("inference_settings", {})
+    class_config = inf.get("class_specific_settings", {}).get(f"class_{target_class}", {})
+    base = class_config.get("confidence_threshold", 0.3 if target_class in small_classes else 0.5)
+    if inf.get("confidence_mode", "auto") == "manual":
+        return base
+    q = calculate_image_quality_score(image)
+    if q < 0.3:
+        return base * 0.7
+    if q < 0.5:
+        return base * 0.85
+    return base
+
+
+def measure_mask(mask: np.ndarray, um_pix: float = 1.0, image: Optional[np.ndarray] = None,
+                 measure_contrast_distribution: bool = False) -> List[Dict[str, float]]:
+    """inference.py:1148-1230 for one instance: contours, area gate, measurements per contour (every contour of an
+    instance carries the contrast values of the whole instance mask, measurements.py:204)."""
     h, w = mask.shape
     min_area = max(5, h * w * 0.000005 * 0.05)
     rows = []
+    contrast = (None, None, None)
+    if measure_contrast_distribution and image is not None:
+        contrast = contrast_distribution(bgr_to_gray(image), mask)
     for c in find_external_contours(mask):
         if contour_area(c) < min_area:
             continue
-        rows.append(calculate_measurements(c, um_pix=um_pix))
+        r = calculate_measurements(c, um_pix=um_pix)
+        r["contrast_d10"], r["contrast_d50"], r["contrast_d90"] = contrast
+        rows.append(r)
     return rows
 
 

@@ -10,13 +10,16 @@ sd = synth.random_d2_state_dict(101, 2, 0)
 eng = E.MaskRCNNEngine(sd, 101, 2, 0.3, 'cuda:0', prec)
 x = torch.from_numpy(np.stack([synth.em_tile(i, 2048) for i in range(B)])).cuda()
 log = []
-orig = eng.conv
-def conv(xx, L, **kw):
+orig = eng.conv_p32 if eng.p32 else eng.conv
+def conv(xx, L, *a, **kw):
     n, h, w, cin = xx.shape
     ho = (h + 2 * L.pad - L.kh) // L.stride + 1; wo = (w + 2 * L.pad - L.kw) // L.stride + 1
     log.append((n * ho * wo, L.cout, L.kh * L.kw * cin, L.kh, L.stride))
-    return orig(xx, L, **kw)
-eng.conv = conv
+    return orig(xx, L, *a, **kw)
+if eng.p32:
+    eng.conv_p32 = conv
+else:
+    eng.conv = conv
 for _ in range(2): eng.forward(x)
 torch.cuda.synchronize(); log.clear(); eng.conv_events = []
 for _ in range(3): eng.forward(x)

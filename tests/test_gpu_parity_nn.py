@@ -35,8 +35,9 @@ def env(gpu_device):
     ref = R.predict(img, sd, 50, THR, return_intermediates=True)
     eng = MaskRCNNEngine(sd, 50, K, THR, gpu_device, "f32")
     eng3 = MaskRCNNEngine(sd, 50, K, THR, gpu_device, "f32x3")   # f32 operands on the bf16 pipe: same parity bar
-    eng2 = MaskRCNNEngine(sd, 50, K, THR, gpu_device, "f16x2")   # f32 operands on the fp16 pipe (2 scaled planes): same bar
-    return dict(sd=sd, img=img, ref=ref, eng=eng, f32=eng, f32x3=eng3, f16x2=eng2, R=R, synth=synth, dev=gpu_device)
+    eng2 = MaskRCNNEngine(sd, 50, K, THR, gpu_device, "f16x2")   # the default: fp16 pipe, activations as two pre-scaled fp16 planes (P32)
+    eng2r = MaskRCNNEngine(sd, 50, K, THR, gpu_device, "f16x2r")  # the same arithmetic from f32 activations (round 1's kernel)
+    return dict(sd=sd, img=img, ref=ref, eng=eng, f32=eng, f32x3=eng3, f16x2=eng2, f16x2r=eng2r, R=R, synth=synth, dev=gpu_device)
 
 
 def nhwc(t):
@@ -85,7 +86,54 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("prec", ["f32", "f32x3", "f16x2", "bf16x2", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_p32_vs_torch(env, case):
+    """The default arithmetic (f16x2 on P32 planes, demia_conv2d_p32) at the tolerance of the exact-f32 kernel; the
+    activations are scaled from 1e-3 to 1e3 and the epilogue's measured max |out| and plane scale are checked too."""
+    from deepemia_amd import engine as E, p32
+    from deepemia_amd._lib import ACT_NONE, ACT_RELU, RES_NONE, RES_SAME, RES_UP2
+
+    cin, cout, k, stride, pad, h, w, n, relu, res = case
+    if cin % 32:
+        pytest.skip("Cin must be a multiple of 32")
+    g = torch.Generator().manual_seed(cin * 131 + cout * 7 + k)
+    eng, dev = env["f16x2"], env["dev"]
+    x = torch.randn((n, cin, h, w), generator=g) * float(10.0 ** ((cin % 7) - 3))
+    wt = torch.randn((cout, cin, k, k), generator=g) / (cin * k * k) ** 0.5
+    scale = torch.rand((cout,), generator=g) + 0.5
+    bias = torch.randn((cout,), generator=g) * 0.1
+    y = F.conv2d(x.double(), wt.double(), None, stride=stride, padding=pad) * scale.double().view(1, -1, 1, 1) + bias.double().view(1, -1, 1, 1)
+    ho, wo = y.shape[2], y.shape[3]
+    residual = None
+    if res == 1:
+        residual = torch.randn((n, cout, ho, wo), generator=g)
+        y = y + residual.double()
+    elif res == 2:
+        residual = torch.randn((n, cout, (ho + 1) // 2, (wo + 1) // 2), generator=g)
+        y = y + F.interpolate(residual.double(), scale_factor=2.0, mode="nearest")[:, :, :ho, :wo]
+    if relu:
+        y = F.relu(y)
+    sd = {"l.weight": wt, "l.bias": bias}
+    eng._used = set()
+    L = eng._conv(sd, "l", stride=stride, pad=pad, bias=True)
+    # a FrozenBN-style scale on top of the bias path: scale3 = scale / 2^e(co), bound rescaled alike
+    L.scale3 = (L.scale3 * scale.to(dev)).contiguous()
+    L.wbound = float((scale.abs() * wt.abs().flatten(1).sum(1)).max())
+    out_f32 = cout % 32 != 0
+    xp = p32.from_f32(nhwc(x).to(dev))
+    rp = None if residual is None else p32.from_f32(nhwc(residual).to(dev))
+    out = eng.conv_p32(xp, L, act=ACT_RELU if relu else ACT_NONE, residual=rp, res_mode=(RES_NONE, RES_SAME, RES_UP2)[res],
+                       out_f32=out_f32, out_ld=(cout + 3) // 4 * 4 if out_f32 else 0)
+    got = (out[..., :cout] if out_f32 else eng.dense(out)).double().cpu().permute(0, 3, 1, 2)
+    err = float((got - y).abs().max() / y.abs().max())
+    assert err <= 2e-5, err
+    if not out_f32:
+        amax, s = float(out.meta[0]), float(out.meta[1])
+        assert abs(amax - float(y.abs().max())) <= 1e-5 * float(y.abs().max())
+        assert amax * s < 32768.0 and s == 2.0 ** round(np.log2(s))
+
+
+@pytest.mark.parametrize("prec", ["f32", "f32x3", "f16x2r", "bf16x2", "bf16"])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_igemm_vs_torch(env, case, prec):
     from deepemia_amd import engine as E
@@ -93,7 +141,7 @@ def test_conv_igemm_vs_torch(env, case, prec):
 
     cin, cout, k, stride, pad, h, w, n, relu, res = case
     g = torch.Generator().manual_seed(cin * 131 + cout * 7 + k)
-    eng = (env["f16x2"] if prec == "f16x2" else env["eng"]) if prec != "bf16" else E.MaskRCNNEngine.__new__(E.MaskRCNNEngine)
+    eng = (env["f16x2r"] if prec == "f16x2r" else env["eng"]) if prec != "bf16" else E.MaskRCNNEngine.__new__(E.MaskRCNNEngine)
     if prec == "bf16":
         eng.__dict__.update(env["eng"].__dict__)
         eng.dt, eng.tdt, eng.precision = E.BF16, torch.bfloat16, "bf16"
@@ -126,7 +174,7 @@ def test_conv_igemm_vs_torch(env, case, prec):
         if cout_pad % 64 or cin % 32:
             pytest.skip("shape stays on the exact-f32 kernel")
         L.w3 = E.tile_weight_planes(E.split3_bf16(wp).to(dev)[: 3 if prec == "f32x3" else 2])
-    if prec == "f16x2":
+    if prec == "f16x2r":
         # two fp16 planes per operand with exact power-of-two scales (weights per channel here, activations from the
         # |x| bound inside the kernel), three MFMAs per product: same tolerance as the exact-f32 kernel
         if cout_pad % 64 or cin % 32:
@@ -154,22 +202,22 @@ def test_conv_igemm_vs_torch(env, case, prec):
     out = eng.conv(nhwc(x).to(dev, eng.tdt), L, act=ACT_RELU if relu else ACT_NONE, residual=rdev,
                    res_mode=(RES_NONE, RES_SAME, RES_UP2)[res], out_dtype=odt)
     got = out.float().cpu().permute(0, 3, 1, 2)
-    tol = {"f32": 2e-5, "f32x3": 2e-5, "f16x2": 2e-5, "bf16x2": 2e-4, "bf16": 3e-2}[prec]
-    if prec == "f16x2":
+    tol = {"f32": 2e-5, "f32x3": 2e-5, "f16x2r": 2e-5, "bf16x2": 2e-4, "bf16": 3e-2}[prec]
+    if prec == "f16x2r":
         # the epilogue's |out| bound (the next layer's operand scale) is the exact maximum
         assert float(out._amax.item()) == float(out.abs().max().item())
     err = float((got - y).abs().max() / y.abs().max())
     assert err <= tol, err
 
 
-@pytest.mark.parametrize("prec", ["f32", "f32x3", "f16x2"])
+@pytest.mark.parametrize("prec", ["f32", "f32x3", "f16x2", "f16x2r"])
 def test_backbone_fpn_features_f32(env, prec):
     eng, d = env[prec], env["ref"]["dbg"]
     x = torch.from_numpy(env["img"])[None].to(env["dev"])
     xin, newh, neww, ph, pw = eng.preprocess(x)
     feats = eng.backbone(xin, ph, pw)
     for k in ("res2", "res3", "res4", "res5", "p2", "p3", "p4", "p5", "p6"):
-        a = feats[k][0].permute(2, 0, 1).cpu()
+        a = eng.dense(feats[k])[0].permute(2, 0, 1).cpu()
         b = d["feats"][k][0]
         assert a.shape == b.shape
         assert float((a - b).abs().max() / b.abs().max()) < 2e-5, k
@@ -312,7 +360,7 @@ def test_unpack_and_area_bbox_bit_exact(env):
         assert bbox[i].cpu().tolist() == exp
 
 
-@pytest.mark.parametrize("prec", ["f32", "f32x3", "f16x2"])
+@pytest.mark.parametrize("prec", ["f32", "f32x3", "f16x2", "f16x2r"])
 def test_end_to_end_f32_matches_oracle(env, prec):
     from deepemia_amd.predictor import Predictor
 
