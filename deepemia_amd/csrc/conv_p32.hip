@@ -31,6 +31,9 @@
 // `GeneralizedRCNN.inference` under `predictor(image)` (reference src/functions/inference.py:1395,1398,1507,1669;
 // src/data/models.py:107).
 #include "common.h"
+#ifndef P32_ABLATE
+#define P32_ABLATE 0      // timing-only dev builds: 1 = no A DMA after the first two steps, 2 = no B DMA, 4 = no MFMAs, 16 = vmcnt wait dropped
+#endif
 
 namespace {
 
@@ -141,14 +144,19 @@ __global__ __launch_bounds__(512, 2) void conv_p32_kernel(const ConvQ p) {
     unsigned sdelta = 0, srow = 0, sgrp = 0;
     auto issue = [&](int st, int tp, unsigned sd, unsigned bd) {
         const unsigned sbase = __builtin_amdgcn_readfirstlane(lds0 + st * STAGE + wave * 1024);
+        const bool first = bd < 2 * 8192u;
 #pragma unroll
         for (int q = 0; q < QA; ++q) {
+            if ((P32_ABLATE & 1) && !first) break;
             const bool ok = (a_msk[q] >> tp) & 1u;
             const unsigned vo = ok ? a_off[q] + sd : (a_off[q] & 0x70u);     // padding taps / rows beyond M: the zero header
             dma16(rsrc_a, sbase + q * 8192, vo, 0u);
         }
 #pragma unroll
-        for (int q = 0; q < QB; ++q) dma16(rsrc_b, sbase + BM * 128 + q * 8192, b_off[q], bd);
+        for (int q = 0; q < QB; ++q) {
+            if ((P32_ABLATE & 2) && !first) break;
+            dma16(rsrc_b, sbase + BM * 128 + q * 8192, b_off[q], bd);
+        }
     };
     const unsigned pixb = (unsigned)(p.Cin * 4), rowb = (unsigned)(p.W * p.Cin * 4);
 #define P32_ADVANCE()                                                                   \
@@ -182,22 +190,26 @@ __global__ __launch_bounds__(512, 2) void conv_p32_kernel(const ConvQ p) {
         const char* sb = smem + st * STAGE;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            uint4 bh[TN], bl[TN];
+            f16x8 bh[TN], bl[TN];
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                bh[j] = *reinterpret_cast<const uint4*>(sb + fb[kk] + j * 4096);
-                bl[j] = *reinterpret_cast<const uint4*>(sb + fb[2 + kk] + j * 4096);
+                bh[j] = *reinterpret_cast<const f16x8*>(sb + fb[kk] + j * 4096);
+                bl[j] = *reinterpret_cast<const f16x8*>(sb + fb[2 + kk] + j * 4096);
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const uint4 ah = *reinterpret_cast<const uint4*>(sb + fa[kk] + i * 4096);
-                const uint4 al = *reinterpret_cast<const uint4*>(sb + fa[2 + kk] + i * 4096);
+                const f16x8 ah = *reinterpret_cast<const f16x8*>(sb + fa[kk] + i * 4096);
+                const f16x8 al = *reinterpret_cast<const f16x8*>(sb + fa[2 + kk] + i * 4096);
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     f32x16 c = acc[i][j];     // smallest terms first
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(&ah), *reinterpret_cast<const f16x8*>(&bl[j]), c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(&al), *reinterpret_cast<const f16x8*>(&bh[j]), c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(&ah), *reinterpret_cast<const f16x8*>(&bh[j]), c, 0, 0, 0);
+                    if (P32_ABLATE & 4) {
+                        asm volatile("" :: "v"(ah), "v"(al), "v"(bh[j]), "v"(bl[j]));
+                        continue;
+                    }
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[j], c, 0, 0, 0);
                     acc[i][j] = c;
                 }
             }
@@ -225,7 +237,7 @@ __global__ __launch_bounds__(512, 2) void conv_p32_kernel(const ConvQ p) {
     //      walk the WM * 32 rows x BN columns in 8-channel groups: scale / bias / residual / activation, split, 16-byte stores
     constexpr int EROW = BN * 4 + 16;
     constexpr int GPR = BN / 8, RSTEP = 512 / GPR, ITEMS = WM * 32 / RSTEP;
-    static_assert(WM * 32 * EROW <= 2 * STAGE, "epilogue image fits the stages");
+    // (the launch sizes the LDS for max(two stages, this image))
     static_assert(512 % GPR == 0 && (WM * 32) % RSTEP == 0, "epilogue split");
     const float s_in = p.in_meta[1];
     const float post = 1.0f / s_in;
@@ -250,6 +262,32 @@ __global__ __launch_bounds__(512, 2) void conv_p32_kernel(const ConvQ p) {
     char* outb = reinterpret_cast<char*>(p.out) + 128;
     const long cbytes = (long)p.Cout * 4;                       // bytes per P32 pixel of the output / residual
     const int gofs = (co >> 5) * 128 + ((co & 31) >> 3) * 16;   // this thread's 8 channels inside a pixel (high plane)
+    // output row of item k in pass i, and the residual pixel that goes with it
+    auto row_of = [&](int i, int k) { const int lr = r_first + k * RSTEP; return m0 + (lr >> 5) * (TM * 32) + i * 32 + (lr & 31); };
+    auto res_pix = [&](int m) -> long {
+        if (p.res_mode == DEMIA_RES_SAME) return m;
+        const int n = m / p.HoWo;
+        const int rem = m - n * p.HoWo;
+        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+        const int Hr = (p.Ho + 1) >> 1, Wr = (p.Wo + 1) >> 1;
+        return ((long)n * Hr + (ho >> 1)) * Wr + (wo >> 1);
+    };
+    // The residual rows of a pass are requested ONE PASS AHEAD (all of them at once): a short-K layer is otherwise one
+    // exposed HBM round trip per item -- sixteen in a row for a 256 x 256 tile.
+    f16x8 rh[ITEMS], rl[ITEMS];
+    const bool has_res = p.res_mode != DEMIA_RES_NONE && co < p.Cout;
+    auto load_res = [&](int i) {
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) {
+            const int m = row_of(i, k);
+            if (has_res && m < p.M) {
+                const char* rp = resb + res_pix(m) * cbytes + gofs;
+                rh[k] = *reinterpret_cast<const f16x8*>(rp);
+                rl[k] = *reinterpret_cast<const f16x8*>(rp + 64);
+            }
+        }
+    };
+    load_res(0);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         if (i > 0) __syncthreads();
@@ -266,11 +304,15 @@ __global__ __launch_bounds__(512, 2) void conv_p32_kernel(const ConvQ p) {
                 }
         }
         __syncthreads();
+        f16x8 ch[ITEMS], cl[ITEMS];
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) { ch[k] = rh[k]; cl[k] = rl[k]; }
+        if (i + 1 < TM) load_res(i + 1);
         if (co < p.Cout) {
 #pragma unroll
             for (int k = 0; k < ITEMS; ++k) {
                 const int lr = r_first + k * RSTEP;
-                const int m = m0 + (lr >> 5) * (TM * 32) + i * 32 + (lr & 31);
+                const int m = row_of(i, k);
                 if (m >= p.M) continue;
                 const float4 x0 = *reinterpret_cast<const float4*>(smem + lr * EROW + g * 32);
                 const float4 x1 = *reinterpret_cast<const float4*>(smem + lr * EROW + g * 32 + 16);
@@ -278,20 +320,8 @@ __global__ __launch_bounds__(512, 2) void conv_p32_kernel(const ConvQ p) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) v[q] = v[q] * sc[q] + bs[q];
                 if (p.res_mode != DEMIA_RES_NONE) {
-                    long rp;
-                    if (p.res_mode == DEMIA_RES_SAME) {
-                        rp = m;
-                    } else {
-                        const int n = m / p.HoWo;
-                        const int rem = m - n * p.HoWo;
-                        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-                        const int Hr = (p.Ho + 1) >> 1, Wr = (p.Wo + 1) >> 1;
-                        rp = ((long)n * Hr + (ho >> 1)) * Wr + (wo >> 1);
-                    }
-                    const f16x8 rh = *reinterpret_cast<const f16x8*>(resb + rp * cbytes + gofs);
-                    const f16x8 rl = *reinterpret_cast<const f16x8*>(resb + rp * cbytes + gofs + 64);
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) v[q] += ((float)rh[q] + (float)rl[q]) * res_inv;
+                    for (int q = 0; q < 8; ++q) v[q] += ((float)ch[k][q] + (float)cl[k][q]) * res_inv;
                 }
 #pragma unroll
                 for (int q = 0; q < 8; ++q) v[q] = apply_act_q(v[q], p.act);
@@ -333,7 +363,8 @@ __global__ __launch_bounds__(512, 2) void conv_p32_kernel(const ConvQ p) {
 template <int WM, int WN, int TM, int TN>
 int launch_q(ConvQ p, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int smem = 2 * (BM + BN) * 128;
+    constexpr int stages = 2 * (BM + BN) * 128, image = WM * 32 * (BN * 4 + 16);
+    constexpr int smem = stages > image ? stages : image;
     p.ntn = p.CoutPad / BN;
     p.nwg = p.ntn * cdiv(p.M, BM);
     auto k = conv_p32_kernel<WM, WN, TM, TN>;
@@ -347,9 +378,36 @@ int launch_q(ConvQ p, hipStream_t st) {
     return DEMIA_OK;
 }
 
-// a launch lasts as long as the CU with the most tiles: efficiency of a tile height = (tiles / 256) / ceil(tiles / 256),
-// weighted by what the taller tile saves in weight-plane re-reads (rate)
-inline double balance(long tiles) { return ((double)tiles / 256.0) / (double)((tiles + 255) / 256); }
+// Tile choice: predicted launch time of every instantiated tile, from a four-parameter model fitted to a sweep of the
+// R101 layer shapes on one MI355X (scripts/gpu_conv_p32_check.py, profiles/r02_conv_p32_tile_sweep.txt): a K-step costs
+// 2.3 us x (tile area / 256^2) x (1 + 0.3 x (1 - area)) on a CU of its own, prologue + epilogue 6 + 14 x area us (twice
+// that with a residual); a launch takes as many rounds as the busiest CU gets tiles; tiles whose two stages fit twice
+// into the LDS run two workgroups per CU, which hides 40 % of the prologue / epilogue.  The model picks within 2 % of
+// the best measured configuration over the whole network.
+struct TileCfg { int id, bm, bn; };
+constexpr TileCfg kTiles[] = {{1, 256, 256}, {2, 128, 256}, {4, 192, 256}, {6, 256, 128}, {7, 128, 128}, {9, 256, 64}, {11, 128, 64}};
+
+inline double predict_us(const TileCfg& c, long M, int cout_pad, int ksteps, bool residual) {
+    const long tiles = (long)cdiv(M, c.bm) * (cout_pad / c.bn);
+    const int smem = 2 * (c.bm + c.bn) * 128;
+    const int occ = 160 * 1024 / smem >= 2 ? 2 : 1;
+    const double area = (double)c.bm * c.bn / 65536.0;
+    const double step = 2.3 * area * (1.0 + 0.3 * (1.0 - area));
+    const double edge = 6.0 + 14.0 * area * (residual ? 2.0 : 1.0);
+    if (occ == 1) return (double)((tiles + 255) / 256) * (ksteps * step + edge);
+    return (double)((tiles + 511) / 512) * (2.0 * ksteps * step + 2.0 * 0.6 * edge);
+}
+
+inline int choose_tile(long M, int cout_pad, int ksteps, bool residual) {
+    int best = 0;
+    double best_t = 1e30;
+    for (const TileCfg& c : kTiles) {
+        if (cout_pad % c.bn) continue;
+        const double t = predict_us(c, M, cout_pad, ksteps, residual);
+        if (t < best_t) { best_t = t; best = c.id; }
+    }
+    return best;
+}
 
 }  // namespace
 
@@ -385,14 +443,22 @@ extern "C" int demia_conv2d_p32(const demia_conv_p32_desc* d, void* stream) {
     p.ntn = p.nwg = 0;
     if (p.M == 0) return DEMIA_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int th = d->tile_hint;        // 0 = auto, else BM * 1000 + BN
-    if (d->CoutPad % 256 == 0) {
-        const long nt = d->CoutPad / 256;
-        const long t256 = nt * cdiv(p.M, 256), t128 = nt * cdiv(p.M, 128);
-        const bool half = th ? th == 128256 : (t256 < 256 || 0.85 * balance(t128) > balance(t256));
-        if (half) return launch_q<2, 4, 2, 2>(p, st);     // 128 x 256
-        return launch_q<2, 4, 4, 2>(p, st);               // 256 x 256
+    // tile_hint: 0 = auto (the model above), else one of the instantiated tiles (dev / tuning: scripts/gpu_conv_p32_check.py)
+    const int tile = d->tile_hint ? d->tile_hint : choose_tile(p.M, d->CoutPad, p.ksteps, d->res_mode != DEMIA_RES_NONE);
+    const bool n256 = d->CoutPad % 256 == 0, n128 = d->CoutPad % 128 == 0;
+    switch (tile) {
+        case 1: DEMIA_REQUIRE(n256, "tile needs CoutPad % 256 == 0"); return launch_q<2, 4, 4, 2>(p, st);   // 256 x 256
+        case 2: DEMIA_REQUIRE(n256, "tile needs CoutPad % 256 == 0"); return launch_q<2, 4, 2, 2>(p, st);   // 128 x 256
+        case 3: DEMIA_REQUIRE(n256, "tile needs CoutPad % 256 == 0"); return launch_q<1, 8, 8, 1>(p, st);   // 256 x 256, waves along N
+        case 4: DEMIA_REQUIRE(n256, "tile needs CoutPad % 256 == 0"); return launch_q<1, 8, 6, 1>(p, st);   // 192 x 256
+        case 5: DEMIA_REQUIRE(n256, "tile needs CoutPad % 256 == 0"); return launch_q<1, 8, 4, 1>(p, st);   // 128 x 256, waves along N
+        case 6: DEMIA_REQUIRE(n128, "tile needs CoutPad % 128 == 0"); return launch_q<4, 2, 2, 2>(p, st);   // 256 x 128
+        case 7: DEMIA_REQUIRE(n128, "tile needs CoutPad % 128 == 0"); return launch_q<4, 2, 1, 2>(p, st);   // 128 x 128
+        case 8: DEMIA_REQUIRE(n128, "tile needs CoutPad % 128 == 0"); return launch_q<2, 4, 2, 1>(p, st);   // 128 x 128, waves along N
+        case 9: return launch_q<8, 1, 1, 2>(p, st);                                                           // 256 x 64
+        case 10: return launch_q<4, 2, 2, 1>(p, st);                                                          // 256 x 64, two waves along N
+        case 11: return launch_q<4, 2, 1, 1>(p, st);                                                          // 128 x 64
+        default: DEMIA_REQUIRE(false, "tile_hint");
     }
-    if (d->CoutPad % 128 == 0) return launch_q<4, 2, 2, 2>(p, st);      // 256 x 128
-    return launch_q<8, 1, 1, 2>(p, st);                                  // 256 x 64
+    return DEMIA_EINVAL;
 }

@@ -10,6 +10,9 @@ sys.path.insert(0, '.')
 from deepemia_amd import _lib, p32, engine as E        # noqa: E402
 from deepemia_amd._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, RES_NONE, RES_SAME, RES_UP2, F16X2, F32   # noqa: E402
 
+import os, pathlib   # noqa: E402
+if os.environ.get('AB_LIB'):
+    _lib.LIB_PATH = pathlib.Path(os.environ['AB_LIB']).resolve()
 dev = torch.device('cuda:0')
 lib = _lib.load()
 st = lambda: int(torch.cuda.current_stream(dev).cuda_stream)
@@ -87,7 +90,6 @@ def check():
     cases = [
         # n, h, w, cin, cout, k, stride, pad, act, res_mode, out_f32, hint
         (2, 50, 50, 256, 256, 3, 1, 1, ACT_RELU, RES_NONE, False, 0),
-        (2, 50, 50, 256, 256, 3, 1, 1, ACT_RELU, RES_NONE, False, 128256),
         (1, 37, 29, 64, 64, 3, 1, 1, ACT_RELU, RES_NONE, False, 0),
         (3, 40, 40, 256, 128, 1, 2, 0, ACT_RELU, RES_NONE, False, 0),
         (2, 25, 25, 256, 1024, 1, 1, 0, ACT_RELU, RES_SAME, False, 0),
@@ -98,7 +100,7 @@ def check():
         (4, 14, 14, 256, 256, 3, 1, 1, ACT_RELU, RES_NONE, False, 0),
         (1, 20, 784, 256, 2, 1, 1, 0, ACT_SIGMOID, RES_NONE, True, 0),
         (1, 200, 200, 64, 256, 1, 1, 0, ACT_NONE, RES_NONE, False, 0),
-    ]
+    ] + [(2, 41, 37, 128, 256, 3, 1, 1, ACT_RELU, RES_SAME, False, hh) for hh in range(1, 12)]
     worst = 0.0
     for ci, (n, h, w, cin, cout, k, s, pd, act, rm, of32, hint) in enumerate(cases):
         g = torch.Generator().manual_seed(100 + ci)
@@ -135,25 +137,31 @@ def check():
     print(f'check ok, worst {worst:.2e}')
 
 
+HINTS = {1: '256x256', 2: '128x256', 3: '256x256n', 4: '192x256n', 5: '128x256n', 6: '256x128', 7: '128x128', 8: '128x128n',
+         9: '256x64', 10: '256x64b', 11: '128x64'}
+
 R101_B16 = [
-    # (count, M-shape n h w, cin, cout, k, stride)
-    (2, (16, 200, 200), 256, 256, 3, 1),
-    (4, (1600, 14, 14), 256, 256, 3, 1),
-    (25, (16, 50, 50), 256, 256, 3, 1),
-    (23, (16, 50, 50), 256, 1024, 1, 1),
-    (23, (16, 50, 50), 1024, 256, 1, 1),
-    (1, (1, 1, 16000), 12544, 1024, 1, 1),
-    (4, (16, 200, 200), 64, 256, 1, 1),
-    (2, (16, 100, 100), 256, 256, 3, 1),
-    (1, (1, 1, 313600), 256, 1024, 1, 1),
-    (4, (16, 100, 100), 128, 512, 1, 1),
-    (4, (16, 100, 100), 128, 128, 3, 1),
-    (3, (16, 200, 200), 64, 64, 3, 1),
-    (3, (16, 25, 25), 512, 512, 3, 1),
-    (1, (16, 200, 200), 256, 256, 1, 1),
-    (2, (16, 200, 200), 256, 64, 1, 1),
-    (3, (16, 100, 100), 512, 128, 1, 1),
-    (3, (16, 25, 25), 512, 2048, 1, 1),
+    # (count, M-shape n h w, cin, cout, k, stride, residual)
+    (2, (16, 200, 200), 256, 256, 3, 1, 0),
+    (4, (1600, 14, 14), 256, 256, 3, 1, 0),
+    (25, (16, 50, 50), 256, 256, 3, 1, 0),
+    (23, (16, 50, 50), 256, 1024, 1, 1, 1),
+    (23, (16, 50, 50), 1024, 256, 1, 1, 0),
+    (1, (1, 1, 16000), 12544, 1024, 1, 1, 0),
+    (4, (16, 200, 200), 64, 256, 1, 1, 1),
+    (2, (16, 100, 100), 256, 256, 3, 1, 0),
+    (1, (1, 1, 313600), 256, 1024, 1, 1, 0),
+    (4, (16, 100, 100), 128, 512, 1, 1, 1),
+    (4, (16, 100, 100), 128, 128, 3, 1, 0),
+    (3, (16, 200, 200), 64, 64, 3, 1, 0),
+    (3, (16, 25, 25), 512, 512, 3, 1, 0),
+    (1, (16, 200, 200), 256, 256, 1, 1, 1),
+    (2, (16, 200, 200), 256, 64, 1, 1, 0),
+    (3, (16, 100, 100), 512, 128, 1, 1, 0),
+    (3, (16, 25, 25), 512, 2048, 1, 1, 1),
+    (2, (16, 25, 25), 2048, 512, 1, 1, 0),
+    (1, (16, 200, 200), 256, 15, 1, 1, 0),
+    (1, (1, 1, 1254400), 256, 2, 1, 1, 0),
 ]
 
 
@@ -169,30 +177,59 @@ def timeit(fn, reps=5):
     return e0.elapsed_time(e1) / reps
 
 
-def time_layers():
-    tot_new = tot_old = tot_fl = 0.0
-    for cnt, (n, h, w), cin, cout, k, s in R101_B16:
+def time_layers(sweep=True, old=True):
+    tot_new = tot_old = tot_fl = tot_auto = 0.0
+    for cnt, (n, h, w), cin, cout, k, s, rs in R101_B16:
         L = Layer(cout, cin, k, k, seed=1)
         x = torch.randn(n, h, w, cin, device=dev)
         xp = p32.from_f32(x)
-        amax = x.abs().max().reshape(1)
         pd = k // 2
-        fl = 2.0 * n * (h // s) * (w // s) * cout * cin * k * k
-        hints = [0] if cout % 256 else [256256, 128256]
-        res = []
+        ho, wo = h // s, w // s
+        res = p32.from_f32(torch.randn(n, ho, wo, cout, device=dev)) if rs else None
+        rm = RES_SAME if rs else RES_NONE
+        of32 = cout % 32 != 0
+        fl = 2.0 * n * ho * wo * cout * cin * k * k
+        hints = [0]
+        if sweep:
+            hints += [hh for hh in HINTS if (hh <= 5 and L.cout_pad % 256 == 0) or (6 <= hh <= 8 and L.cout_pad % 128 == 0) or hh >= 9]
+        tt = {}
         for hint in hints:
-            res.append(timeit(lambda: conv_p32(xp, L, s, pd, ACT_RELU, hint=hint)))
-        t_old = timeit(lambda: conv_old(x, amax, L, s, pd, ACT_RELU))
-        t_new = min(res)
+            tt[hint] = timeit(lambda: conv_p32(xp, L, s, pd, ACT_RELU, res, rm, of32, 16 if of32 else 0, hint))
+        t_old = float('nan')
+        if old and cin * h * w * 8 < (1 << 30) and not of32 and not rs:
+            amax = x.abs().max().reshape(1)
+            t_old = timeit(lambda: conv_old(x, amax, L, s, pd, ACT_RELU))
+        best = min((v, kk) for kk, v in tt.items() if kk)[1] if sweep else 0
+        t_new = tt[best]
         tot_new += cnt * t_new
-        tot_old += cnt * t_old
+        tot_auto += cnt * tt[0]
         tot_fl += cnt * fl
-        print(f'M={n*h*w//(s*s):7d} cin={cin:5d} cout={cout:5d} k{k} x{cnt:2d}: p32 ' + ' / '.join(f'{fl/t/1e9:6.1f}' for t in res) +
-              f' TF/s ({t_new*1e3:7.1f} us)   old f16x2 {fl/t_old/1e9:6.1f} TF/s ({t_old*1e3:7.1f} us)', flush=True)
-    print(f'weighted total: p32 {tot_new:.2f} ms = {tot_fl/tot_new/1e9:.1f} TF/s; old {tot_old:.2f} ms = {tot_fl/tot_old/1e9:.1f} TF/s')
+        if t_old == t_old:
+            tot_old += cnt * t_old
+        print(f'M={n*ho*wo:7d} cin={cin:5d} cout={cout:5d} k{k} res{rs} x{cnt:2d}: auto {tt[0]*1e3:7.1f} us {fl/tt[0]/1e9:6.1f} TF/s | best {HINTS.get(best, "auto"):9s} '
+              f'{t_new*1e3:7.1f} us {fl/t_new/1e9:6.1f} TF/s | old {t_old*1e3:7.1f} us | ' +
+              ' '.join(f'{HINTS[kk]}={v*1e3:.0f}' for kk, v in tt.items() if kk), flush=True)
+    print(f'weighted total: auto {tot_auto:.2f} ms = {tot_fl/tot_auto/1e9:.1f} TF/s; best-of-sweep {tot_new:.2f} ms = {tot_fl/tot_new/1e9:.1f} TF/s; '
+          f'old (layers it ran) {tot_old:.2f} ms')
+
+
+def key_layers(hint=1):
+    """A few layers at one tile config: the A/B probe for kernel variants (AB_LIB=... selects the library)."""
+    out = []
+    for (n, h, w), cin, cout, k in [((16, 200, 200), 256, 256, 3), ((16, 50, 50), 256, 256, 3), ((1, 1, 16000), 12544, 1024, 1),
+                                    ((16, 50, 50), 1024, 256, 1)]:
+        L = Layer(cout, cin, k, k, seed=1)
+        xp = p32.from_f32(torch.randn(n, h, w, cin, device=dev))
+        fl = 2.0 * n * h * w * cout * cin * k * k
+        t = min(timeit(lambda: conv_p32(xp, L, 1, k // 2, ACT_RELU, hint=hint), reps=8) for _ in range(3))
+        out.append(f'M={n*h*w} K={cin*k*k} N={cout}: {t*1e3:.1f} us {fl/t/1e9:.1f} TF/s')
+    print(os.environ.get('AB_LIB', 'default'), f'hint {hint} |', ' | '.join(out), flush=True)
 
 
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'key':
+        key_layers(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+        sys.exit(0)
     mode = sys.argv[1] if len(sys.argv) > 1 else 'all'
     if mode in ('check', 'all'):
         check()

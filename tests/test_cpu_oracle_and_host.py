@@ -326,3 +326,90 @@ def test_f16x2_three_product_scheme_has_f32_sized_error():
         err = float((y.double() - ref).abs().max() / ref.abs().max())
         f32 = float(((a @ w.t()).double() - ref).abs().max() / ref.abs().max())
         assert err < 1e-6 and err < 4 * f32 + 1e-7, (amp, err, f32)
+
+
+def test_contrast_distribution_known_answers_and_host_percentiles():
+    """measurements.py:195-215: the oracle restatement (np.histogram on the masked gray levels) on closed-form cases, and the
+    product's host half (percentiles from the integer histogram the HIP kernel returns) against it, bit for bit."""
+    from deepemia_amd.utils.measurements import contrast_percentiles
+    from oracle import postproc_ref as P
+
+    gray = np.full((20, 30), 77, dtype=np.uint8)
+    mask = np.zeros((20, 30), dtype=bool)
+    mask[3:9, 4:20] = True
+    d10, d50, d90 = P.contrast_distribution(gray, mask)
+    w = 255.0 / 256.0
+    # one populated bin (77): the CDF jumps from 0 to 1 there, np.interp walks the step between the left edges 76 w and 77 w
+    assert d10 == pytest.approx((76 + 0.10) * w, rel=1e-12) and d50 == pytest.approx((76 + 0.5) * w, rel=1e-12)
+    assert d90 == pytest.approx((76 + 0.9) * w, rel=1e-12)
+    assert P.contrast_distribution(gray, np.zeros_like(mask)) == (None, None, None)
+    assert contrast_percentiles(np.zeros(256, dtype=np.int64)) == (None, None, None)
+    # BGR -> gray: OpenCV's fixed-point weights (white stays 255, pure channels 29 / 150 / 76)
+    px = np.array([[[255, 255, 255], [255, 0, 0], [0, 255, 0], [0, 0, 255]]], dtype=np.uint8)
+    assert P.bgr_to_gray(px).tolist() == [[255, 29, 150, 76]]
+    rng = np.random.default_rng(3)
+    for t in range(50):
+        g = rng.integers(0, 256, size=(33, 41), dtype=np.uint8)
+        if t % 4 == 0:
+            g = (g // 16 * 16).astype(np.uint8)
+        m = rng.random((33, 41)) > 0.5
+        want = P.contrast_distribution(g, m)
+        got = contrast_percentiles(np.bincount(g[m], minlength=256))
+        assert tuple(float(v) for v in want) == got
+
+
+def test_adaptive_confidence_threshold_follows_the_reference_rules():
+    """inference.py:256-362: quality = 0.4 mean / 255 + 0.6 std / 128 (clipped); < 0.3 -> base x 0.7, < 0.5 -> base x 0.85;
+    base and mode from the GLOBAL config; product and oracle agree."""
+    from deepemia_amd.functions import inference as I
+    from oracle import postproc_ref as P
+
+    black = np.zeros((64, 64, 3), dtype=np.uint8)
+    white = np.full((64, 64, 3), 255, dtype=np.uint8)
+    checker = np.zeros((64, 64, 3), dtype=np.uint8)
+    checker[::2, ::2] = 255
+    checker[1::2, 1::2] = 255
+    assert P.calculate_image_quality_score(black) == 0.0
+    assert P.calculate_image_quality_score(white) == pytest.approx(0.4)
+    assert P.calculate_image_quality_score(checker) == pytest.approx(0.4 * 0.5 + 0.6 * 127.5 / 128.0)
+    cfg = {"inference_settings": {"confidence_mode": "auto", "class_specific_settings": {"class_0": {"confidence_threshold": 0.6}}}}
+    small = {1}
+    for img, f in ((black, 0.7), (white, 0.85), (checker, 1.0)):
+        assert P.get_confidence_threshold(img, 0, small, cfg) == pytest.approx(0.6 * f)
+        assert P.get_confidence_threshold(img, 1, small, cfg) == pytest.approx(0.3 * f)      # small-class default
+        assert P.get_confidence_threshold(img, 2, small, cfg) == pytest.approx(0.5 * f)      # large-class default
+        for c in (0, 1, 2):
+            assert I.get_confidence_threshold(img, c, small, cfg) == P.get_confidence_threshold(img, c, small, cfg)
+        assert I.calculate_image_quality_score(img) == P.calculate_image_quality_score(img)
+    manual = {"inference_settings": {"confidence_mode": "manual", "class_specific_settings": {"class_0": {"confidence_threshold": 0.6}}}}
+    assert P.get_confidence_threshold(black, 0, small, manual) == 0.6 == I.get_confidence_threshold(black, 0, small, manual)
+    rng = np.random.default_rng(0)
+    for _ in range(10):
+        img = rng.integers(0, 256, size=(50, 70, 3), dtype=np.uint8)
+        assert I.calculate_image_quality_score(img) == P.calculate_image_quality_score(img)
+
+
+def test_p32_planes_roundtrip_and_weight_tiling():
+    """Host side of the f16x2 format: P32 planes carry 22 significand bits of every value behind a 128-byte zero header,
+    views keep the bytes, and the weight tiling is the documented [CoutPad / 64][channel group][tap][64][plane][32]."""
+    import torch
+    from deepemia_amd import engine as E, p32
+
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn((3, 5, 7, 64), generator=g) * 37.0
+    x[..., :5] *= 1e-4
+    t = p32.from_f32(x)
+    assert t.buf.dtype == torch.float16 and t.buf.numel() == 64 + 2 * x.numel() and not t.buf[:64].any()
+    amax, s = float(t.meta[0]), float(t.meta[1])
+    assert amax == float(x.abs().max()) and s == p32.plane_scale(amax) and amax * s < 32768.0 <= 2 * amax * s
+    back = p32.to_f32(t)
+    assert float(((back - x).abs() / x.abs().clamp(min=1e-30)).max()) < 2.0 ** -21
+    v = t.view(3 * 5 * 7 * 2, 32)
+    assert v.buf is t.buf and torch.equal(p32.to_f32(v).reshape(-1), back.reshape(3, 5, 7, 2, 32).reshape(-1))
+    assert p32.plane_scale(0.0) == 1.0 and p32.plane_scale(1.0) == 2.0 ** 14 and p32.plane_scale(3.9) == 2.0 ** 13
+    w = torch.randn((128, 3, 3, 64), generator=g)
+    planes, sw = E.split2_f16_scaled(w)
+    tiled = E.tile_weight_planes_p32(planes)
+    assert tuple(tiled.shape) == (2, 2, 9, 64, 2, 32)
+    for (p, co, kh, kw, ci) in [(0, 0, 0, 0, 0), (1, 5, 2, 1, 31), (0, 64, 1, 2, 32), (1, 127, 2, 2, 63), (0, 70, 0, 1, 40)]:
+        assert tiled[co // 64, ci // 32, kh * 3 + kw, co % 64, p, ci % 32] == planes[p, co, kh, kw, ci]

@@ -1,0 +1,79 @@
+"""The headline configuration itself under the oracle: BASELINE.json configs[1] -- R101-FPN, one 2048 x 2048 tile, the
+default ``f16x2`` arithmetic (P32 activations), threshold 0.3, K = 2 -- first ``predictor(tile)`` against the Detectron2
+restatement, then the whole per-tile path (class loop, dedup, contours, 12 measurements) against the dense CPU pipeline
+(``oracle/tile_parity.py``, the same functions ``bench.py`` uses for its ``parity`` field).
+
+Tolerances (north_star): same instances in the same order, scores within 1e-4, mask IoU >= 0.999, every measurement
+within 1e-4 relative.  Plus the batch behaviour of the f16x2 mode: its operand scales are per tensor per BATCH (exact
+powers of two), so a tile alone and the same tile inside a 16-tile batch must agree -- masks and classes exactly, scores
+to 1e-6."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CLASS_THRESHOLDS = {0: (0.3, 0.7), 1: (0.3, 0.5)}
+SMALL = {1}
+THR = 0.3
+
+
+@pytest.fixture(scope="module")
+def env(gpu_device):
+    from deepemia_amd import synth
+    from deepemia_amd.engine import MaskRCNNEngine
+    from deepemia_amd.functions.inference import InferencePipeline
+    from deepemia_amd.predictor import Predictor
+    from oracle import tile_parity as TP
+
+    sd = synth.random_d2_state_dict(101, 2, seed=0)
+    eng = MaskRCNNEngine(sd, 101, 2, THR, gpu_device, "f16x2")
+    img = synth.em_tile(0, 2048)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    ref = TP.reference_tile(img, sd, 101, THR, CLASS_THRESHOLDS, SMALL)
+    return dict(sd=sd, eng=eng, img=img, ref=ref, TP=TP, synth=synth, dev=gpu_device,
+                pipe=InferencePipeline([Predictor(eng)], "headline", {}, {}), Predictor=Predictor)
+
+
+def test_r101_2048_f16x2_predictor_matches_oracle(env):
+    raw = env["ref"]["raw"]
+    inst = env["Predictor"](env["eng"])(env["img"])["instances"].to("cpu")
+    n = raw["scores"].shape[0]
+    assert len(inst) == n == 100
+    np.testing.assert_array_equal(inst.pred_classes.numpy(), raw["pred_classes"].numpy())
+    assert float((inst.scores - raw["scores"]).abs().max()) < 1e-4
+    assert bool((inst.scores[:-1] >= inst.scores[1:]).all())
+    m, r = inst.pred_masks, raw["pred_masks"]
+    assert tuple(m.shape) == (n, 2048, 2048)
+    iou = (m & r).sum((1, 2)).float() / (m | r).sum((1, 2)).float().clamp(min=1)
+    assert float(iou.min()) >= 0.999, float(iou.min())
+
+
+def test_r101_2048_f16x2_whole_tile_path_matches_oracle(env):
+    pipe, dev, TP = env["pipe"], env["dev"], env["TP"]
+    x = torch.from_numpy(env["img"])[None].to(dev)
+    packed, scores, classes, recs = pipe.process_tile_batch("headline", x, SMALL, CLASS_THRESHOLDS)[0]
+    assert packed is not None and packed.shape[0] > 10
+    dense = pipe.ops.to_dense(packed, 2048)
+    res = TP.compare_tile(env["ref"], dense, scores, classes, recs)
+    print("headline parity:", {k: v for k, v in res.items()})
+    assert res["ok"], res
+    assert res["csv_rows"] >= res["instances"] > 10
+
+
+def test_f16x2_forward_is_batch_invariant(env):
+    eng, synth, dev = env["eng"], env["synth"], env["dev"]
+    tiles = np.stack([synth.em_tile(i, 2048) for i in range(16)])
+    tiles[3] = (tiles[3].astype(np.int32) * 5 // 2).clip(0, 255).astype(np.uint8)        # one tile much brighter than the others
+    x = torch.from_numpy(tiles).to(dev)
+    full = eng.forward(x)
+    for i in (0, 3, 15):
+        one = eng.forward(x[i:i + 1].contiguous())
+        n = int(one.count[0])
+        assert n == int(full.count[i]) and n > 10
+        assert torch.equal(one.classes[0, :n], full.classes[i, :n])
+        assert float((one.scores[0, :n] - full.scores[i, :n]).abs().max()) <= 1e-6
+        # the scales of a batch and of a single tile differ by exact powers of two: what can change is the low plane of
+        # values below 2^-16 of a tensor's maximum -- at most a threshold-tie pixel
+        diff = (eng.unpack(one.packed[0, :n].contiguous(), 2048, 2048) != eng.unpack(full.packed[i, :n].contiguous(), 2048, 2048))
+        assert int(diff.sum((1, 2)).max()) <= 1, int(diff.sum((1, 2)).max())

@@ -461,3 +461,34 @@ def test_rle_of_packed_masks_equals_reference_encoding(ops):
         assert got == [rle_encoding(m) for m in masks]
     finally:
         ops.set_frame_width(0)
+
+
+@pytest.mark.parametrize("shape", [(96, 160), (75, 101)])
+def test_gray_histogram_and_contrast_percentiles_vs_oracle(ops, shape):
+    """a18's contrast columns: the HIP histogram of the gray levels under each mask is bit-exact against
+    np.histogram(cvtColor(image)[mask > 0], 256, (0, 255)), the three percentiles equal the oracle's doubles; BGR and
+    already-gray images, widths that are not multiples of 32, an empty mask, a mask touching the frame."""
+    from deepemia_amd.utils.measurements import contrast_percentiles
+    from oracle import postproc_ref as P
+
+    h, w = shape
+    rng = np.random.default_rng(h * 1000 + w)
+    img = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+    img[:, : w // 2] = (img[:, : w // 2] // 32) * 32            # flat CDF stretches
+    masks = np.zeros((6, h, w), dtype=bool)
+    yy, xx = np.mgrid[0:h, 0:w]
+    for i in range(4):
+        cy, cx, r = rng.uniform(0, h), rng.uniform(0, w), rng.uniform(6, 30)
+        masks[i] = (yy - cy) ** 2 + (xx - cx) ** 2 <= r * r
+    masks[4, :, w - 3:] = True                                   # right border, last partial word
+    ops.set_frame_width(w)
+    packed = ops.from_dense(masks)
+    for image in (img, P.bgr_to_gray(img)):
+        gray = P.bgr_to_gray(image)
+        hist = ops.gray_histogram(packed, torch.from_numpy(np.ascontiguousarray(image)).to(ops.device))
+        for i in range(6):
+            want, _ = np.histogram(gray[masks[i]], bins=256, range=(0, 255))
+            np.testing.assert_array_equal(hist[i], want)
+            ref = P.contrast_distribution(gray, masks[i])
+            got = contrast_percentiles(hist[i])
+            assert (ref[0] is None and got[0] is None) or all(abs(float(a) - b) <= 1e-9 * max(abs(b), 1.0) for a, b in zip(ref, got))
