@@ -90,6 +90,138 @@ __device__ __forceinline__ float plane_scale(float bound) {
     return ldexpf(1.f, e);
 }
 
+// Epilogue shared by the conv_p32 kernels: TM passes; in pass i every wave hands tile-row i of its accumulators to LDS,
+// then the 512 threads walk the WM * 32 rows x BN columns in 8-channel groups: scale / bias / residual / activation,
+// split into planes, 16-byte stores.  All waves have passed a barrier after their last LDS read.
+template <int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void p32_epilogue(const ConvQ& p, char* smem, f32x16 (&acc)[TM][TN], int wm, int wn, int m0, int n0) {
+    constexpr int BN = WN * TN * 32;
+    const int tid = threadIdx.x, lane = tid & 63;
+    constexpr int EROW = BN * 4 + 16;
+    constexpr int GPR = BN / 8, RSTEP = 512 / GPR, ITEMS = WM * 32 / RSTEP;
+    // (the launch sizes the LDS for max(two stages, this image))
+    static_assert(512 % GPR == 0 && (WM * 32) % RSTEP == 0, "epilogue split");
+    const float s_in = p.in_meta[1];
+    const float post = 1.0f / s_in;
+    float s_out = 1.f, res_inv = 0.f;
+    if (p.res_mode != DEMIA_RES_NONE) res_inv = 1.0f / p.res_meta[1];
+    if (!p.out_f32) {
+        const float bound = p.in_meta[0] * p.wbound + p.bbound + (p.res_mode != DEMIA_RES_NONE ? p.res_meta[0] : 0.f);
+        s_out = plane_scale(bound);
+        if (blockIdx.x == 0 && tid == 0) p.out_meta[1] = s_out;
+    }
+    const int g = tid % GPR, r_first = tid / GPR;
+    const int co = n0 + g * 8;
+    float sc[8], bs[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const bool ok = (co + q) < p.Cout;
+        sc[q] = (p.scale && ok) ? p.scale[co + q] * post : post;
+        bs[q] = (p.bias && ok) ? p.bias[co + q] : 0.0f;
+    }
+    float vmax = 0.f;
+    const char* resb = reinterpret_cast<const char*>(p.res) + 128;
+    char* outb = reinterpret_cast<char*>(p.out) + 128;
+    const long cbytes = (long)p.Cout * 4;                       // bytes per P32 pixel of the output / residual
+    const int gofs = (co >> 5) * 128 + ((co & 31) >> 3) * 16;   // this thread's 8 channels inside a pixel (high plane)
+    // output row of item k in pass i, and the residual pixel that goes with it
+    auto row_of = [&](int i, int k) { const int lr = r_first + k * RSTEP; return m0 + (lr >> 5) * (TM * 32) + i * 32 + (lr & 31); };
+    auto res_pix = [&](int m) -> long {
+        if (p.res_mode == DEMIA_RES_SAME) return m;
+        const int n = m / p.HoWo;
+        const int rem = m - n * p.HoWo;
+        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+        const int Hr = (p.Ho + 1) >> 1, Wr = (p.Wo + 1) >> 1;
+        return ((long)n * Hr + (ho >> 1)) * Wr + (wo >> 1);
+    };
+    // The residual rows of a pass are requested ONE PASS AHEAD (all of them at once): a short-K layer is otherwise one
+    // exposed HBM round trip per item -- sixteen in a row for a 256 x 256 tile.
+    f16x8 rh[ITEMS], rl[ITEMS];
+    const bool has_res = p.res_mode != DEMIA_RES_NONE && co < p.Cout;
+    auto load_res = [&](int i) {
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) {
+            const int m = row_of(i, k);
+            if (has_res && m < p.M) {
+                const char* rp = resb + res_pix(m) * cbytes + gofs;
+                rh[k] = *reinterpret_cast<const f16x8*>(rp);
+                rl[k] = *reinterpret_cast<const f16x8*>(rp + 64);
+            }
+        }
+    };
+    load_res(0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        if (i > 0) __syncthreads();
+        {
+            float* e = reinterpret_cast<float*>(smem);
+            constexpr int EF = EROW / 4;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const int col = wn * TN * 32 + j * 32 + (lane & 31);
+                    e[row * EF + col] = acc[i][j][r];
+                }
+        }
+        __syncthreads();
+        f16x8 ch[ITEMS], cl[ITEMS];
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) { ch[k] = rh[k]; cl[k] = rl[k]; }
+        if (i + 1 < TM) load_res(i + 1);
+        if (co < p.Cout) {
+#pragma unroll
+            for (int k = 0; k < ITEMS; ++k) {
+                const int lr = r_first + k * RSTEP;
+                const int m = row_of(i, k);
+                if (m >= p.M) continue;
+                const float4 x0 = *reinterpret_cast<const float4*>(smem + lr * EROW + g * 32);
+                const float4 x1 = *reinterpret_cast<const float4*>(smem + lr * EROW + g * 32 + 16);
+                float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = v[q] * sc[q] + bs[q];
+                if (p.res_mode != DEMIA_RES_NONE) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] += ((float)ch[k][q] + (float)cl[k][q]) * res_inv;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = apply_act_q(v[q], p.act);
+                if (p.out_f32) {
+                    float* o = reinterpret_cast<float*>(p.out) + (long)m * p.out_ld + co;
+                    if (co + 8 <= p.Cout && (p.out_ld & 3) == 0) {
+                        *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+                        *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q)
+                            if (co + q < p.Cout) o[q] = v[q];
+                    }
+                } else {
+                    f16x8 h, l;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        vmax = fmaxf(vmax, fabsf(v[q]));
+                        const float y = v[q] * s_out;
+                        h[q] = (_Float16)y;
+                        l[q] = (_Float16)(y - (float)h[q]);
+                    }
+                    char* o = outb + (long)m * cbytes + gofs;
+                    *reinterpret_cast<f16x8*>(o) = h;
+                    *reinterpret_cast<f16x8*>(o + 64) = l;
+                }
+            }
+        }
+    }
+    if (!p.out_f32) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+        // the bound only grows: a (possibly stale) read that already covers this wave's maximum makes the atomic unnecessary
+        if (lane == 0 && vmax > *reinterpret_cast<volatile const float*>(p.out_meta))
+            atomicMax(reinterpret_cast<unsigned int*>(p.out_meta), __float_as_uint(vmax));
+    }
+}
+
 template <int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(512, 2) void conv_p32_kernel(const ConvQ p) {
     static_assert(WM * WN == 8, "eight waves");
@@ -233,131 +365,223 @@ __global__ __launch_bounds__(512, 2) void conv_p32_kernel(const ConvQ p) {
     }
 #undef P32_ADVANCE
 
-    // ---- epilogue: TM passes; in pass i every wave hands tile-row i of its accumulators to LDS, then the 512 threads
-    //      walk the WM * 32 rows x BN columns in 8-channel groups: scale / bias / residual / activation, split, 16-byte stores
-    constexpr int EROW = BN * 4 + 16;
-    constexpr int GPR = BN / 8, RSTEP = 512 / GPR, ITEMS = WM * 32 / RSTEP;
-    // (the launch sizes the LDS for max(two stages, this image))
-    static_assert(512 % GPR == 0 && (WM * 32) % RSTEP == 0, "epilogue split");
-    const float s_in = p.in_meta[1];
-    const float post = 1.0f / s_in;
-    float s_out = 1.f, res_inv = 0.f;
-    if (p.res_mode != DEMIA_RES_NONE) res_inv = 1.0f / p.res_meta[1];
-    if (!p.out_f32) {
-        const float bound = p.in_meta[0] * p.wbound + p.bbound + (p.res_mode != DEMIA_RES_NONE ? p.res_meta[0] : 0.f);
-        s_out = plane_scale(bound);
-        if (blockIdx.x == 0 && tid == 0) p.out_meta[1] = s_out;
-    }
-    const int g = tid % GPR, r_first = tid / GPR;
-    const int co = n0 + g * 8;
-    float sc[8], bs[8];
+    p32_epilogue<WM, WN, TM, TN>(p, smem, acc, wm, wn, m0, n0);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same tile as a PING-PONG of two wave groups (waves 0-3 = the upper half of the rows, waves 4-7 = the lower half;
+// wave w and wave w + 4 share a SIMD).  The plain kernel above runs all eight waves in lockstep -- fragment reads, MFMAs
+// and the barrier hit both waves of a SIMD at the same moment, and timing-only builds show its matrix pipe waiting for
+// LDS most of the time it is not busy (all work 1810 us, MFMAs alone 1090, everything but the MFMAs 914 on the largest
+// 3x3 layer: they add up instead of overlapping).  Here a K-step is four phases separated by workgroup barriers; in each
+// phase ONE group issues nothing but MFMAs on fragments it already holds in registers (24 of them, 768 matrix-pipe
+// cycles) while the OTHER group reads its next twelve fragments from LDS and requests the next K-step's operands:
+//
+//      phase 4t     group 0: LOAD(t, 0) + DMA(t+1): its A rows, B rows 0..127      group 1: MFMA(t-1, 1)
+//      phase 4t + 1 group 0: MFMA(t, 0)                                             group 1: LOAD(t, 0) + DMA(t+1): half of its A rows
+//      phase 4t + 2 group 0: LOAD(t, 1) + DMA(t+1): B rows 128..255                group 1: MFMA(t, 0)
+//      phase 4t + 3 group 0: MFMA(t, 1), then waits for its DMA(t+1)               group 1: LOAD(t, 1) + DMA(t+1): the other half
+//
+// so every SIMD always has one wave feeding the matrix pipe.  Stage (t+1) % 2 was last read in phase 4t - 1, its DMA is
+// issued from phase 4t on and waited for (by the waves that issued it, before a barrier) ahead of its first read in phase
+// 4t + 4 (group 0) / 4t + 5 (group 1): two to four phases of flight, like the plain kernel's one K-step.  A LOAD phase
+// ends with s_waitcnt lgkmcnt(0) before its barrier, so no read of a stage is still in flight when the other group starts
+// refilling it.  Fragments are single-buffered (48 registers): a group's LOAD and MFMA phases never overlap.
+template <int TM, int TN>
+__global__ __launch_bounds__(512, 2) void conv_p32_pp_kernel(const ConvQ p) {
+    constexpr int WM = 2, WN = 4;
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int STAGE = (BM + BN) * 128;
+    constexpr int QA = TM;            // A pieces (8 rows = 1 KiB) per wave per K-step: its group's half of the rows / 4 waves
+    constexpr int QB = TN * 4;        // B pieces per GROUP-0 wave per K-step
+    static_assert(QB % 2 == 0, "B pieces split over the two LOAD phases");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wn = wave & 3, wm = grp;
+    const int swz = xcd_remap(blockIdx.x, p.nwg);
+    const int tile_n = swz % p.ntn, tile_m = swz / p.ntn;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const i32x4 rsrc_a = make_rsrc(p.in, p.in_bytes), rsrc_b = make_rsrc(p.w, p.w_bytes);
+    const unsigned lds0 = (unsigned)(__SIZE_TYPE__)((lds_void*)smem);
+
+    // ---- DMA bookkeeping: wave (grp, wn) moves A pieces grp * 4 TM + wn + 4 q (q < TM) = rows of ITS group's half;
+    //      group-0 waves also move B pieces wn + 4 q (q < QB) ----
+    unsigned a_off[QA], a_msk[QA];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const bool ok = (co + q) < p.Cout;
-        sc[q] = (p.scale && ok) ? p.scale[co + q] * post : post;
-        bs[q] = (p.bias && ok) ? p.bias[co + q] : 0.0f;
-    }
-    float vmax = 0.f;
-    const char* resb = reinterpret_cast<const char*>(p.res) + 128;
-    char* outb = reinterpret_cast<char*>(p.out) + 128;
-    const long cbytes = (long)p.Cout * 4;                       // bytes per P32 pixel of the output / residual
-    const int gofs = (co >> 5) * 128 + ((co & 31) >> 3) * 16;   // this thread's 8 channels inside a pixel (high plane)
-    // output row of item k in pass i, and the residual pixel that goes with it
-    auto row_of = [&](int i, int k) { const int lr = r_first + k * RSTEP; return m0 + (lr >> 5) * (TM * 32) + i * 32 + (lr & 31); };
-    auto res_pix = [&](int m) -> long {
-        if (p.res_mode == DEMIA_RES_SAME) return m;
-        const int n = m / p.HoWo;
-        const int rem = m - n * p.HoWo;
+    for (int q = 0; q < QA; ++q) {
+        const int row = (grp * 4 * TM + wn + 4 * q) * 8 + (lane >> 3);
+        const int csw = (lane & 7) ^ ((row >> 1) & 7);
+        const int m = m0 + row;
+        const bool vm = m < p.M;
+        const int mm = vm ? m : 0;
+        const int n = mm / p.HoWo;
+        const int rem = mm - n * p.HoWo;
         const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-        const int Hr = (p.Ho + 1) >> 1, Wr = (p.Wo + 1) >> 1;
-        return ((long)n * Hr + (ho >> 1)) * Wr + (wo >> 1);
-    };
-    // The residual rows of a pass are requested ONE PASS AHEAD (all of them at once): a short-K layer is otherwise one
-    // exposed HBM round trip per item -- sixteen in a row for a 256 x 256 tile.
-    f16x8 rh[ITEMS], rl[ITEMS];
-    const bool has_res = p.res_mode != DEMIA_RES_NONE && co < p.Cout;
-    auto load_res = [&](int i) {
-#pragma unroll
-        for (int k = 0; k < ITEMS; ++k) {
-            const int m = row_of(i, k);
-            if (has_res && m < p.M) {
-                const char* rp = resb + res_pix(m) * cbytes + gofs;
-                rh[k] = *reinterpret_cast<const f16x8*>(rp);
-                rl[k] = *reinterpret_cast<const f16x8*>(rp + 64);
-            }
+        const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+        const long pix = ((long)n * p.H + hi0) * p.W + wi0;
+        a_off[q] = (unsigned)(128 + pix * (long)(p.Cin * 4) + csw * 16);
+        unsigned mk = 0;
+        for (int t = 0; t < p.taps; ++t) {
+            const int th = t / p.KW, tw = t - th * p.KW;
+            if (vm && (unsigned)(hi0 + th) < (unsigned)p.H && (unsigned)(wi0 + tw) < (unsigned)p.W) mk |= 1u << t;
         }
-    };
-    load_res(0);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        if (i > 0) __syncthreads();
-        {
-            float* e = reinterpret_cast<float*>(smem);
-            constexpr int EF = EROW / 4;
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    const int col = wn * TN * 32 + j * 32 + (lane & 31);
-                    e[row * EF + col] = acc[i][j][r];
-                }
-        }
-        __syncthreads();
-        f16x8 ch[ITEMS], cl[ITEMS];
-#pragma unroll
-        for (int k = 0; k < ITEMS; ++k) { ch[k] = rh[k]; cl[k] = rl[k]; }
-        if (i + 1 < TM) load_res(i + 1);
-        if (co < p.Cout) {
-#pragma unroll
-            for (int k = 0; k < ITEMS; ++k) {
-                const int lr = r_first + k * RSTEP;
-                const int m = row_of(i, k);
-                if (m >= p.M) continue;
-                const float4 x0 = *reinterpret_cast<const float4*>(smem + lr * EROW + g * 32);
-                const float4 x1 = *reinterpret_cast<const float4*>(smem + lr * EROW + g * 32 + 16);
-                float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-#pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = v[q] * sc[q] + bs[q];
-                if (p.res_mode != DEMIA_RES_NONE) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) v[q] += ((float)ch[k][q] + (float)cl[k][q]) * res_inv;
-                }
-#pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = apply_act_q(v[q], p.act);
-                if (p.out_f32) {
-                    float* o = reinterpret_cast<float*>(p.out) + (long)m * p.out_ld + co;
-                    if (co + 8 <= p.Cout && (p.out_ld & 3) == 0) {
-                        *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-                        *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < 8; ++q)
-                            if (co + q < p.Cout) o[q] = v[q];
-                    }
-                } else {
-                    f16x8 h, l;
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        vmax = fmaxf(vmax, fabsf(v[q]));
-                        const float y = v[q] * s_out;
-                        h[q] = (_Float16)y;
-                        l[q] = (_Float16)(y - (float)h[q]);
-                    }
-                    char* o = outb + (long)m * cbytes + gofs;
-                    *reinterpret_cast<f16x8*>(o) = h;
-                    *reinterpret_cast<f16x8*>(o + 64) = l;
-                }
-            }
-        }
+        a_msk[q] = mk;
     }
-    if (!p.out_f32) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
-        // the bound only grows: a (possibly stale) read that already covers this wave's maximum makes the atomic unnecessary
-        if (lane == 0 && vmax > *reinterpret_cast<volatile const float*>(p.out_meta))
-            atomicMax(reinterpret_cast<unsigned int*>(p.out_meta), __float_as_uint(vmax));
+    // B piece q of this wave = tile rows (wn + 4 q) * 8 ..: 32 rows further per q, i.e. half a 64-row block of the tiled planes
+    unsigned b_off0;
+    {
+        const int row = wn * 8 + (lane >> 3);
+        const int csw = (lane & 7) ^ ((row >> 1) & 7);
+        const int co = n0 + row;
+        b_off0 = (unsigned)(((co >> 6) * p.ksteps) * 8192 + (co & 63) * 128 + csw * 16);
     }
+    const unsigned b_blk = (unsigned)p.ksteps * 8192u;          // bytes between consecutive 64-row blocks
+
+    // K-step being REQUESTED (scalar state, identical in every wave)
+    int tap = 0, kw = 0, tstep = 0;
+    unsigned sdelta = 0, srow = 0, sgrp = 0;
+    const unsigned pixb = (unsigned)(p.Cin * 4), rowb = (unsigned)(p.W * p.Cin * 4);
+#define P32_ADVANCE()                                                                   \
+    do {                                                                                \
+        ++tstep;                                                                        \
+        if (++tap == p.taps) { tap = 0; kw = 0; srow = 0; sgrp += 128u; sdelta = sgrp; } \
+        else if (++kw == p.KW) { kw = 0; srow += rowb; sdelta = srow + sgrp; }          \
+        else sdelta += pixb;                                                            \
+    } while (0)
+    auto issue_a = [&](int st, int q0, int q1) {        // A pieces q0 .. q1 - 1 of this wave for the requested K-step
+        const unsigned sbase = __builtin_amdgcn_readfirstlane(lds0 + st * STAGE + (grp * 4 * TM + wn) * 1024);
+#pragma unroll
+        for (int q = 0; q < QA; ++q) {
+            if (q < q0 || q >= q1) continue;
+            const bool ok = (a_msk[q] >> tap) & 1u;
+            const unsigned vo = ok ? a_off[q] + sdelta : (a_off[q] & 0x70u);
+            dma16(rsrc_a, sbase + q * 4096, vo, 0u);
+        }
+    };
+    auto issue_b = [&](int st, int q0, int q1) {        // B pieces (group 0 only)
+        const unsigned sbase = __builtin_amdgcn_readfirstlane(lds0 + st * STAGE + BM * 128 + wn * 1024);
+        const unsigned bd = (unsigned)tstep * 8192u;
+#pragma unroll
+        for (int q = 0; q < QB; ++q) {
+            if (q < q0 || q >= q1) continue;
+            dma16(rsrc_b, sbase + q * 4096, b_off0 + (q & 1) * 4096u + (q >> 1) * b_blk, bd);
+        }
+    };
+
+    // ---- fragments: single-buffered, twelve 16-byte reads per (K-step, kk) ----
+    const int fsw = (lane >> 1) & 7, hh = lane >> 5;
+    const int a_row = (wm * TM * 32 + (lane & 31)) * 128, b_row = BM * 128 + (wn * TN * 32 + (lane & 31)) * 128;
+    f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+    auto load_frags = [&](int st, int kk) {
+        const char* sb = smem + st * STAGE;
+        const int ch = (((kk * 2 + hh) ^ fsw) * 16), cl = (((4 + kk * 2 + hh) ^ fsw) * 16);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            bh[j] = *reinterpret_cast<const f16x8*>(sb + b_row + ch + j * 4096);
+            bl[j] = *reinterpret_cast<const f16x8*>(sb + b_row + cl + j * 4096);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            ah[i] = *reinterpret_cast<const f16x8*>(sb + a_row + ch + i * 4096);
+            al[i] = *reinterpret_cast<const f16x8*>(sb + a_row + cl + i * 4096);
+        }
+    };
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto mfma_phase = [&]() {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                f32x16 c = acc[i][j];     // smallest terms first
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], c, 0, 0, 0);
+                acc[i][j] = c;
+            }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // phase boundary: every LDS read of this wave has returned, then the workgroup barrier
+#define P32_PHASE_END()                                                  \
+    do {                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                               \
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
+        __builtin_amdgcn_sched_barrier(0);                               \
+    } while (0)
+
+    // ---- prologue: stage 0 <- K-step 0, by the same piece assignment ----
+    issue_a(0, 0, QA);
+    if (grp == 0) issue_b(0, 0, QB);
+    P32_ADVANCE();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    P32_PHASE_END();
+
+    const int T = p.ksteps;
+    if (grp == 0) {
+        for (int t = 0; t < T; ++t) {
+            const int st = t & 1;
+            const bool more = t + 1 < T;
+            load_frags(st, 0);                                   // phase 4t
+            if (more) { issue_a(st ^ 1, 0, QA); issue_b(st ^ 1, 0, QB / 2); }
+            P32_PHASE_END();
+            mfma_phase();                                        // phase 4t + 1
+            P32_PHASE_END();
+            load_frags(st, 1);                                   // phase 4t + 2
+            if (more) { issue_b(st ^ 1, QB / 2, QB); P32_ADVANCE(); }
+            P32_PHASE_END();
+            mfma_phase();                                        // phase 4t + 3
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of stage t + 1 has landed
+            P32_PHASE_END();
+        }
+        P32_PHASE_END();                                         // phase 4T: group 1's last MFMAs
+    } else {
+        for (int t = 0; t < T; ++t) {
+            const int st = t & 1;
+            const bool more = t + 1 < T;
+            if (t > 0) mfma_phase();                             // phase 4t: MFMA(t - 1, 1)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's A rows of stage t (requested a K-step ago)
+            P32_PHASE_END();
+            load_frags(st, 0);                                   // phase 4t + 1
+            if (more) issue_a(st ^ 1, 0, (QA + 1) / 2);
+            P32_PHASE_END();
+            mfma_phase();                                        // phase 4t + 2
+            P32_PHASE_END();
+            load_frags(st, 1);                                   // phase 4t + 3
+            if (more) { issue_a(st ^ 1, (QA + 1) / 2, QA); P32_ADVANCE(); }
+            P32_PHASE_END();
+        }
+        mfma_phase();                                            // phase 4T
+        P32_PHASE_END();
+    }
+#undef P32_ADVANCE
+#undef P32_PHASE_END
+    p32_epilogue<WM, WN, TM, TN>(p, smem, acc, wm, wn, m0, n0);
+}
+
+template <int TM, int TN>
+int launch_pp(ConvQ p, hipStream_t st) {
+    constexpr int BM = 2 * TM * 32, BN = 4 * TN * 32;
+    constexpr int stages = 2 * (BM + BN) * 128, image = 2 * 32 * (BN * 4 + 16);
+    constexpr int smem = stages > image ? stages : image;
+    p.ntn = p.CoutPad / BN;
+    p.nwg = p.ntn * cdiv(p.M, BM);
+    auto k = conv_p32_pp_kernel<TM, TN>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k, dim3(p.nwg), dim3(512), smem, st, p);
+    DEMIA_CHECK_LAUNCH("conv_p32_pp_kernel");
+    return DEMIA_OK;
 }
 
 template <int WM, int WN, int TM, int TN>
@@ -458,6 +682,9 @@ extern "C" int demia_conv2d_p32(const demia_conv_p32_desc* d, void* stream) {
         case 9: return launch_q<8, 1, 1, 2>(p, st);                                                           // 256 x 64
         case 10: return launch_q<4, 2, 2, 1>(p, st);                                                          // 256 x 64, two waves along N
         case 11: return launch_q<4, 2, 1, 1>(p, st);                                                          // 128 x 64
+        case 21: DEMIA_REQUIRE(n256, "tile needs CoutPad % 256 == 0"); return launch_pp<4, 2>(p, st);        // 256 x 256, ping-pong
+        case 22: DEMIA_REQUIRE(n256, "tile needs CoutPad % 256 == 0"); return launch_pp<2, 2>(p, st);        // 128 x 256, ping-pong
+        case 26: DEMIA_REQUIRE(n128, "tile needs CoutPad % 128 == 0"); return launch_pp<4, 1>(p, st);        // 256 x 128, ping-pong
         default: DEMIA_REQUIRE(false, "tile_hint");
     }
     return DEMIA_EINVAL;

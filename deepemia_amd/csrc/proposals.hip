@@ -302,21 +302,37 @@ struct DetP {
 constexpr int DET_MAXC = 4096;
 constexpr int DET_MAXK = 128;
 
-// grid N, block 1024.  LDS: keys 32 KiB + cand boxes 64 KiB + kept list
+// Class-specific box of proposal `pb` from its four deltas (weights 10, 10, 5, 5), clipped to the image; `fin` is cleared
+// when a coordinate is not finite BEFORE clipping (Detectron2 drops such rows).
+__device__ __forceinline__ float4 det_class_box(const float* d, const float4& pb, float iw, float ih, bool& fin) {
+    const float widths = pb.z - pb.x, heights = pb.w - pb.y;
+    const float cx = pb.x + 0.5f * widths, cy = pb.y + 0.5f * heights;
+    const float dx = d[0] / 10.0f, dy = d[1] / 10.0f;
+    const float dw = fminf(d[2] / 5.0f, SCALE_CLAMP), dh = fminf(d[3] / 5.0f, SCALE_CLAMP);
+    const float pcx = dx * widths + cx, pcy = dy * heights + cy;
+    const float pw = expf(dw) * widths, ph = expf(dh) * heights;
+    const float x1 = pcx - 0.5f * pw, y1 = pcy - 0.5f * ph, x2 = pcx + 0.5f * pw, y2 = pcy + 0.5f * ph;
+    fin = fin && isfinite(x1) && isfinite(y1) && isfinite(x2) && isfinite(y2);
+    return make_float4(fminf(fmaxf(x1, 0.f), iw), fminf(fmaxf(y1, 0.f), ih), fminf(fmaxf(x2, 0.f), iw), fminf(fmaxf(y2, 0.f), ih));
+}
+
+// grid N, block 1024.  LDS: keys 32 KiB + kept list.  Only candidates whose score passes the threshold take a slot (a
+// softmax row has at most floor(1 / thresh) of them), so any number of classes fits as long as R * min(K, 1 / thresh)
+// stays within DET_MAXC; the sort key carries the row-major candidate id (proposal * K + class), so the order does not
+// depend on which slot a candidate landed in, and the NMS wave recomputes a candidate's box from its id.
 __global__ __launch_bounds__(1024) void box_detections_kernel(const DetP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);   // [4096]
-    float4* cbox = reinterpret_cast<float4*>(keys + DET_MAXC);                // [4096] by candidate id
-    float4* kbox = cbox + DET_MAXC;                                           // [128] kept boxes
+    float4* kbox = reinterpret_cast<float4*>(keys + DET_MAXC);                // [128] kept boxes
     int* kcls = reinterpret_cast<int*>(kbox + DET_MAXK);                      // [128]
     float* kscore = reinterpret_cast<float*>(kcls + DET_MAXK);                // [128]
-    __shared__ int nkept;
+    __shared__ int nkept, ncand;
     const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int K = p.K;
     const int R = p.prop_count[n] < p.R ? p.prop_count[n] : p.R;
     const float iw = (float)p.img_w, ih = (float)p.img_h;
     for (int i = tid; i < DET_MAXC; i += blockDim.x) keys[i] = 0ull;
-    if (tid == 0) nkept = 0;
+    if (tid == 0) { nkept = 0; ncand = 0; }
     __syncthreads();
     for (int r = tid; r < R; r += blockDim.x) {
         const float* lg = p.logits + ((long)n * p.R + r) * p.ld;
@@ -325,28 +341,17 @@ __global__ __launch_bounds__(1024) void box_detections_kernel(const DetP p) {
         float sum = 0.f;
         for (int c = 0; c <= K; ++c) sum += expf(lg[c] - mx);
         const float4 pb = reinterpret_cast<const float4*>(p.props)[(long)n * p.R + r];
-        const float widths = pb.z - pb.x, heights = pb.w - pb.y;
-        const float cx = pb.x + 0.5f * widths, cy = pb.y + 0.5f * heights;
         bool row_fin = true;
         for (int c = 0; c <= K; ++c) row_fin = row_fin && isfinite(expf(lg[c] - mx) / sum);
-        float4 bb[8];
-        for (int c = 0; c < K && c < 8; ++c) {
-            const float* d = lg + K + 1 + 4 * c;
-            const float dx = d[0] / 10.0f, dy = d[1] / 10.0f;
-            const float dw = fminf(d[2] / 5.0f, SCALE_CLAMP), dh = fminf(d[3] / 5.0f, SCALE_CLAMP);
-            const float pcx = dx * widths + cx, pcy = dy * heights + cy;
-            const float pw = expf(dw) * widths, ph = expf(dh) * heights;
-            const float x1 = pcx - 0.5f * pw, y1 = pcy - 0.5f * ph, x2 = pcx + 0.5f * pw, y2 = pcy + 0.5f * ph;
-            row_fin = row_fin && isfinite(x1) && isfinite(y1) && isfinite(x2) && isfinite(y2);
-            bb[c] = make_float4(fminf(fmaxf(x1, 0.f), iw), fminf(fmaxf(y1, 0.f), ih), fminf(fmaxf(x2, 0.f), iw),
-                                fminf(fmaxf(y2, 0.f), ih));
-        }
-        for (int c = 0; c < K && c < 8; ++c) {
+        for (int c = 0; c < K; ++c) (void)det_class_box(lg + K + 1 + 4 * c, pb, iw, ih, row_fin);
+        if (!row_fin) continue;
+        for (int c = 0; c < K; ++c) {
             const float sc = expf(lg[c] - mx) / sum;
-            const int cand = r * K + c;
-            cbox[cand] = bb[c];
-            if (row_fin && sc > p.score_thresh)
-                keys[cand] = ((unsigned long long)f2key(sc) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)cand);
+            if (sc > p.score_thresh) {
+                const int slot = atomicAdd(&ncand, 1);
+                if (slot < DET_MAXC)
+                    keys[slot] = ((unsigned long long)f2key(sc) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)(r * K + c));
+            }
         }
     }
     __syncthreads();
@@ -359,8 +364,10 @@ __global__ __launch_bounds__(1024) void box_detections_kernel(const DetP p) {
             const bool live = kk != 0ull;
             if (!__any(live)) break;
             const int cand = live ? (int)(0xFFFFFFFFu - (unsigned)(kk & 0xFFFFFFFFull)) : 0;
-            const int cls = cand % K;
-            const float4 b = cbox[cand];
+            const int cls = cand % K, prow = cand / K;
+            bool fin_unused = true;
+            const float4 b = det_class_box(p.logits + ((long)n * p.R + prow) * p.ld + K + 1 + 4 * cls,
+                                           reinterpret_cast<const float4*>(p.props)[(long)n * p.R + prow], iw, ih, fin_unused);
             bool sup = !live;
             for (int j = 0; j < kept_n && !sup; ++j)
                 if (kcls[j] == cls && iou_gt(kbox[j], b, p.nms_thresh)) sup = true;
@@ -448,8 +455,12 @@ extern "C" int demia_rpn_proposals(const demia_rpn_desc* d, void* stream) {
 extern "C" int demia_box_detections(const demia_dets_desc* d, void* stream) {
     DEMIA_REQUIRE(d && d->logits && d->props && d->prop_count && d->det_boxes && d->det_scores && d->det_classes &&
                       d->det_count, "null pointer");
-    DEMIA_REQUIRE(d->K >= 1 && d->K <= 8, "1 <= K <= 8");
-    DEMIA_REQUIRE((long)d->R * d->K <= DET_MAXC, "R*K <= 4096");
+    DEMIA_REQUIRE(d->K >= 1 && d->score_thresh > 0.f, "K >= 1, score_thresh > 0");
+    {
+        // a softmax row has at most floor(1 / thresh) entries above thresh: that many candidates per proposal can take a slot
+        const long per_row = d->K < (long)(1.0f / d->score_thresh) ? d->K : (long)(1.0f / d->score_thresh);
+        DEMIA_REQUIRE((long)d->R * per_row <= DET_MAXC, "R * min(K, floor(1 / score_thresh)) must stay within 4096 candidates");
+    }
     DEMIA_REQUIRE(d->topk > 0 && d->topk <= DET_MAXK, "topk <= 128");
     DEMIA_REQUIRE(d->ld >= 5 * d->K + 1, "ld");
     DetP p;
@@ -458,7 +469,7 @@ extern "C" int demia_box_detections(const demia_dets_desc* d, void* stream) {
     p.score_thresh = d->score_thresh; p.nms_thresh = d->nms_thresh; p.topk = d->topk;
     p.det_boxes = d->det_boxes; p.det_scores = d->det_scores; p.det_classes = d->det_classes; p.det_count = d->det_count;
     if (d->N == 0) return DEMIA_OK;
-    const int smem = DET_MAXC * 8 + DET_MAXC * 16 + DET_MAXK * (16 + 4 + 4);
+    const int smem = DET_MAXC * 8 + DET_MAXK * (16 + 4 + 4);
     static bool done = false;
     if (!done) {
         (void)hipFuncSetAttribute((const void*)box_detections_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);

@@ -214,6 +214,13 @@ class MaskRCNNEngine:
         self.depth = depth
         self.K = int(num_classes)
         self.score_thresh = float(score_thresh)
+        # demia_box_detections keeps at most 4096 above-threshold candidates per image in LDS; a softmax row has at most
+        # floor(1 / thresh) of them, so every class count works for thresholds above 0.2 (the reference's default is 0.65)
+        per_row = min(self.K, int(1.0 / self.score_thresh)) if self.score_thresh > 0 else self.K
+        if self.score_thresh <= 0 or POST_NMS_TOPK * per_row > 4096:
+            raise ValueError(f"{self.K} classes at score threshold {self.score_thresh}: up to {POST_NMS_TOPK} x {per_row} candidates per "
+                             f"image exceed the 4096 the detection kernel sorts -- raise --threshold above {1.0 / (4096 // POST_NMS_TOPK + 1):.2f} "
+                             f"or use at most {4096 // POST_NMS_TOPK} classes")
         self.device = torch.device(device)
         self.precision = precision
         # INPUT.MIN_SIZE_TEST / MAX_SIZE_TEST of the model-zoo config the reference loads (800 / 1333, never overridden

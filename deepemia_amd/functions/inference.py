@@ -184,6 +184,9 @@ class InferencePipeline:
         self.ensemble_weights = list(gens.get("weights", {"R50": 0.6, "R101": 0.4}).values())
         self.class_specific_settings = inf_settings.get("class_specific_settings", {})
         self._cache: Dict[Tuple[int, str], List[_Detections]] = {}
+        # images per batched forward: l4_performance_optimizations.forward_batch_size / DEEPEMIA_FORWARD_BATCH (default 16:
+        # fills 256 CUs on the 50^2 feature maps, 8.6 GiB of activations per 2048^2-tile batch)
+        self.forward_batch = max(1, int(os.environ.get("DEEPEMIA_FORWARD_BATCH", l4.get("forward_batch_size", 16))))
         self.last_batch_stats = None
         self.forward_calls = 0
         import torch.distributed as dist
@@ -197,8 +200,9 @@ class InferencePipeline:
         can overlap this batch's network with the previous batch's post-processing on another stream."""
         pred = self.predictors[model_idx]
         raws = []
-        for b0 in range(0, images.shape[0], 16):
-            raws.append(pred.engine.forward(images[b0:b0 + 16].contiguous()))
+        step = self.forward_batch
+        for b0 in range(0, images.shape[0], step):
+            raws.append(pred.engine.forward(images[b0:b0 + step].contiguous()))
             self.forward_calls += 1
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.dev))
@@ -206,9 +210,15 @@ class InferencePipeline:
 
     def finish_forward(self, handle) -> List[_Detections]:
         raws, ev, (h, w) = handle
-        torch.cuda.current_stream(self.dev).wait_event(ev)
+        cur = torch.cuda.current_stream(self.dev)
+        cur.wait_event(ev)
         out: List[_Detections] = []
         for raw in raws:
+            # the forward allocated these on ITS stream; they are consumed on this one: tell the caching allocator, or a
+            # later forward could be handed the blocks while kernels of this stream still read them
+            for t in (raw.packed, raw.bbox, raw.scores, raw.classes, raw.valid, raw.count, raw.boxes):
+                if t is not None:
+                    t.record_stream(cur)
             counts = raw.count.cpu().numpy()
             valid = raw.valid.cpu().numpy().astype(bool)
             scores = raw.scores.cpu().numpy()

@@ -222,7 +222,9 @@ int demia_roi_align(const demia_roialign_desc* d, void* stream);
  *   logits [N, R, ld] f32: channels 0..K = class logits, K+1 .. K+4K = deltas
  *   props  [N, R, 4] f32, prop_count [N] i32
  *   det_boxes [N, topk, 4] f32 (network-input coords), det_scores [N, topk] f32,
- *   det_classes [N, topk] i32, det_count [N] i32;  R*K <= 4096, topk <= 128           */
+ *   det_classes [N, topk] i32, det_count [N] i32;  topk <= 128; any number of classes K as long as
+ *   R * min(K, floor(1 / score_thresh)) <= 4096 (a softmax row has at most floor(1 / thresh) scores above thresh;
+ *   R = 1000: every K for thresholds above 0.2, K <= 4 below)                                            */
 typedef struct demia_dets_desc {
     const float* logits;
     int32_t ld;

@@ -64,6 +64,8 @@ def main(argv=None) -> int:
         system_logger.error("--dataset_name is required for --task inference")
         return 2
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    dist = None
     if world > 1:
         # one process per GPU (torchrun): tiles of each image are sharded over the ranks, rank 0 writes the outputs
         import torch
@@ -83,7 +85,16 @@ def main(argv=None) -> int:
     bucket = config.get("bucket")
     online = gcs_available() and bool(bucket)
     downloaded = False
-    if online and args.download:
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    # Host side effects (download, clean-up, upload, removing the inputs) belong to rank 0 alone; the other ranks wait at a
+    # barrier until the inputs are in place and again until rank 0 has written every output that is uploaded or removed.
+    if rank != 0:
+        pass
+    elif online and args.download:
         try:
             subprocess.run(["gsutil", "cp", f"gs://{bucket}/dataset_info.json", str(category_json)], check=True)
             inf_dir = local_root / "DATASET" / "INFERENCE"
@@ -97,27 +108,33 @@ def main(argv=None) -> int:
             raise
     else:
         system_logger.info("GCS disabled (no gsutil / DEEPEMIA_OFFLINE): using local dataset_info.json and DATASET/INFERENCE")
-    for pattern in ("*.png", "*.csv", "*.jpg"):     # reference main.py:462-468
-        for f in glob.glob(pattern):
-            try:
-                os.remove(f)
-            except OSError:
-                pass
+    if rank == 0:
+        for pattern in ("*.png", "*.csv", "*.jpg"):     # reference main.py:462-468
+            for f in glob.glob(pattern):
+                try:
+                    os.remove(f)
+                except OSError:
+                    pass
+    barrier()
     from deepemia_amd.functions.inference import run_inference
 
     t0 = time.perf_counter()
     run_inference(args.dataset_name, str(split_dir), visualize=args.visualize, threshold=args.threshold, draw_id=args.draw_id,
                   dataset_format=args.dataset_format, draw_scalebar=args.draw_scalebar)
     system_logger.info(f"Inference task finished in {time.perf_counter() - t0:.2f}s; results in {split_dir}")
-    if online and args.upload:
+    barrier()                                   # rank 0 has written the CSVs / overlays (it is the last to leave run_inference)
+    if rank == 0 and online and args.upload:
         try:
             stamp = time.strftime("%Y%m%d_%H%M%S")
             subprocess.run(["gsutil", "-m", "cp", str(split_dir / "*.csv"), f"gs://{bucket}/Archive/{stamp}_{args.dataset_name}/"],
                            check=False)
         except OSError as e:
             system_logger.warning(f"GCS upload skipped: {e}")
-    if downloaded:
+    if rank == 0 and downloaded:
         shutil.rmtree(local_root / "DATASET" / "INFERENCE", ignore_errors=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
     return 0
 
 

@@ -406,7 +406,7 @@ def test_p32_planes_roundtrip_and_weight_tiling():
     err = (back - x).abs()
     big = x.abs() >= amax * 2.0 ** -14                       # both planes normal: 22 significand bits
     assert float((err[big] / x.abs()[big]).max()) < 2.0 ** -21
-    assert float(err.max()) <= amax * 2.0 ** -38             # below that the LOW plane is denormal: absolute error, tiny
+    assert float(err[~big].max()) <= amax * 2.0 ** -38       # below that the LOW plane is denormal: absolute error, tiny
     v = t.view(3 * 5 * 7 * 2, 32)
     assert v.buf is t.buf and torch.equal(p32.to_f32(v).reshape(-1), back.reshape(3, 5, 7, 2, 32).reshape(-1))
     assert p32.plane_scale(0.0) == 1.0 and p32.plane_scale(1.0) == 2.0 ** 14 and p32.plane_scale(3.9) == 2.0 ** 13

@@ -302,6 +302,41 @@ def test_box_detections_on_oracle_inputs(env):
     assert float((db[0, :n].cpu() - d["det_boxes"]).abs().max()) < 2e-3
 
 
+def test_box_detections_many_classes_and_a_non_finite_row(env):
+    """demia_box_detections with K = 12 classes and 1000 proposals (12 000 (proposal, class) pairs; only those above
+    the score threshold take a sort slot) and one proposal whose deltas overflow: same survivors, order and classes as
+    the oracle's fast_rcnn_inference."""
+    import torch.nn.functional as F2
+
+    eng, R, dev = env["eng"], env["R"], env["dev"]
+    k, r, newh, neww = 12, 1000, 800, 800
+    g = torch.Generator().manual_seed(12)
+    cls_logits = torch.randn((r, k + 1), generator=g) * 2.5
+    deltas = torch.randn((r, 4 * k), generator=g) * 0.5
+    deltas[17, 6] = 4.0e38                        # exp overflow -> inf coordinate: Detectron2 drops the whole row
+    cx, cy = torch.rand(r, generator=g) * 700 + 50, torch.rand(r, generator=g) * 700 + 50
+    bw, bh = torch.rand(r, generator=g) * 120 + 8, torch.rand(r, generator=g) * 120 + 8
+    props = torch.stack([cx - bw / 2, cy - bh / 2, cx + bw / 2, cy + bh / 2], dim=1)
+    probs = F2.softmax(cls_logits, dim=-1)
+    pred = R.apply_deltas(deltas, props, (10.0, 10.0, 5.0, 5.0))
+    rb, rs, rc, _ = R.fast_rcnn_inference(pred, probs, (newh, neww), 0.3)
+    ld = 5 * k + 1 + 3
+    logits = torch.zeros((1, r, ld))
+    logits[0, :, :k + 1] = cls_logits
+    logits[0, :, k + 1:k + 1 + 4 * k] = deltas
+    saved_k, eng.K = eng.K, k
+    try:
+        db, ds, dc, dn = eng.detections(logits.to(dev), props[None].contiguous().to(dev), torch.tensor([r], dtype=torch.int32, device=dev),
+                                        newh, neww)
+    finally:
+        eng.K = saved_k
+    n = int(dn[0])
+    assert n == rb.shape[0] == 100
+    np.testing.assert_array_equal(dc[0, :n].cpu().numpy(), rc.numpy())
+    assert float((ds[0, :n].cpu() - rs).abs().max()) < 1e-6
+    assert float((db[0, :n].cpu() - rb).abs().max()) < 2e-3
+
+
 def test_paste_on_oracle_inputs(env):
     eng, d, ref = env["eng"], env["ref"]["dbg"], env["ref"]
     dev = env["dev"]
