@@ -121,8 +121,9 @@ def _compare(split, images, ref_rows, ref_masks, contrast=False):
     assert rle[0] == ["ImageId", "EncodedPixels"]
     assert len(rle) - 1 == sum(len(v) for v in ref_masks.values())
     # What is left must be explained pixel by pixel: the instance's own mask (decoded from the RLE file) against the
-    # oracle's masks of that image -- a threshold-tie pixel (mask IoU >= 0.999, or at most 2 pixels on a small mask)
-    # shifts a contour vertex and with it the 1e-4 columns.  Anything else is a parity failure.
+    # oracle's masks of that image.  A threshold-tie pixel of the pasted mask goes through fill / erosion / dilation with
+    # the 3x3 cross before it reaches the CSV, which can turn it into up to a cross-sized patch: mask IoU >= 0.999, or at
+    # most 8 pixels on a small mask.  Anything else is a parity failure.
     got_masks = {}
     for img_id, runs in rle[1:]:
         got_masks.setdefault(img_id, []).append(runs)
@@ -138,7 +139,7 @@ def _compare(split, images, ref_rows, ref_masks, contrast=False):
             if best is None or d < best[0]:
                 best = (d, int((mine | rm).sum()))
         d, union = best
-        assert d <= 2 or 1.0 - d / max(union, 1) >= 0.999, (uid, d, union)
+        assert d <= 8 or 1.0 - d / max(union, 1) >= 0.999, (uid, d, union)
     assert len(unresolved) <= max(2, len(by_id_r) // 50), (len(unresolved), len(by_id_r), unresolved[:5])
     assert (split / "class_color_legend.txt").exists()
     for name, img in images.items():                       # --visualize: one overlay per image, same size, not the input
