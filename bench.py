@@ -98,6 +98,8 @@ def main() -> None:
     ap.add_argument("--min-size-test", type=int, default=800, help="INPUT.MIN_SIZE_TEST; anything but 800 is the flagged NON-parity "
                     "native-resolution mode (not BASELINE.json's workload)")
     ap.add_argument("--max-size-test", type=int, default=1333)
+    ap.add_argument("--total-tiles", type=int, default=0, help="BASELINE configs[4]: a job of this many DISTINCT tiles per GPU (e.g. 256), "
+                    "walked in steps of --batch; overrides --steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="do not overlap batch i+1's network with batch i's post-processing")
     ap.add_argument("--forward-only", action="store_true", help="time predictor(tile) only, without the per-tile post-processing")
@@ -140,6 +142,21 @@ def main() -> None:
     pipe = InferencePipeline([Predictor(eng)], "bench", {}, {})
     tiles = np.stack([synth.em_tile(rank * args.batch + i, args.size) for i in range(args.batch)])
     x = torch.from_numpy(tiles).to(dev)
+    xs = [x]
+    if args.total_tiles:
+        # configs[4]: every step sees different tiles.  Generating 256 tiles takes minutes on the host, so steps 1.. are the
+        # eight dihedral images of the 16 base tiles, plain and intensity-inverted (distinct content, same statistics class)
+        assert args.total_tiles % args.batch == 0, "--total-tiles must be a multiple of --batch"
+        args.steps = args.total_tiles // args.batch
+        base = torch.from_numpy(tiles).to(dev)
+        xs = []
+        for k in range(args.steps):
+            t = base if (k // 8) % 2 == 0 else 255 - base
+            d = k % 8
+            t = torch.rot90(t, d % 4, dims=(1, 2))
+            if d >= 4:
+                t = torch.flip(t, dims=(2,))
+            xs.append(t.contiguous())
 
     def sync_all():
         torch.cuda.synchronize()
@@ -153,12 +170,12 @@ def main() -> None:
 
     def launch(i):
         with torch.cuda.stream(net_stream):
-            return pipe.forward_async(0, x)
+            return pipe.forward_async(0, xs[i % len(xs)] if i >= 0 else x)
 
     def step(i, handle=None):
         """One pass of the hot path over this rank's batch of tiles."""
         if args.forward_only:
-            raw = eng.forward(x)
+            raw = eng.forward(xs[i % len(xs)] if i >= 0 else x)
             return int(raw.count.sum().item()), 0
         with torch.cuda.stream(post_stream):
             return post(i, handle if handle is not None else launch(i))
@@ -168,7 +185,8 @@ def main() -> None:
     def post(i, handle):
         dets = pipe.finish_forward(handle)
         res = pipe.process_tile_batch(f"step{i}", x, SMALL_CLASSES, CLASS_THRESHOLDS, dets=dets)
-        last["res"] = res
+        if i >= 0 and i % len(xs) == 0 or not args.total_tiles:
+            last["res"] = res          # the step whose tile 0 is synthetic tile 0 (the parity check's reference)
         n_inst = sum(0 if r[0] is None else int(r[0].shape[0]) for r in res)
         n_rows = sum(len(c) for r in res for c in r[3])
         if dist is not None:
@@ -245,7 +263,8 @@ def main() -> None:
             "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": ("NON-PARITY native-resolution mode, not configs[1]: " if native else "configs[1]: ") +
+            "config": {"workload": ("NON-PARITY native-resolution mode, not configs[1]: " if native else
+                                    (f"configs[4] (a job of {args.total_tiles} distinct tiles per GPU, {args.steps} steps): " if args.total_tiles else "configs[1]: ")) +
                                    f"R{args.depth}-FPN, {args.size}x{args.size} synthetic EM tiles, "
                                    f"{args.batch} tiles per GPU per step; per tile: resize {args.min_size_test} -> backbone/FPN/RPN/ROI heads -> mask paste to "
                                    f"bit-packed {args.size}^2 masks" + ("" if args.forward_only else " -> class loop (fill holes, closing, overlap "
@@ -290,7 +309,7 @@ def main() -> None:
             line["parity"] = {k: par[k] for k in ("mask_iou_min", "csv_max_rel_err", "csv_max_rel_err_all", "score_max_abs_err", "instances",
                                                   "instances_ref", "masks_identical", "masks_with_tie_pixels", "tie_pixels_max", "csv_rows",
                                                   "ellipse_rows_skipped", "ok")}
-            line["parity"]["checked"] = ("tile 0 of the last timed step vs oracle/tile_parity.py; bar: every mask IoU >= 0.999, CSV within 1e-4 "
+            line["parity"]["checked"] = (("tile 0 of the first timed step vs" if args.total_tiles else "tile 0 of the last timed step vs") + " oracle/tile_parity.py; bar: every mask IoU >= 0.999, CSV within 1e-4 "
                                          "relative on the instances whose mask equals the reference's bit for bit, the others differ by <= 2 "
                                          "threshold-tie pixels (csv_max_rel_err_all includes them)")
             if "why" in par:

@@ -32,7 +32,8 @@
 // src/data/models.py:107).
 #include "common.h"
 #ifndef P32_ABLATE
-#define P32_ABLATE 0      // timing-only dev builds: 1 = no A DMA after the first two steps, 2 = no B DMA, 4 = no MFMAs, 16 = vmcnt wait dropped
+#define P32_ABLATE 0      // timing-only dev builds: 1 = no A DMA after the first two steps, 2 = no B DMA, 4 = no MFMAs,
+                          // 32 = no residual loads, 64 = no global stores in the epilogue, 128 = one K-step only
 #endif
 
 namespace {
@@ -142,6 +143,8 @@ __device__ __forceinline__ void p32_epilogue(const ConvQ& p, char* smem, WriteRo
         bs[q] = (p.bias && ok) ? p.bias[co + q] : 0.0f;
     }
     float vmax = 0.f;
+    const bool res_on = p.res_mode != DEMIA_RES_NONE, sigmoid_on = p.act == DEMIA_ACT_SIGMOID;
+    const float act_lo = p.act == DEMIA_ACT_RELU ? 0.f : -INFINITY;
     const char* resb = reinterpret_cast<const char*>(p.res) + 128;
     char* outb = reinterpret_cast<char*>(p.out) + 128;
     const long cbytes = (long)p.Cout * 4;                       // bytes per P32 pixel of the output / residual
@@ -164,7 +167,7 @@ __device__ __forceinline__ void p32_epilogue(const ConvQ& p, char* smem, WriteRo
 #pragma unroll
         for (int k = 0; k < ITEMS; ++k) {
             const int m = row_of(i, k);
-            if (has_res && m < p.M) {
+            if (has_res && m < p.M && !(P32_ABLATE & 32)) {
                 const char* rp = resb + res_pix(m) * cbytes + gofs;
                 rh[k] = *reinterpret_cast<const f16x8*>(rp);
                 rl[k] = *reinterpret_cast<const f16x8*>(rp + 64);
@@ -193,12 +196,19 @@ __device__ __forceinline__ void p32_epilogue(const ConvQ& p, char* smem, WriteRo
                 float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
 #pragma unroll
                 for (int q = 0; q < 8; ++q) v[q] = v[q] * sc[q] + bs[q];
-                if (p.res_mode != DEMIA_RES_NONE) {
+                if (res_on) {
 #pragma unroll
                     for (int q = 0; q < 8; ++q) v[q] += ((float)ch[k][q] + (float)cl[k][q]) * res_inv;
                 }
+                // ReLU as a max against 0 / -inf: no per-element branch (one wave-uniform branch per ITEM at most -- the
+                // per-element `switch (act)` this replaces cost three scalar branches and an inlined division per element
+                // and made the epilogue the longest part of every short-K layer)
 #pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = apply_act_q(v[q], p.act);
+                for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], act_lo);
+                if (sigmoid_on) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = 1.0f / (1.0f + expf(-v[q]));
+                }
                 if (p.out_f32) {
                     float* o = reinterpret_cast<float*>(p.out) + (long)m * p.out_ld + co;
                     if (co + 8 <= p.Cout && (p.out_ld & 3) == 0) {
@@ -219,8 +229,12 @@ __device__ __forceinline__ void p32_epilogue(const ConvQ& p, char* smem, WriteRo
                         l[q] = (_Float16)(y - (float)h[q]);
                     }
                     char* o = outb + (long)m * cbytes + gofs;
-                    *reinterpret_cast<f16x8*>(o) = h;
-                    *reinterpret_cast<f16x8*>(o + 64) = l;
+                    if (P32_ABLATE & 64) {
+                        asm volatile("" :: "v"(h), "v"(l), "v"(o));
+                    } else {
+                        *reinterpret_cast<f16x8*>(o) = h;
+                        *reinterpret_cast<f16x8*>(o + 64) = l;
+                    }
                 }
             }
         }
@@ -234,7 +248,7 @@ __device__ __forceinline__ void p32_epilogue(const ConvQ& p, char* smem, WriteRo
     }
 }
 
-template <int WM, int WN, int TM, int TN, bool M16 = false>
+template <int WM, int WN, int TM, int TN, bool M16 = true>
 __global__ __launch_bounds__(512, 2) void conv_p32_kernel(const ConvQ p) {
     static_assert(WM * WN == 8, "eight waves");
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -270,9 +284,9 @@ __global__ __launch_bounds__(512, 2) void conv_p32_kernel(const ConvQ p) {
         const long pix = ((long)n * p.H + hi0) * p.W + wi0;
         a_off[q] = (unsigned)(128 + pix * (long)(p.Cin * 4) + csw * 16);
         unsigned mk = 0;
-        for (int t = 0; t < p.taps; ++t) {
-            const int th = t / p.KW, tw = t - th * p.KW;
+        for (int t = 0, th = 0, tw = 0; t < p.taps; ++t) {
             if (vm && (unsigned)(hi0 + th) < (unsigned)p.H && (unsigned)(wi0 + tw) < (unsigned)p.W) mk |= 1u << t;
+            if (++tw == p.KW) { tw = 0; ++th; }
         }
         a_msk[q] = mk;
     }
@@ -322,8 +336,10 @@ __global__ __launch_bounds__(512, 2) void conv_p32_kernel(const ConvQ p) {
         fb[c] = BM * 128 + (wn * TN * 32 + (lane & 31)) * 128 + ch;
     }
 
-    // 32x32x16 MFMAs (two K sub-steps per stage) or, M16, 16x16x32 ones (one per stage; the chip holds a higher clock on
-    // that shape at equal cycles per FLOP -- MI355X_MICROARCH.md, DVFS give-back item 7); the unused set is dead code
+    // M16 (default): v_mfma_f32_16x16x32_f16, one K sub-step per stage -- the chip holds a higher clock on that shape at
+    // equal cycles per FLOP (MI355X_MICROARCH.md, DVFS give-back item 7): measured +6 % on the MFMA-bound layers (large 3x3
+    // 420 -> 446, FC 427 -> 455 TFLOP/s).  M16 = false: 32x32x16, two K sub-steps per stage, kept for A/B (tile hints 31, 34).
+    // The unused accumulator set is dead code.
     f32x16 acc[M16 ? 1 : TM][M16 ? 1 : TN];
     f32x4 acc16[M16 ? 2 * TM : 1][M16 ? 2 * TN : 1];
 #pragma unroll
@@ -404,7 +420,7 @@ __global__ __launch_bounds__(512, 2) void conv_p32_kernel(const ConvQ p) {
     P32_ADVANCE();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    for (int t = 0; t < p.ksteps; ++t) {
+    for (int t = 0; t < ((P32_ABLATE & 128) ? 1 : p.ksteps); ++t) {
         const int st = t & 1;
         if (t + 1 < p.ksteps) {                   // that stage was last read before the previous barrier
             issue(st ^ 1, tap, sdelta, (unsigned)tstep * 8192u);
@@ -480,9 +496,9 @@ __global__ __launch_bounds__(512, 2) void conv_p32_pp_kernel(const ConvQ p) {
         const long pix = ((long)n * p.H + hi0) * p.W + wi0;
         a_off[q] = (unsigned)(128 + pix * (long)(p.Cin * 4) + csw * 16);
         unsigned mk = 0;
-        for (int t = 0; t < p.taps; ++t) {
-            const int th = t / p.KW, tw = t - th * p.KW;
+        for (int t = 0, th = 0, tw = 0; t < p.taps; ++t) {
             if (vm && (unsigned)(hi0 + th) < (unsigned)p.H && (unsigned)(wi0 + tw) < (unsigned)p.W) mk |= 1u << t;
+            if (++tw == p.KW) { tw = 0; ++th; }
         }
         a_msk[q] = mk;
     }
@@ -641,7 +657,7 @@ int launch_pp(ConvQ p, hipStream_t st) {
     return DEMIA_OK;
 }
 
-template <int WM, int WN, int TM, int TN, bool M16 = false>
+template <int WM, int WN, int TM, int TN, bool M16 = true>
 int launch_q(ConvQ p, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int stages = 2 * (BM + BN) * 128, image = WM * 32 * (BN * 4 + 16);
@@ -739,8 +755,8 @@ extern "C" int demia_conv2d_p32(const demia_conv_p32_desc* d, void* stream) {
         case 9: return launch_q<8, 1, 1, 2>(p, st);                                                           // 256 x 64
         case 10: return launch_q<4, 2, 2, 1>(p, st);                                                          // 256 x 64, two waves along N
         case 11: return launch_q<4, 2, 1, 1>(p, st);                                                          // 128 x 64
-        case 31: DEMIA_REQUIRE(n256, "tile needs CoutPad % 256 == 0"); return launch_q<2, 4, 4, 2, true>(p, st);   // 256 x 256, 16x16x32 MFMAs
-        case 34: DEMIA_REQUIRE(n256, "tile needs CoutPad % 256 == 0"); return launch_q<1, 8, 6, 1, true>(p, st);   // 192 x 256, 16x16x32 MFMAs
+        case 31: DEMIA_REQUIRE(n256, "tile needs CoutPad % 256 == 0"); return launch_q<2, 4, 4, 2, false>(p, st);  // 256 x 256, 32x32x16 MFMAs (A/B)
+        case 34: DEMIA_REQUIRE(n256, "tile needs CoutPad % 256 == 0"); return launch_q<1, 8, 6, 1, false>(p, st);  // 192 x 256, 32x32x16 MFMAs (A/B)
         case 21: DEMIA_REQUIRE(n256, "tile needs CoutPad % 256 == 0"); return launch_pp<4, 2>(p, st);        // 256 x 256, ping-pong
         case 22: DEMIA_REQUIRE(n256, "tile needs CoutPad % 256 == 0"); return launch_pp<2, 2>(p, st);        // 128 x 256, ping-pong
         case 26: DEMIA_REQUIRE(n128, "tile needs CoutPad % 128 == 0"); return launch_pp<4, 1>(p, st);        // 256 x 128, ping-pong

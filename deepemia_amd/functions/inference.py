@@ -356,10 +356,13 @@ class InferencePipeline:
         return tiles, offs
 
     # ------------------------------------------------------------------ a13 + the tile pipeline
-    def tile_based_inference_pipeline(self, model_ids: Sequence[int], image_key: str, image_dev: torch.Tensor, target_class,
-                                      small_classes, confidence_threshold, tile_size=512, overlap_ratio=0.1, upscale_factor=2.0,
-                                      iou_threshold=0.7, edge_filter_enabled=True):
-        """``inference.py:2299-2485`` for one class."""
+    def _tile_pipeline_local(self, model_ids: Sequence[int], image_key: str, image_dev: torch.Tensor, target_class,
+                             small_classes, confidence_threshold, tile_size=512, overlap_ratio=0.1, upscale_factor=2.0,
+                             iou_threshold=0.7, edge_filter_enabled=True):
+        """``inference.py:2299-2460`` for one class, THIS RANK'S share: the full-image pass (rank 0) and the tiles
+        ``t % world == rank``, each through the class pass, the nearest resize back to tile scale, the edge filter and the
+        paste into the global frame.  Returns ``(full_masks, full_scores, full_classes, tile_masks, tile_scores,
+        tile_classes, tile_units)`` -- no communication here."""
         h, w = int(image_dev.shape[0]), int(image_dev.shape[1])
         self.ops.set_frame_width(w)
         ensemble = len(model_ids) > 1
@@ -422,47 +425,85 @@ class InferencePipeline:
                     tile_classes.extend([target_class] * len(keep))
                     tile_units.extend(un[i] for i in keep)
             self.ops.set_frame_width(w)
-        if world > 1:
-            # the ONE exchange of the path: every rank receives every rank's instance table, ordered by unit id
-            empty_full = isinstance(full_masks, str)
-            parts = ([full_masks] if (full_masks is not None and not empty_full and full_masks.shape[0]) else []) + tile_masks
-            sc = ([] if (full_masks is None or empty_full) else list(full_scores)) + list(tile_scores)
-            cl = ([] if (full_masks is None or empty_full) else list(full_classes)) + list(tile_classes)
-            un = [0] * (len(sc) - len(tile_scores)) + tile_units
-            local = torch.cat(parts, dim=0) if parts else None
-            if local is not None:
-                a, b = self.ops.area_bbox(local)
-                hdr, pay = parallel.encode_instance_table(local, sc, cl, un, b.cpu().numpy(), a.cpu().numpy())
-            else:
-                hdr = torch.zeros((0, parallel.HDR), dtype=torch.int32, device=self.dev)
-                pay = torch.zeros((0,), dtype=torch.int32, device=self.dev)
-            if rank == 0 and empty_full:   # N4 marker travels too: unit -1 row, no payload
-                mark = torch.zeros((1, parallel.HDR), dtype=torch.int32, device=self.dev)
-                mark[0, 0] = -1
-                mark[0, 4:8] = -1
-                hdr = torch.cat([mark, hdr], dim=0)
-            gh, gp = parallel.all_gather_instance_tables(hdr, pay)
-            packed_all, s_all, c_all, u_all = parallel.decode_instance_table(gh, gp, h, w, self.dev)
-            has_marker = bool(u_all) and u_all[0] == -1
-            if has_marker:
-                packed_all, s_all, c_all, u_all = packed_all[1:], s_all[1:], c_all[1:], u_all[1:]
-                if len(s_all):
-                    raise EmptyEnsembleTypeError("operands could not be broadcast together (empty ensemble result + tile masks)")
-                return None, [], []
-            if not ensemble:
-                s_all = [np.float32(v) for v in s_all]      # single-model scores are the predictor's float32 values
-            if len(s_all) == 0:
-                return None, [], []
-            return self.deduplicate_masks_smart(packed_all, s_all, c_all, 0.4)
+        return full_masks, full_scores, full_classes, tile_masks, tile_scores, tile_classes, tile_units
+
+    def _merge_full_and_tiles(self, full_masks, full_scores, full_classes, tile_masks, tile_scores, tile_classes):
+        """``inference.py:2452-2472``: full-image results + tile results -> ``deduplicate_masks_smart`` at 0.4 (N4 included)."""
         if isinstance(full_masks, str):        # N4: ndarray + list
             if tile_masks:
                 raise EmptyEnsembleTypeError("operands could not be broadcast together (empty ensemble result + tile masks)")
             return None, [], []
-        parts = ([full_masks] if full_masks is not None and full_masks.shape[0] else []) + tile_masks
+        parts = ([full_masks] if full_masks is not None and full_masks.shape[0] else []) + list(tile_masks)
         if not parts:
             return None, [], []
         packed = torch.cat(parts, dim=0)
         return self.deduplicate_masks_smart(packed, list(full_scores) + list(tile_scores), list(full_classes) + list(tile_classes), 0.4)
+
+    def gather_and_merge(self, locals_by_class: Dict[int, tuple], hw: Tuple[int, int], ensemble_by_class: Dict[int, bool]):
+        """The ONE exchange of the multi-GPU path, once per IMAGE: every rank contributes the class-tagged instance tables
+        of all its local class passes (full-image pass on rank 0, its tiles), every rank receives the global table ordered
+        by (unit id, local order) and runs the per-class 0.4 merges on it -- deterministic and identical everywhere.
+        Rows of one class keep the reference's order (full image first, tiles in row-major order, detector order inside),
+        because each rank appends its classes in the same order and the merge is stable.  Returns {class: (masks, scores,
+        classes)}; a class whose merge would raise in the reference (N4) maps to an ``EmptyEnsembleTypeError`` instance."""
+        h, w = hw
+        hdrs, pays = [], []
+        for cls, (fm, fs, fc, tm, ts, tc, tu) in locals_by_class.items():
+            empty_full = isinstance(fm, str)
+            parts = ([fm] if (fm is not None and not empty_full and fm.shape[0]) else []) + list(tm)
+            sc = ([] if (fm is None or empty_full) else list(fs)) + list(ts)
+            cl = [cls] * len(sc)
+            un = [0] * (len(sc) - len(ts)) + list(tu)
+            if self.rank == 0 and empty_full:   # N4 marker travels too: unit -1 row of this class, no payload
+                mark = torch.zeros((1, parallel.HDR), dtype=torch.int32, device=self.dev)
+                mark[0, 0] = -1
+                mark[0, 1] = cls
+                mark[0, 4:8] = -1
+                hdrs.append(mark)
+            if parts:
+                local = torch.cat(parts, dim=0)
+                a, b = self.ops.area_bbox(local)
+                hdr, pay = parallel.encode_instance_table(local, sc, cl, un, b.cpu().numpy(), a.cpu().numpy())
+                hdrs.append(hdr)
+                pays.append(pay)
+        hdr = torch.cat(hdrs, dim=0) if hdrs else torch.zeros((0, parallel.HDR), dtype=torch.int32, device=self.dev)
+        pay = torch.cat(pays, dim=0) if pays else torch.zeros((0,), dtype=torch.int32, device=self.dev)
+        gh, gp = parallel.all_gather_instance_tables(hdr, pay)
+        packed_all, s_all, c_all, u_all = parallel.decode_instance_table(gh, gp, h, w, self.dev)
+        out = {}
+        c_arr, u_arr = np.asarray(c_all, dtype=np.int64), np.asarray(u_all, dtype=np.int64)
+        for cls in locals_by_class:
+            rows = np.nonzero(c_arr == cls)[0]
+            marker = rows[u_arr[rows] == -1]
+            rows = rows[u_arr[rows] != -1]
+            if len(marker):
+                out[cls] = (EmptyEnsembleTypeError("operands could not be broadcast together (empty ensemble result + tile masks)")
+                            if len(rows) else (None, [], []))
+                continue
+            if len(rows) == 0:
+                out[cls] = (None, [], [])
+                continue
+            sel = torch.from_numpy(rows).to(self.dev)
+            sc = [s_all[i] for i in rows]
+            if not ensemble_by_class.get(cls, False):
+                sc = [np.float32(v) for v in sc]      # single-model scores are the predictor's float32 values
+            out[cls] = self.deduplicate_masks_smart(packed_all[sel].contiguous(), sc, [cls] * len(rows), 0.4)
+        return out
+
+    def tile_based_inference_pipeline(self, model_ids: Sequence[int], image_key: str, image_dev: torch.Tensor, target_class,
+                                      small_classes, confidence_threshold, tile_size=512, overlap_ratio=0.1, upscale_factor=2.0,
+                                      iou_threshold=0.7, edge_filter_enabled=True):
+        """``inference.py:2299-2485`` for one class (with more than one rank: one exchange for this class; ``run_inference``
+        batches the exchange over the classes of an image instead)."""
+        loc = self._tile_pipeline_local(model_ids, image_key, image_dev, target_class, small_classes, confidence_threshold,
+                                        tile_size, overlap_ratio, upscale_factor, iou_threshold, edge_filter_enabled)
+        if self.world > 1:
+            res = self.gather_and_merge({target_class: loc}, (int(image_dev.shape[0]), int(image_dev.shape[1])),
+                                        {target_class: len(model_ids) > 1})[target_class]
+            if isinstance(res, Exception):
+                raise res
+            return res
+        return self._merge_full_and_tiles(*loc[:6])
 
     # ------------------------------------------------------------------ batch of independent tiles (configs[1] / [4])
     def process_tile_batch_unbatched(self, key: str, tiles: torch.Tensor, small_classes, class_thresholds: Dict[int, Tuple[float, float]],
@@ -944,6 +985,7 @@ def run_inference(dataset_name, output_dir, visualize=True, threshold=0.65, draw
         try:
             image_host = None
             parts, all_scores, all_classes = [], [], []
+            locals_by_class, ens_by_class = {}, {}
             targets = range(num_classes) if classes_to_infer is None else [c for c in classes_to_infer if c < num_classes]
             for target_class in targets:
                 is_small = target_class in small_classes
@@ -957,6 +999,13 @@ def run_inference(dataset_name, output_dir, visualize=True, threshold=0.65, draw
                 iou_thresh = ccfg.get("iou_threshold", 0.5 if is_small else 0.7)
                 use_ens = ensemble_enabled and (not ensemble_small_only or is_small)
                 model_ids = list(range(len(predictors))) if (use_ens and len(predictors) > 1) else [0]
+                if pipe.world > 1:
+                    # local passes only; ONE all-gather per image after the class loop
+                    locals_by_class[target_class] = pipe._tile_pipeline_local(model_ids, name, image_dev, target_class, small_classes, conf,
+                                                                              tile_size, overlap_ratio, upscale_factor, iou_thresh,
+                                                                              edge_filter_enabled)
+                    ens_by_class[target_class] = len(model_ids) > 1
+                    continue
                 m, s, c = pipe.tile_based_inference_pipeline(model_ids, name, image_dev, target_class, small_classes, conf,
                                                              tile_size, overlap_ratio, upscale_factor, iou_thresh,
                                                              edge_filter_enabled)
@@ -964,6 +1013,17 @@ def run_inference(dataset_name, output_dir, visualize=True, threshold=0.65, draw
                     parts.append(m)
                     all_scores.extend(s)
                     all_classes.extend(c)
+            if pipe.world > 1:
+                merged = pipe.gather_and_merge(locals_by_class, (int(image_dev.shape[0]), int(image_dev.shape[1])), ens_by_class)
+                for target_class in targets:
+                    r = merged[target_class]
+                    if isinstance(r, Exception):
+                        raise r               # the reference raises inside the class loop and skips the image (N4)
+                    m, s, c = r
+                    if m is not None and m.shape[0]:
+                        parts.append(m)
+                        all_scores.extend(s)
+                        all_classes.extend(c)
             packed = torch.cat(parts, dim=0) if parts else None
             packed, scores, classes = pipe.deduplicate_masks_smart(packed, all_scores, all_classes, iou_threshold=0.7)
             if packed is not None and packed.shape[0]:

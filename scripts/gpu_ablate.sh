@@ -1,8 +1,8 @@
 #!/bin/bash
 # Dev helper (GPU): time the key conv layers with the shipped library and with every timing-only variant under build/ab/
-hint=${1:-1}
-python scripts/gpu_conv_p32_check.py key $hint
+# usage: gpu_ablate.sh "<hints>" <mfma|hbm>
+hints=${1:-1}; which=${2:-mfma}
+for h in $hints; do python scripts/gpu_conv_p32_check.py key $h $which; done
 for lib in build/ab/*.so; do
-    AB_LIB=$lib python scripts/gpu_conv_p32_check.py key $hint
+    for h in $hints; do AB_LIB=$lib python scripts/gpu_conv_p32_check.py key $h $which; done
 done
-python scripts/gpu_conv_p32_check.py key $hint

@@ -100,9 +100,10 @@ def check():
         (4, 14, 14, 256, 256, 3, 1, 1, ACT_RELU, RES_NONE, False, 0),
         (1, 20, 784, 256, 2, 1, 1, 0, ACT_SIGMOID, RES_NONE, True, 0),
         (1, 200, 200, 64, 256, 1, 1, 0, ACT_NONE, RES_NONE, False, 0),
-    ] + [(2, 41, 37, 128, 256, 3, 1, 1, ACT_RELU, RES_SAME, False, hh) for hh in list(range(1, 12)) + [21, 22, 26]] + \
+    ] + [(2, 41, 37, 128, 256, 3, 1, 1, ACT_RELU, RES_SAME, False, hh) for hh in list(range(1, 12)) + [21, 22, 26, 31, 34]] + \
         [(3, 50, 50, 256, 256, 3, 1, 1, ACT_RELU, RES_NONE, False, 21), (2, 25, 25, 64, 512, 1, 1, 0, ACT_NONE, RES_SAME, False, 21),
-         (1, 1, 1000, 12544, 1024, 1, 1, 0, ACT_RELU, RES_NONE, False, 21), (5, 40, 40, 256, 128, 1, 2, 0, ACT_RELU, RES_NONE, False, 26)]
+         (1, 1, 1000, 12544, 1024, 1, 1, 0, ACT_RELU, RES_NONE, False, 21), (3, 50, 50, 256, 256, 3, 1, 1, ACT_RELU, RES_NONE, False, 31),
+         (2, 25, 25, 64, 512, 1, 1, 0, ACT_NONE, RES_UP2, False, 34), (1, 1, 700, 1024, 1024, 1, 1, 0, ACT_RELU, RES_SAME, False, 31), (5, 40, 40, 256, 128, 1, 2, 0, ACT_RELU, RES_NONE, False, 26)]
     worst = 0.0
     for ci, (n, h, w, cin, cout, k, s, pd, act, rm, of32, hint) in enumerate(cases):
         g = torch.Generator().manual_seed(100 + ci)
@@ -139,7 +140,7 @@ def check():
     print(f'check ok, worst {worst:.2e}')
 
 
-HINTS = {21: '256x256pp', 22: '128x256pp', 26: '256x128pp', 1: '256x256', 2: '128x256', 3: '256x256n', 4: '192x256n', 5: '128x256n', 6: '256x128', 7: '128x128', 8: '128x128n',
+HINTS = {31: '256x256m32', 34: '192x256m32', 21: '256x256pp', 22: '128x256pp', 26: '256x128pp', 1: '256x256', 2: '128x256', 3: '256x256n', 4: '192x256n', 5: '128x256n', 6: '256x128', 7: '128x128', 8: '128x128n',
          9: '256x64', 10: '256x64b', 11: '128x64'}
 
 R101_B16 = [
@@ -193,7 +194,7 @@ def time_layers(sweep=True, old=True):
         fl = 2.0 * n * ho * wo * cout * cin * k * k
         hints = [0]
         if sweep:
-            hints += [hh for hh in HINTS if ((hh <= 5 or hh in (21, 22)) and L.cout_pad % 256 == 0) or ((6 <= hh <= 8 or hh == 26) and L.cout_pad % 128 == 0) or 9 <= hh <= 11]
+            hints += [hh for hh in HINTS if ((hh <= 5 or hh in (21, 22, 31, 34)) and L.cout_pad % 256 == 0) or ((6 <= hh <= 8 or hh == 26) and L.cout_pad % 128 == 0) or 9 <= hh <= 11]
         tt = {}
         for hint in hints:
             tt[hint] = timeit(lambda: conv_p32(xp, L, s, pd, ACT_RELU, res, rm, of32, 16 if of32 else 0, hint))
@@ -215,22 +216,27 @@ def time_layers(sweep=True, old=True):
           f'old (layers it ran) {tot_old:.2f} ms')
 
 
-def key_layers(hint=1):
+def key_layers(hint=1, which='mfma'):
     """A few layers at one tile config: the A/B probe for kernel variants (AB_LIB=... selects the library)."""
     out = []
-    for (n, h, w), cin, cout, k in [((16, 200, 200), 256, 256, 3), ((16, 50, 50), 256, 256, 3), ((1, 1, 16000), 12544, 1024, 1),
-                                    ((16, 50, 50), 1024, 256, 1)]:
+    layers = {'mfma': [((16, 200, 200), 256, 256, 3, 0), ((16, 50, 50), 256, 256, 3, 0), ((1, 1, 16000), 12544, 1024, 1, 0),
+                       ((16, 50, 50), 1024, 256, 1, 0)],
+              'hbm': [((16, 50, 50), 256, 1024, 1, 1), ((16, 200, 200), 64, 256, 1, 1), ((16, 200, 200), 256, 256, 1, 1),
+                      ((16, 100, 100), 128, 512, 1, 1)]}[which]
+    for (n, h, w), cin, cout, k, rs in layers:
         L = Layer(cout, cin, k, k, seed=1)
         xp = p32.from_f32(torch.randn(n, h, w, cin, device=dev))
+        res = p32.from_f32(torch.randn(n, h, w, cout, device=dev)) if rs else None
         fl = 2.0 * n * h * w * cout * cin * k * k
-        t = min(timeit(lambda: conv_p32(xp, L, 1, k // 2, ACT_RELU, hint=hint), reps=8) for _ in range(3))
-        out.append(f'M={n*h*w} K={cin*k*k} N={cout}: {t*1e3:.1f} us {fl/t/1e9:.1f} TF/s')
+        gb = (n * h * w * (cin + cout * (2 if rs else 1)) * 4 + cout * cin * k * k * 4) / 1e9
+        t = min(timeit(lambda: conv_p32(xp, L, 1, k // 2, ACT_RELU, res, RES_SAME if rs else RES_NONE, hint=hint), reps=8) for _ in range(3))
+        out.append(f'M={n*h*w} K={cin*k*k} N={cout}: {t*1e3:.1f} us {fl/t/1e9:.1f} TF/s {gb/t:.2f} TB/s')
     print(os.environ.get('AB_LIB', 'default'), f'hint {hint} |', ' | '.join(out), flush=True)
 
 
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'key':
-        key_layers(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+        key_layers(int(sys.argv[2]) if len(sys.argv) > 2 else 1, sys.argv[3] if len(sys.argv) > 3 else 'mfma')
         sys.exit(0)
     mode = sys.argv[1] if len(sys.argv) > 1 else 'all'
     if mode in ('check', 'all'):
