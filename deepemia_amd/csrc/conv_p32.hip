@@ -53,6 +53,8 @@ struct ConvQ {
     int act, res_mode, out_f32, out_ld;
     int M, HoWo, ntn, nwg, ksteps, taps;
     unsigned in_bytes, w_bytes;
+    int stagger_ticks;      // > 0: the second half of the first resident set of workgroups starts this many 10-ns ticks late
+    int resident;           // workgroups resident at once (256 CUs x workgroups per CU) -- for the stagger
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -262,20 +264,32 @@ __global__ __launch_bounds__(512, 2) void conv_p32_kernel(const ConvQ p) {
     const int swz = xcd_remap(blockIdx.x, p.nwg);
     const int tile_n = swz % p.ntn, tile_m = swz / p.ntn;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+    if (p.stagger_ticks > 0) {
+        // Short-K layers alternate a K loop that barely touches HBM with an epilogue that saturates it, and every CU starts
+        // in the same phase: delaying half of the first resident set by about half a tile period puts one half of the
+        // chip in its epilogue while the other half is in its K loop (the later workgroups inherit the offset).
+        const int b = blockIdx.x;
+        const bool late = p.resident > 256 ? (b >= p.resident / 2 && b < p.resident) : (b < p.resident && ((b >> 3) & 1));
+        if (late) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)p.stagger_ticks) __builtin_amdgcn_s_sleep(32);
+        }
+    }
 
     const i32x4 rsrc_a = make_rsrc(p.in, p.in_bytes), rsrc_b = make_rsrc(p.w, p.w_bytes);
     const unsigned lds0 = (unsigned)(__SIZE_TYPE__)((lds_void*)smem);
 
     // ---- DMA bookkeeping: wave w moves pieces w, w + 8, ... (8 rows = 1 KiB each) of the A tile and of the B tile ----
-    constexpr int QA = NIA / 8, QB = NIB / 8;
-    static_assert(NIA % 8 == 0 && NIB % 8 == 0, "tile sides are multiples of 64");
+    constexpr int QA = (NIA + 7) / 8, QB = NIB / 8;
+    constexpr bool A_EVEN = NIA % 8 == 0;       // else the last round of A pieces is issued by the first NIA % 8 waves only
+    static_assert(NIB % 8 == 0, "tile width is a multiple of 64");
     unsigned a_off[QA], a_msk[QA], b_off[QB];
 #pragma unroll
     for (int q = 0; q < QA; ++q) {
         const int row = (wave + 8 * q) * 8 + (lane >> 3);
         const int csw = (lane & 7) ^ ((row >> 1) & 7);
         const int m = m0 + row;
-        const bool vm = m < p.M;
+        const bool vm = m < p.M && row < BM;
         const int mm = vm ? m : 0;
         const int n = mm / p.HoWo;
         const int rem = mm - n * p.HoWo;
@@ -306,6 +320,7 @@ __global__ __launch_bounds__(512, 2) void conv_p32_kernel(const ConvQ p) {
 #pragma unroll
         for (int q = 0; q < QA; ++q) {
             if ((P32_ABLATE & 1) && !first) break;
+            if (!A_EVEN && q == QA - 1 && wave + 8 * q >= NIA) break;
             const bool ok = (a_msk[q] >> tp) & 1u;
             const unsigned vo = ok ? a_off[q] + sd : (a_off[q] & 0x70u);     // padding taps / rows beyond M: the zero header
             dma16(rsrc_a, sbase + q * 8192, vo, 0u);
@@ -664,6 +679,7 @@ int launch_q(ConvQ p, hipStream_t st) {
     constexpr int smem = stages > image ? stages : image;
     p.ntn = p.CoutPad / BN;
     p.nwg = p.ntn * cdiv(p.M, BM);
+    p.resident = 256 * (160 * 1024 / smem >= 2 ? 2 : 1);
     auto k = conv_p32_kernel<WM, WN, TM, TN, M16>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -677,22 +693,22 @@ int launch_q(ConvQ p, hipStream_t st) {
 
 // Tile choice: predicted launch time of every instantiated tile, from a four-parameter model fitted to a sweep of the
 // R101 layer shapes on one MI355X (scripts/gpu_conv_p32_check.py, profiles/r02_conv_p32_tile_sweep.txt): a K-step costs
-// 2.3 us x (tile area / 256^2) x (1 + 0.3 x (1 - area)) on a CU of its own, prologue + epilogue 6 + 14 x area us (twice
-// that with a residual); a launch takes as many rounds as the busiest CU gets tiles; tiles whose two stages fit twice
-// into the LDS run two workgroups per CU, which hides 40 % of the prologue / epilogue.  The model picks within 2 % of
-// the best measured configuration over the whole network.
+// 2.0 us x (tile area / 256^2) x (1 + 0.2 x (1 - area)) on a CU of its own, prologue + epilogue 6 + 6 x area us (x 1.5
+// with a residual); a launch takes as many rounds as the busiest CU gets tiles; tiles whose two stages fit twice into
+// the LDS run two workgroups per CU, which hides half of the prologue / epilogue.  The model picks within 1 % of the
+// best measured configuration over the whole network (it ranks tiles; it is not a time estimate for the HBM-bound layers).
 struct TileCfg { int id, bm, bn; };
-constexpr TileCfg kTiles[] = {{1, 256, 256}, {2, 128, 256}, {4, 192, 256}, {6, 256, 128}, {7, 128, 128}, {9, 256, 64}, {11, 128, 64}};
+constexpr TileCfg kTiles[] = {{1, 256, 256}, {2, 128, 256}, {4, 192, 256}, {12, 160, 256}, {13, 224, 256}, {6, 256, 128}, {7, 128, 128}, {9, 256, 64}, {11, 128, 64}};
 
 inline double predict_us(const TileCfg& c, long M, int cout_pad, int ksteps, bool residual) {
     const long tiles = (long)cdiv(M, c.bm) * (cout_pad / c.bn);
     const int smem = 2 * (c.bm + c.bn) * 128;
     const int occ = 160 * 1024 / smem >= 2 ? 2 : 1;
     const double area = (double)c.bm * c.bn / 65536.0;
-    const double step = 2.3 * area * (1.0 + 0.3 * (1.0 - area));
-    const double edge = 6.0 + 14.0 * area * (residual ? 2.0 : 1.0);
+    const double step = 2.0 * area * (1.0 + 0.2 * (1.0 - area));
+    const double edge = 6.0 + 6.0 * area * (residual ? 1.5 : 1.0);
     if (occ == 1) return (double)((tiles + 255) / 256) * (ksteps * step + edge);
-    return (double)((tiles + 511) / 512) * (2.0 * ksteps * step + 2.0 * 0.6 * edge);
+    return (double)((tiles + 511) / 512) * (2.0 * ksteps * step + 2.0 * 0.5 * edge);
 }
 
 inline int choose_tile(long M, int cout_pad, int ksteps, bool residual) {
@@ -738,6 +754,11 @@ extern "C" int demia_conv2d_p32(const demia_conv_p32_desc* d, void* stream) {
     p.ksteps = p.taps * (d->Cin / 32);
     p.in_bytes = (unsigned)in_bytes; p.w_bytes = (unsigned)w_bytes;
     p.ntn = p.nwg = 0;
+    p.resident = 256;
+    {
+        static const char* env = getenv("DEMIA_P32_STAGGER_US");      // experiment switch (microseconds)
+        p.stagger_ticks = env ? atoi(env) * 100 : 0;
+    }
     if (p.M == 0) return DEMIA_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     // tile_hint: 0 = auto (the model above), else one of the instantiated tiles (dev / tuning: scripts/gpu_conv_p32_check.py)
@@ -755,6 +776,8 @@ extern "C" int demia_conv2d_p32(const demia_conv_p32_desc* d, void* stream) {
         case 9: return launch_q<8, 1, 1, 2>(p, st);                                                           // 256 x 64
         case 10: return launch_q<4, 2, 2, 1>(p, st);                                                          // 256 x 64, two waves along N
         case 11: return launch_q<4, 2, 1, 1>(p, st);                                                          // 128 x 64
+        case 12: DEMIA_REQUIRE(n256, "tile needs CoutPad % 256 == 0"); return launch_q<1, 8, 5, 1>(p, st);   // 160 x 256
+        case 13: DEMIA_REQUIRE(n256, "tile needs CoutPad % 256 == 0"); return launch_q<1, 8, 7, 1>(p, st);   // 224 x 256
         case 31: DEMIA_REQUIRE(n256, "tile needs CoutPad % 256 == 0"); return launch_q<2, 4, 4, 2, false>(p, st);  // 256 x 256, 32x32x16 MFMAs (A/B)
         case 34: DEMIA_REQUIRE(n256, "tile needs CoutPad % 256 == 0"); return launch_q<1, 8, 6, 1, false>(p, st);  // 192 x 256, 32x32x16 MFMAs (A/B)
         case 21: DEMIA_REQUIRE(n256, "tile needs CoutPad % 256 == 0"); return launch_pp<4, 2>(p, st);        // 256 x 256, ping-pong

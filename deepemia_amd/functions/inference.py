@@ -187,6 +187,7 @@ class InferencePipeline:
         # images per batched forward: l4_performance_optimizations.forward_batch_size / DEEPEMIA_FORWARD_BATCH (default 16:
         # fills 256 CUs on the 50^2 feature maps, 8.6 GiB of activations per 2048^2-tile batch)
         self.forward_batch = max(1, int(os.environ.get("DEEPEMIA_FORWARD_BATCH", l4.get("forward_batch_size", 16))))
+        self.use_graphs = os.environ.get("DEEPEMIA_GRAPHS", "0") == "1"
         self.last_batch_stats = None
         self.forward_calls = 0
         import torch.distributed as dist
@@ -202,7 +203,10 @@ class InferencePipeline:
         raws = []
         step = self.forward_batch
         for b0 in range(0, images.shape[0], step):
-            raws.append(pred.engine.forward(images[b0:b0 + step].contiguous()))
+            chunk = images[b0:b0 + step].contiguous()
+            # hipGraph replay (two alternating output sets per shape: the previous batch may still be read by the
+            # post-processing stream) where the caller asked for it; eager otherwise
+            raws.append(pred.engine.forward_graphed(chunk) if self.use_graphs else pred.engine.forward(chunk))
             self.forward_calls += 1
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.dev))
