@@ -50,6 +50,8 @@ class ConvP32Desc(C.Structure):
         ("Ho", C.c_int32), ("Wo", C.c_int32), ("Cout", C.c_int32), ("CoutPad", C.c_int32),
         ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
         ("act", C.c_int32), ("res_mode", C.c_int32), ("out_f32", C.c_int32), ("out_ld", C.c_int32), ("tile_hint", C.c_int32),
+        ("head_w", C.c_void_p), ("head_b", C.c_void_p), ("head_out", C.c_void_p),
+        ("head_n", C.c_int32), ("head_ld", C.c_int32), ("head_act", C.c_int32),
     ]
 
 

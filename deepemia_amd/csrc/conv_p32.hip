@@ -53,6 +53,10 @@ struct ConvQ {
     int act, res_mode, out_f32, out_ld;
     int M, HoWo, ntn, nwg, ksteps, taps;
     unsigned in_bytes, w_bytes;
+    const float* head_w;    // fused 1x1 head (head_n > 0): [head_n][256] f32 weights applied to every 256-channel block of the
+    const float* head_b;    // activated output row, + bias, sigmoid -> head_out[(m * ntn + tile_n) * head_ld + j]; the P32
+    float* head_out;        // output itself is then not written
+    int head_n, head_ld, head_act;
     int stagger_ticks;      // > 0: the second half of the first resident set of workgroups starts this many 10-ns ticks late
     int resident;           // workgroups resident at once (256 CUs x workgroups per CU) -- for the stagger
 };
@@ -130,7 +134,8 @@ __device__ __forceinline__ void p32_epilogue(const ConvQ& p, char* smem, WriteRo
     const float post = 1.0f / s_in;
     float s_out = 1.f, res_inv = 0.f;
     if (p.res_mode != DEMIA_RES_NONE) res_inv = 1.0f / p.res_meta[1];
-    if (!p.out_f32) {
+    const bool planes_out = !p.out_f32 && !(BN == 256 && p.head_n > 0);
+    if (planes_out) {
         const float bound = p.in_meta[0] * p.wbound + p.bbound + (p.res_mode != DEMIA_RES_NONE ? p.res_meta[0] : 0.f);
         s_out = plane_scale(bound);
         if (blockIdx.x == 0 && tid == 0) p.out_meta[1] = s_out;
@@ -145,6 +150,17 @@ __device__ __forceinline__ void p32_epilogue(const ConvQ& p, char* smem, WriteRo
         bs[q] = (p.bias && ok) ? p.bias[co + q] : 0.0f;
     }
     float vmax = 0.f;
+    // fused head (BN == 256 only): this thread's 8 columns of up to 4 head rows
+    constexpr int HMAX = 4;
+    float hw[HMAX][8];
+    const bool head_on = BN == 256 && p.head_n > 0;
+    if (head_on) {
+#pragma unroll
+        for (int j = 0; j < HMAX; ++j)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) hw[j][q] = j < p.head_n ? p.head_w[j * 256 + g * 8 + q] : 0.f;
+    }
+    const int tile_n_ = n0 / BN;
     const bool res_on = p.res_mode != DEMIA_RES_NONE, sigmoid_on = p.act == DEMIA_ACT_SIGMOID;
     const float act_lo = p.act == DEMIA_ACT_RELU ? 0.f : -INFINITY;
     const char* resb = reinterpret_cast<const char*>(p.res) + 128;
@@ -211,7 +227,29 @@ __device__ __forceinline__ void p32_epilogue(const ConvQ& p, char* smem, WriteRo
 #pragma unroll
                     for (int q = 0; q < 8; ++q) v[q] = 1.0f / (1.0f + expf(-v[q]));
                 }
-                if (p.out_f32) {
+                if (head_on) {
+                    // 256 activated channels of this row live in the 32 lanes of this half-wave: 8 FMAs per head row, then
+                    // a 5-step butterfly; lane 0 of the group adds the bias, applies the sigmoid and stores
+                    float acc_h[HMAX];
+#pragma unroll
+                    for (int j = 0; j < HMAX; ++j) {
+                        float a = 0.f;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) a = fmaf(v[q], hw[j][q], a);
+#pragma unroll
+                        for (int o = 16; o > 0; o >>= 1) a += __shfl_xor(a, o, 32);
+                        acc_h[j] = a;
+                    }
+                    if (g == 0) {
+                        float* o = p.head_out + ((long)m * p.ntn + tile_n_) * p.head_ld;
+#pragma unroll
+                        for (int j = 0; j < HMAX; ++j)
+                            if (j < p.head_n) {
+                                const float z = acc_h[j] + p.head_b[j];
+                                o[j] = p.head_act == DEMIA_ACT_SIGMOID ? 1.0f / (1.0f + expf(-z)) : (p.head_act == DEMIA_ACT_RELU ? fmaxf(z, 0.f) : z);
+                            }
+                    }
+                } else if (p.out_f32) {
                     float* o = reinterpret_cast<float*>(p.out) + (long)m * p.out_ld + co;
                     if (co + 8 <= p.Cout && (p.out_ld & 3) == 0) {
                         *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
@@ -241,7 +279,7 @@ __device__ __forceinline__ void p32_epilogue(const ConvQ& p, char* smem, WriteRo
             }
         }
     }
-    if (!p.out_f32) {
+    if (planes_out) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
         // the bound only grows: a (possibly stale) read that already covers this wave's maximum makes the atomic unnecessary
@@ -711,11 +749,11 @@ inline double predict_us(const TileCfg& c, long M, int cout_pad, int ksteps, boo
     return (double)((tiles + 511) / 512) * (2.0 * ksteps * step + 2.0 * 0.5 * edge);
 }
 
-inline int choose_tile(long M, int cout_pad, int ksteps, bool residual) {
+inline int choose_tile(long M, int cout_pad, int ksteps, bool residual, bool need256 = false) {
     int best = 0;
     double best_t = 1e30;
     for (const TileCfg& c : kTiles) {
-        if (cout_pad % c.bn) continue;
+        if (cout_pad % c.bn || (need256 && c.bn != 256)) continue;
         const double t = predict_us(c, M, cout_pad, ksteps, residual);
         if (t < best_t) { best_t = t; best = c.id; }
     }
@@ -725,8 +763,8 @@ inline int choose_tile(long M, int cout_pad, int ksteps, bool residual) {
 }  // namespace
 
 extern "C" int demia_conv2d_p32(const demia_conv_p32_desc* d, void* stream) {
-    DEMIA_REQUIRE(d && d->in && d->in_meta && d->w && d->out, "null pointer");
-    DEMIA_REQUIRE(d->out_f32 || d->out_meta, "P32 output needs out_meta");
+    DEMIA_REQUIRE(d && d->in && d->in_meta && d->w && (d->out || d->head_n > 0), "null pointer");
+    DEMIA_REQUIRE(d->out_f32 || d->out_meta || d->head_n > 0, "P32 output needs out_meta");
     DEMIA_REQUIRE(d->Cin > 0 && d->Cin % 32 == 0, "Cin must be a multiple of 32");
     DEMIA_REQUIRE(d->CoutPad >= d->Cout && d->CoutPad % 64 == 0, "CoutPad must be a multiple of 64");
     DEMIA_REQUIRE(d->out_f32 || d->Cout % 32 == 0, "P32 output needs Cout % 32 == 0");
@@ -755,6 +793,11 @@ extern "C" int demia_conv2d_p32(const demia_conv_p32_desc* d, void* stream) {
     p.in_bytes = (unsigned)in_bytes; p.w_bytes = (unsigned)w_bytes;
     p.ntn = p.nwg = 0;
     p.resident = 256;
+    p.head_w = d->head_w; p.head_b = d->head_b; p.head_out = d->head_out; p.head_n = d->head_n; p.head_ld = d->head_ld; p.head_act = d->head_act;
+    if (d->head_n > 0) {
+        DEMIA_REQUIRE(d->head_n <= 4 && d->head_w && d->head_b && d->head_out && d->head_ld >= d->head_n, "fused head: at most 4 rows, pointers, head_ld");
+        DEMIA_REQUIRE(d->CoutPad % 256 == 0 && d->Cout == d->CoutPad && !d->out_f32, "fused head needs Cout % 256 == 0 and a planes layer");
+    }
     {
         static const char* env = getenv("DEMIA_P32_STAGGER_US");      // experiment switch (microseconds)
         p.stagger_ticks = env ? atoi(env) * 100 : 0;
@@ -762,7 +805,8 @@ extern "C" int demia_conv2d_p32(const demia_conv_p32_desc* d, void* stream) {
     if (p.M == 0) return DEMIA_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     // tile_hint: 0 = auto (the model above), else one of the instantiated tiles (dev / tuning: scripts/gpu_conv_p32_check.py)
-    const int tile = d->tile_hint ? d->tile_hint : choose_tile(p.M, d->CoutPad, p.ksteps, d->res_mode != DEMIA_RES_NONE);
+    int tile = d->tile_hint ? d->tile_hint : choose_tile(p.M, d->CoutPad, p.ksteps, d->res_mode != DEMIA_RES_NONE, d->head_n > 0);
+    if (d->head_n > 0) DEMIA_REQUIRE(tile == 1 || tile == 2 || tile == 3 || tile == 4 || tile == 5 || tile == 12 || tile == 13, "fused head needs a 256-wide tile");
     const bool n256 = d->CoutPad % 256 == 0, n128 = d->CoutPad % 128 == 0;
     switch (tile) {
         case 1: DEMIA_REQUIRE(n256, "tile needs CoutPad % 256 == 0"); return launch_q<2, 4, 4, 2>(p, st);   // 256 x 256

@@ -358,6 +358,9 @@ class MaskRCNNEngine:
         wd = wd.permute(2, 3, 1, 0).reshape(4 * wd.shape[1], wd.shape[0], 1, 1)
         self.deconv = self._conv(sd, "", bias=True, weight=wd, bias_t=self._get(sd, mh + "deconv.bias").repeat(4))
         self.mask_pred = self._conv(sd, mh + "predictor", bias=True)
+        # f32 copy of the class predictor for the fused deconv + predictor launch of the f16x2 path (K <= 4 classes)
+        self.mask_pred_w32 = self._get(sd, mh + "predictor.weight").reshape(-1, 256).to(self.device).contiguous()
+        self.mask_pred_b32 = self._get(sd, mh + "predictor.bias").to(self.device).contiguous()
         self.unmatched_keys = sorted(k for k in sd if k not in self._used
                                      and not k.startswith(EXPECTED_IGNORED_PREFIXES))
 
@@ -421,13 +424,22 @@ class MaskRCNNEngine:
         return p32.to_f32(x) if isinstance(x, p32.P32) else x.float()
 
     def conv_p32(self, x: p32.P32, L: ConvLayer, act=ACT_NONE, residual: Optional[p32.P32] = None, res_mode=RES_NONE,
-                 out_f32: bool = False, out_ld: int = 0, tile_hint: int = 0):
-        """``demia_conv2d_p32``: P32 in, P32 out (or plain f32 [.., out_ld] for the prediction heads)."""
+                 out_f32: bool = False, out_ld: int = 0, tile_hint: int = 0, head=None):
+        """``demia_conv2d_p32``: P32 in, P32 out (or plain f32 [.., out_ld] for the prediction heads).  ``head`` =
+        (weights [hn, 256] f32, bias [hn] f32, ld, activation): the fused 1x1 head -- returns f32 [pixels * Cout / 256, ld]
+        instead of the layer's own output, which is never written."""
         n, h, w, cin = x.shape
         assert cin == L.cin, (cin, L.cin)
         ho = (h + 2 * L.pad - L.kh) // L.stride + 1
         wo = (w + 2 * L.pad - L.kw) // L.stride + 1
-        if out_f32:
+        hw_ptr = hb_ptr = ho_ptr = hn = hld = hact = 0
+        if head is not None:
+            hw_t, hb_t, hld, hact = head
+            hn = int(hw_t.shape[0])
+            out = self._scratch(n * ho * wo * (L.cout // 256) * hld, torch.float32).view(n * ho * wo * (L.cout // 256), hld)
+            hw_ptr, hb_ptr, ho_ptr = _lib.ptr(hw_t), _lib.ptr(hb_t), _lib.ptr(out)
+            optr, ometa = 0, 0
+        elif out_f32:
             ld = out_ld if out_ld > 0 else L.cout
             out = self._scratch(n * ho * wo * ld, torch.float32).view(n, ho, wo, ld)
             optr, ometa = _lib.ptr(out), 0
@@ -454,8 +466,9 @@ class MaskRCNNEngine:
             d = _lib.ConvP32Desc(_lib.ptr(x.buf) + c0 * pix_bytes, _lib.ptr(x.meta), _lib.ptr(L.w3), _lib.ptr(L.scale3), _lib.ptr(L.bias),
                                  0 if residual is None else _lib.ptr(residual.buf) + c0 * L.cout * 4,
                                  0 if residual is None else _lib.ptr(residual.meta),
-                                 optr + c0 * (ld if out_f32 else L.cout) * 4, ometa, L.wbound, L.bbound, cn, h, w, cin, ho, wo, L.cout,
-                                 L.cout_pad, L.kh, L.kw, L.stride, L.pad, act, res_mode, 1 if out_f32 else 0, out_ld, tile_hint)
+                                 (optr + c0 * (ld if out_f32 else L.cout) * 4) if optr else 0, ometa, L.wbound, L.bbound, cn, h, w, cin,
+                                 ho, wo, L.cout, L.cout_pad, L.kh, L.kw, L.stride, L.pad, act, res_mode, 1 if out_f32 else 0, out_ld,
+                                 tile_hint, hw_ptr, hb_ptr, (ho_ptr + c0 * (L.cout // 256) * hld * 4) if ho_ptr else 0, hn, hld, hact)
             _lib.check(self.lib.demia_conv2d_p32(C.byref(d), self._stream()), "demia_conv2d_p32")
         if ev is not None:
             e1.record(torch.cuda.current_stream(self.device))
@@ -701,6 +714,12 @@ class MaskRCNNEngine:
         x = self.view_as(mpooled, b * dd, 14, 14, 256)
         for L in self.mask_fcn:
             x = self.conv(x, L, act=ACT_RELU)
+        ld = (self.K + 3) // 4 * 4
+        if self.p32 and self.K <= 4:
+            # ConvTranspose2d(k2, s2) as a GEMM onto (dy, dx, co) + ReLU with the class predictor + sigmoid fused into its
+            # epilogue: the [.., 1024] deconv output (1.3 GB per 16-tile batch) is never written or re-read
+            return self.conv_p32(self.view_as(x, b * dd * 196, 1, 1, 256), self.deconv, act=ACT_RELU,
+                                 head=(self.mask_pred_w32, self.mask_pred_b32, ld, ACT_SIGMOID)).view(b * dd * 196 * 4, 1, 1, ld)
         x = self.conv(self.view_as(x, b * dd * 196, 1, 1, 256), self.deconv, act=ACT_RELU)        # [.., 1024] = (dy,dx,co)
         x = self.conv(self.view_as(x, b * dd * 196 * 4, 1, 1, 256), self.mask_pred, act=ACT_SIGMOID,
                       out_dtype=torch.float32, out_ld=(self.K + 3) // 4 * 4)

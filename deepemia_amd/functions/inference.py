@@ -187,7 +187,9 @@ class InferencePipeline:
         # images per batched forward: l4_performance_optimizations.forward_batch_size / DEEPEMIA_FORWARD_BATCH (default 16:
         # fills 256 CUs on the 50^2 feature maps, 8.6 GiB of activations per 2048^2-tile batch)
         self.forward_batch = max(1, int(os.environ.get("DEEPEMIA_FORWARD_BATCH", l4.get("forward_batch_size", 16))))
-        self.use_graphs = os.environ.get("DEEPEMIA_GRAPHS", "0") == "1"
+        self.use_graphs = os.environ.get("DEEPEMIA_GRAPHS", "1") == "1"     # hipGraph replay of repeated forward shapes
+        self.graph_after = 2                                                   # ... from their second occurrence on
+        self._shape_seen: Dict[tuple, int] = {}
         self.last_batch_stats = None
         self.forward_calls = 0
         import torch.distributed as dist
@@ -206,7 +208,21 @@ class InferencePipeline:
             chunk = images[b0:b0 + step].contiguous()
             # hipGraph replay (two alternating output sets per shape: the previous batch may still be read by the
             # post-processing stream) where the caller asked for it; eager otherwise
-            raws.append(pred.engine.forward_graphed(chunk) if self.use_graphs else pred.engine.forward(chunk))
+            key = (model_idx,) + tuple(int(d) for d in chunk.shape[:3])
+            self._shape_seen[key] = self._shape_seen.get(key, 0) + 1
+            # a batch shape that comes back (the tiles of the next image, the next batch of a job) is worth a capture; a
+            # one-off shape runs eagerly.  Same kernels in the same order either way: identical results.
+            graphed = self.use_graphs and self._shape_seen[key] >= self.graph_after
+            if graphed:
+                # a replay writes into the graph's own output buffers, which the next replay of this shape overwrites:
+                # the pipeline keeps detections for a whole image (and the first images' for the small-class statistics),
+                # so it takes its own copy (one device-to-device copy of the packed masks, ~0.3 ms per 16 tiles)
+                r = pred.engine.forward_graphed(chunk, slots=1)
+                r = type(r)(r.boxes.clone(), r.scores.clone(), r.classes.clone(), r.valid.clone(), r.count.clone(), r.packed.clone(),
+                            r.height, r.width, None if r.bbox is None else r.bbox.clone())
+                raws.append(r)
+            else:
+                raws.append(pred.engine.forward(chunk))
             self.forward_calls += 1
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.dev))

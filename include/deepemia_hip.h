@@ -129,7 +129,15 @@ typedef struct demia_conv_p32_desc {
     int32_t act, res_mode;
     int32_t out_f32;
     int32_t out_ld;          /* f32 output: elements between consecutive output pixels (>= Cout); 0 -> Cout */
-    int32_t tile_hint;       /* 0 = auto; else BM * 1000 + BN of an instantiated tile */
+    int32_t tile_hint;       /* 0 = auto (a cost model fitted on MI355X picks the tile); else the id of an instantiated tile (tuning) */
+    /* Optional fused 1x1 head (head_n in 1..4, Cout % 256 == 0): instead of writing the P32 output, every 256-channel block
+     * b of an activated output row m is multiplied by head_w [head_n][256] (+ head_b, then head_act) and stored as f32 at
+     * head_out[(m * (Cout / 256) + b) * head_ld + j].  Used for the mask head: ConvTranspose2d(k2, s2) as a GEMM onto
+     * (dy, dx, co) + ReLU, then the class predictor + sigmoid -- the 4 x 256-channel deconv output never reaches HBM.   */
+    const float* head_w;
+    const float* head_b;
+    float* head_out;
+    int32_t head_n, head_ld, head_act;
 } demia_conv_p32_desc;
 int demia_conv2d_p32(const demia_conv_p32_desc* d, void* stream);
 

@@ -80,7 +80,8 @@ def test_config2_one_8192_image_through_the_cli(tmp_path, monkeypatch, gpu_devic
     rows, rle = outs[0]
     assert outs[1] == outs[0], "two runs over the same 8192^2 image differ"
     inst = {r[0] for r in rows[1:]}
-    assert len(rle) - 1 == len(inst) and len(inst) > 300, (len(rle) - 1, len(inst))
+    # every CSV instance has an RLE row; an instance whose contours all fail the area gate (inference.py:1175-1190) has none in the CSV
+    assert len(rle) - 1 >= len(inst) > 300 and len(rle) - 1 - len(inst) <= 0.02 * len(inst), (len(rle) - 1, len(inst))
     assert all(np.isfinite(float(r[c])) for r in rows[1:] for c in range(3, 15))
     # every run of every mask lies inside the 8192 x 8192 frame (column-major 1-based starts)
     for _, runs in rle[1:50]:
