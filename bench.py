@@ -331,7 +331,7 @@ def main() -> None:
                                                   "instances_ref", "masks_identical", "masks_with_tie_pixels", "tie_pixels_max", "csv_rows",
                                                   "ellipse_rows_skipped", "ok")}
             line["parity"]["checked"] = (("tile 0 of the first timed step vs" if args.total_tiles else "tile 0 of the last timed step vs") + " oracle/tile_parity.py; bar: every mask IoU >= 0.999, CSV within 1e-4 "
-                                         "relative on the instances whose mask equals the reference's bit for bit, the others differ by <= 2 "
+                                         "relative on the instances whose mask equals the reference's bit for bit, the others differ by <= 8 "
                                          "threshold-tie pixels (csv_max_rel_err_all includes them)")
             if "why" in par:
                 line["parity"]["why"] = par["why"]

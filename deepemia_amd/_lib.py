@@ -52,6 +52,7 @@ class ConvP32Desc(C.Structure):
         ("act", C.c_int32), ("res_mode", C.c_int32), ("out_f32", C.c_int32), ("out_ld", C.c_int32), ("tile_hint", C.c_int32),
         ("head_w", C.c_void_p), ("head_b", C.c_void_p), ("head_out", C.c_void_p),
         ("head_n", C.c_int32), ("head_ld", C.c_int32), ("head_act", C.c_int32),
+        ("groups", C.c_int32), ("group_rows", C.c_int32), ("row0", C.c_int32),
     ]
 
 
@@ -70,7 +71,7 @@ class RoiAlignDesc(C.Structure):
         ("feat", C.c_void_p * 4), ("H", C.c_int32 * 4), ("W", C.c_int32 * 4),
         ("N", C.c_int32), ("R", C.c_int32), ("C", C.c_int32), ("P", C.c_int32), ("dtype", C.c_int32),
         ("boxes", C.c_void_p), ("count", C.c_void_p), ("out", C.c_void_p),
-        ("meta", C.c_void_p * 4), ("out_meta", C.c_void_p),
+        ("meta", C.c_void_p * 4), ("out_meta", C.c_void_p), ("groups", C.c_int32),
     ]
 
 
@@ -111,7 +112,7 @@ EXPORTS = {
     "demia_stem_conv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                    C.c_int, C.c_int, C.c_void_p]),
     "demia_maxpool3x3s2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
-    "demia_maxpool3x3s2_p32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "demia_maxpool3x3s2_p32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "demia_subsample2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "demia_rpn_workspace_bytes": (C.c_int64, [C.c_int]),
     "demia_rpn_proposals": (C.c_int, [C.POINTER(RpnDesc), C.c_void_p]),

@@ -57,6 +57,8 @@ struct ConvQ {
     const float* head_b;    // activated output row, + bias, sigmoid -> head_out[(m * ntn + tile_n) * head_ld + j]; the P32
     float* head_out;        // output itself is then not written
     int head_n, head_ld, head_act;
+    int groups, group_rows, row0;   // scale groups (images): in_meta / res_meta / out_meta are [groups][2]; output row m of this
+                                    // call belongs to group (m + row0) / group_rows
     int stagger_ticks;      // > 0: the second half of the first resident set of workgroups starts this many 10-ns ticks late
     int resident;           // workgroups resident at once (256 CUs x workgroups per CU) -- for the stagger
 };
@@ -122,7 +124,9 @@ __device__ __forceinline__ void write_acc16(const f32x4 (&r0)[2 * TN], const f32
 // Epilogue shared by the conv_p32 kernels: TM passes; in pass i every wave hands tile-row i of its accumulators to LDS,
 // then the 512 threads walk the WM * 32 rows x BN columns in 8-channel groups: scale / bias / residual / activation,
 // split into planes, 16-byte stores.  All waves have passed a barrier after their last LDS read.
-template <int WM, int WN, int TM, int TN, typename WriteRow>
+__device__ __forceinline__ float uniform(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+
+template <int WM, int WN, int TM, int TN, bool HEAD, typename WriteRow>
 __device__ __forceinline__ void p32_epilogue(const ConvQ& p, char* smem, WriteRow&& write_tile_row, int wm, int wn, int m0, int n0) {
     constexpr int BN = WN * TN * 32;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -130,15 +134,29 @@ __device__ __forceinline__ void p32_epilogue(const ConvQ& p, char* smem, WriteRo
     constexpr int GPR = BN / 8, RSTEP = 512 / GPR, ITEMS = WM * 32 / RSTEP;
     // (the launch sizes the LDS for max(two stages, this image))
     static_assert(512 % GPR == 0 && (WM * 32) % RSTEP == 0, "epilogue split");
-    const float s_in = p.in_meta[1];
-    const float post = 1.0f / s_in;
-    float s_out = 1.f, res_inv = 0.f;
-    if (p.res_mode != DEMIA_RES_NONE) res_inv = 1.0f / p.res_meta[1];
-    const bool planes_out = !p.out_f32 && !(BN == 256 && p.head_n > 0);
-    if (planes_out) {
-        const float bound = p.in_meta[0] * p.wbound + p.bbound + (p.res_mode != DEMIA_RES_NONE ? p.res_meta[0] : 0.f);
-        s_out = plane_scale(bound);
-        if (blockIdx.x == 0 && tid == 0) p.out_meta[1] = s_out;
+    constexpr int BM_ = WM * TM * 32;
+    static_assert(!HEAD || BN == 256, "the fused head needs a 256-wide tile");
+    const bool planes_out = !HEAD && !p.out_f32;
+    // Scales are per GROUP of rows (one group per image, so that a tile's result does not depend on its batch neighbours).
+    // A tile of <= 256 rows meets at most three groups (group_rows >= 128, checked by the host): g0, g0 + 1, g0 + 2, the
+    // second and third starting at local rows b1 and b2.
+    const int g0 = (m0 + p.row0) / p.group_rows;
+    const int b1 = (g0 + 1) * p.group_rows - p.row0, b2 = b1 + p.group_rows;
+    float post3[3], resi3[3], sout3[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int gi = min(g0 + d, p.groups - 1);
+        // block-uniform values: kept in scalar registers (the 256 x 256 tile has no vector register to spare)
+        post3[d] = uniform(1.0f / p.in_meta[2 * gi + 1]);
+        resi3[d] = p.res_mode != DEMIA_RES_NONE ? uniform(1.0f / p.res_meta[2 * gi + 1]) : 0.f;
+        sout3[d] = 1.f;
+        if (planes_out) {
+            const float bound = p.in_meta[2 * gi] * p.wbound + p.bbound + (p.res_mode != DEMIA_RES_NONE ? p.res_meta[2 * gi] : 0.f);
+            sout3[d] = uniform(plane_scale(bound));
+            // the tile (of the first column block) that holds a group's first row publishes the group's scale
+            const int first = d == 0 ? g0 * p.group_rows - p.row0 : (d == 1 ? b1 : b2);
+            if (n0 == 0 && tid == 0 && g0 + d < p.groups && first >= m0 && first < m0 + BM_ && first < p.M) p.out_meta[2 * gi + 1] = sout3[d];
+        }
     }
     const int g = tid % GPR, r_first = tid / GPR;
     const int co = n0 + g * 8;
@@ -146,14 +164,14 @@ __device__ __forceinline__ void p32_epilogue(const ConvQ& p, char* smem, WriteRo
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const bool ok = (co + q) < p.Cout;
-        sc[q] = (p.scale && ok) ? p.scale[co + q] * post : post;
+        sc[q] = (p.scale && ok) ? p.scale[co + q] : 1.0f;
         bs[q] = (p.bias && ok) ? p.bias[co + q] : 0.0f;
     }
-    float vmax = 0.f;
+    float vmax3[3] = {0.f, 0.f, 0.f};
     // fused head (BN == 256 only): this thread's 8 columns of up to 4 head rows
     constexpr int HMAX = 4;
     float hw[HMAX][8];
-    const bool head_on = BN == 256 && p.head_n > 0;
+    constexpr bool head_on = HEAD;      // its own instantiation: the head's 32 weight registers stay out of every other kernel
     if (head_on) {
 #pragma unroll
         for (int j = 0; j < HMAX; ++j)
@@ -212,9 +230,12 @@ __device__ __forceinline__ void p32_epilogue(const ConvQ& p, char* smem, WriteRo
                 const float4 x0 = *reinterpret_cast<const float4*>(smem + lr * EROW + g * 32);
                 const float4 x1 = *reinterpret_cast<const float4*>(smem + lr * EROW + g * 32 + 16);
                 float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                const int gd = (m >= b1) + (m >= b2);
+                const float post = gd == 0 ? post3[0] : (gd == 1 ? post3[1] : post3[2]);     // exact powers of two
 #pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = v[q] * sc[q] + bs[q];
+                for (int q = 0; q < 8; ++q) v[q] = (v[q] * post) * sc[q] + bs[q];
                 if (res_on) {
+                    const float res_inv = gd == 0 ? resi3[0] : (gd == 1 ? resi3[1] : resi3[2]);
 #pragma unroll
                     for (int q = 0; q < 8; ++q) v[q] += ((float)ch[k][q] + (float)cl[k][q]) * res_inv;
                 }
@@ -261,13 +282,18 @@ __device__ __forceinline__ void p32_epilogue(const ConvQ& p, char* smem, WriteRo
                     }
                 } else {
                     f16x8 h, l;
+                    const float s_out = gd == 0 ? sout3[0] : (gd == 1 ? sout3[1] : sout3[2]);
+                    float vm = 0.f;
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
-                        vmax = fmaxf(vmax, fabsf(v[q]));
+                        vm = fmaxf(vm, fabsf(v[q]));
                         const float y = v[q] * s_out;
                         h[q] = (_Float16)y;
                         l[q] = (_Float16)(y - (float)h[q]);
                     }
+                    vmax3[0] = fmaxf(vmax3[0], gd == 0 ? vm : 0.f);
+                    vmax3[1] = fmaxf(vmax3[1], gd == 1 ? vm : 0.f);
+                    vmax3[2] = fmaxf(vmax3[2], gd == 2 ? vm : 0.f);
                     char* o = outb + (long)m * cbytes + gofs;
                     if (P32_ABLATE & 64) {
                         asm volatile("" :: "v"(h), "v"(l), "v"(o));
@@ -281,14 +307,21 @@ __device__ __forceinline__ void p32_epilogue(const ConvQ& p, char* smem, WriteRo
     }
     if (planes_out) {
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
-        // the bound only grows: a (possibly stale) read that already covers this wave's maximum makes the atomic unnecessary
-        if (lane == 0 && vmax > *reinterpret_cast<volatile const float*>(p.out_meta))
-            atomicMax(reinterpret_cast<unsigned int*>(p.out_meta), __float_as_uint(vmax));
+        for (int d = 0; d < 3; ++d) {
+            if (d > 0 && (d == 1 ? b1 : b2) >= m0 + BM_) break;            // this tile has no rows of that group (block-uniform)
+            if (g0 + d >= p.groups) break;
+            float vmax = vmax3[d];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+            // the bound only grows: a (possibly stale) read that already covers this wave's maximum makes the atomic unnecessary
+            float* slot = p.out_meta + 2 * (g0 + d);
+            if (lane == 0 && vmax > *reinterpret_cast<volatile const float*>(slot))
+                atomicMax(reinterpret_cast<unsigned int*>(slot), __float_as_uint(vmax));
+        }
     }
 }
 
-template <int WM, int WN, int TM, int TN, bool M16 = true>
+template <int WM, int WN, int TM, int TN, bool M16 = true, bool HEAD = false>
 __global__ __launch_bounds__(512, 2) void conv_p32_kernel(const ConvQ p) {
     static_assert(WM * WN == 8, "eight waves");
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -488,9 +521,9 @@ __global__ __launch_bounds__(512, 2) void conv_p32_kernel(const ConvQ p) {
 #undef P32_ADVANCE
 
     if constexpr (M16) {
-        p32_epilogue<WM, WN, TM, TN>(p, smem, [&](int i, float* e) { write_acc16<TN, BN + 4>(acc16[2 * i], acc16[2 * i + 1], e, lane); }, wm, wn, m0, n0);
+        p32_epilogue<WM, WN, TM, TN, HEAD>(p, smem, [&](int i, float* e) { write_acc16<TN, BN + 4>(acc16[2 * i], acc16[2 * i + 1], e, lane); }, wm, wn, m0, n0);
     } else {
-        p32_epilogue<WM, WN, TM, TN>(p, smem, [&](int i, float* e) { write_acc32<TN, BN + 4>(acc[i], e, lane); }, wm, wn, m0, n0);
+        p32_epilogue<WM, WN, TM, TN, HEAD>(p, smem, [&](int i, float* e) { write_acc32<TN, BN + 4>(acc[i], e, lane); }, wm, wn, m0, n0);
     }
 }
 
@@ -689,7 +722,7 @@ __global__ __launch_bounds__(512, 2) void conv_p32_pp_kernel(const ConvQ p) {
     }
 #undef P32_ADVANCE
 #undef P32_PHASE_END
-    p32_epilogue<WM, WN, TM, TN>(p, smem, [&](int i, float* e) { write_acc32<TN, BN + 4>(acc[i], e, lane); }, wm, wn, m0, n0);
+    p32_epilogue<WM, WN, TM, TN, false>(p, smem, [&](int i, float* e) { write_acc32<TN, BN + 4>(acc[i], e, lane); }, wm, wn, m0, n0);
 }
 
 template <int TM, int TN>
@@ -710,7 +743,7 @@ int launch_pp(ConvQ p, hipStream_t st) {
     return DEMIA_OK;
 }
 
-template <int WM, int WN, int TM, int TN, bool M16 = true>
+template <int WM, int WN, int TM, int TN, bool M16 = true, bool HEAD = false>
 int launch_q(ConvQ p, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int stages = 2 * (BM + BN) * 128, image = WM * 32 * (BN * 4 + 16);
@@ -718,7 +751,7 @@ int launch_q(ConvQ p, hipStream_t st) {
     p.ntn = p.CoutPad / BN;
     p.nwg = p.ntn * cdiv(p.M, BM);
     p.resident = 256 * (160 * 1024 / smem >= 2 ? 2 : 1);
-    auto k = conv_p32_kernel<WM, WN, TM, TN, M16>;
+    auto k = conv_p32_kernel<WM, WN, TM, TN, M16, HEAD>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -793,6 +826,11 @@ extern "C" int demia_conv2d_p32(const demia_conv_p32_desc* d, void* stream) {
     p.in_bytes = (unsigned)in_bytes; p.w_bytes = (unsigned)w_bytes;
     p.ntn = p.nwg = 0;
     p.resident = 256;
+    p.groups = d->groups > 1 ? d->groups : 1;
+    p.group_rows = p.groups > 1 ? d->group_rows : (1 << 29);
+    p.row0 = p.groups > 1 ? d->row0 : 0;
+    DEMIA_REQUIRE(p.groups == 1 || (d->group_rows >= 128 && d->row0 >= 0 && ((long)p.M + d->row0 + d->group_rows - 1) / d->group_rows <= p.groups),
+                  "scale groups: group_rows >= 128 and the rows of this call must fall inside `groups` groups");
     p.head_w = d->head_w; p.head_b = d->head_b; p.head_out = d->head_out; p.head_n = d->head_n; p.head_ld = d->head_ld; p.head_act = d->head_act;
     if (d->head_n > 0) {
         DEMIA_REQUIRE(d->head_n <= 4 && d->head_w && d->head_b && d->head_out && d->head_ld >= d->head_n, "fused head: at most 4 rows, pointers, head_ld");
@@ -806,7 +844,15 @@ extern "C" int demia_conv2d_p32(const demia_conv_p32_desc* d, void* stream) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     // tile_hint: 0 = auto (the model above), else one of the instantiated tiles (dev / tuning: scripts/gpu_conv_p32_check.py)
     int tile = d->tile_hint ? d->tile_hint : choose_tile(p.M, d->CoutPad, p.ksteps, d->res_mode != DEMIA_RES_NONE, d->head_n > 0);
-    if (d->head_n > 0) DEMIA_REQUIRE(tile == 1 || tile == 2 || tile == 3 || tile == 4 || tile == 5 || tile == 12 || tile == 13, "fused head needs a 256-wide tile");
+    if (d->head_n > 0) {
+        // the fused head has its own instantiations: 256 x 256, 128 x 256 and 192 x 256
+        if (tile != 1 && tile != 2) tile = 4;
+        switch (tile) {
+            case 1: return launch_q<2, 4, 4, 2, true, true>(p, st);
+            case 2: return launch_q<2, 4, 2, 2, true, true>(p, st);
+            default: return launch_q<1, 8, 6, 1, true, true>(p, st);
+        }
+    }
     const bool n256 = d->CoutPad % 256 == 0, n128 = d->CoutPad % 128 == 0;
     switch (tile) {
         case 1: DEMIA_REQUIRE(n256, "tile needs CoutPad % 256 == 0"); return launch_q<2, 4, 4, 2>(p, st);   // 256 x 256

@@ -221,18 +221,18 @@ __global__ void maxpool3x3s2_kernel(const T* __restrict__ in, T* __restrict__ ou
     }
 }
 
-// maxpool 3x3 s2 p1 from f32 into P32 planes (conv_p32.hip): 8 channels per thread, 16-byte stores per plane
+// maxpool 3x3 s2 p1 from f32 into P32 planes (conv_p32.hip): 8 channels per thread, 16-byte stores per plane.
+// blockIdx.y = image; meta is [groups][2] with groups = 1 or one group per image.
 __global__ void maxpool3x3s2_p32_kernel(const float* __restrict__ in, char* __restrict__ out, float* __restrict__ meta, float s,
-                                        long total, int H, int W, int C, int Ho, int Wo) {
+                                        long per_image, int H, int W, int C, int Ho, int Wo, int groups) {
     const int C8 = C / 8;
+    const long n = blockIdx.y;
     float vmax = 0.f;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < per_image; i += (long)gridDim.x * blockDim.x) {
         const int c8 = (int)(i % C8);
         long t = i / C8;
         const int wo = (int)(t % Wo);
-        t /= Wo;
-        const int ho = (int)(t % Ho);
-        const long n = t / Ho;
+        const int ho = (int)(t / Wo);
         float m[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) m[q] = -INFINITY;
@@ -262,11 +262,12 @@ __global__ void maxpool3x3s2_p32_kernel(const float* __restrict__ in, char* __re
         *reinterpret_cast<f16x8*>(o) = h;
         *reinterpret_cast<f16x8*>(o + 64) = l;
     }
+    float* slot = meta + (groups > 1 ? 2 * n : 0);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
-    if ((threadIdx.x & 63) == 0 && vmax > *reinterpret_cast<volatile const float*>(meta))
-        atomicMax(reinterpret_cast<unsigned int*>(meta), __float_as_uint(vmax));
-    if (blockIdx.x == 0 && threadIdx.x == 0) meta[1] = s;
+    if ((threadIdx.x & 63) == 0 && vmax > *reinterpret_cast<volatile const float*>(slot))
+        atomicMax(reinterpret_cast<unsigned int*>(slot), __float_as_uint(vmax));
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (groups > 1 || n == 0)) slot[1] = s;
 }
 
 template <typename T>
@@ -354,13 +355,17 @@ extern "C" int demia_maxpool3x3s2(const void* in, void* out, int N, int H, int W
     return DEMIA_OK;
 }
 
-extern "C" int demia_maxpool3x3s2_p32(const float* in, void* out, float* out_meta, float s, int N, int H, int W, int C, void* stream) {
+extern "C" int demia_maxpool3x3s2_p32(const float* in, void* out, float* out_meta, float s, int N, int H, int W, int C, int groups,
+                                      void* stream) {
     DEMIA_REQUIRE(in && out && out_meta && C % 32 == 0 && s > 0.f, "args");
+    DEMIA_REQUIRE(groups <= 1 || groups == N, "scale groups: one per image");
+    DEMIA_REQUIRE(N <= 65535, "N");
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-    const long total = (long)N * Ho * Wo * (C / 8);
-    if (total == 0) return DEMIA_OK;
-    hipLaunchKernelGGL(maxpool3x3s2_p32_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, in, (char*)out, out_meta, s,
-                       total, H, W, C, Ho, Wo);
+    const long per_image = (long)Ho * Wo * (C / 8);
+    if (per_image * N == 0) return DEMIA_OK;
+    const int gx = (int)((grid_for(per_image * N, 256) + N - 1) / N);
+    hipLaunchKernelGGL(maxpool3x3s2_p32_kernel, dim3(gx, N), dim3(256), 0, (hipStream_t)stream, in, (char*)out, out_meta, s,
+                       per_image, H, W, C, Ho, Wo, groups);
     DEMIA_CHECK_LAUNCH("maxpool3x3s2_p32_kernel");
     return DEMIA_OK;
 }

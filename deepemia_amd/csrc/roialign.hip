@@ -18,8 +18,9 @@ struct RoiP {
     const float* boxes;
     const int* count;
     void* out;
-    const float* meta[4];   // P32 only: {amax, s} of each level
-    float* out_meta;        // P32 only
+    const float* meta[4];   // P32 only: {amax, s} of each level, [groups][2]
+    float* out_meta;        // P32 only, [groups][2]
+    int groups;             // P32 only: 1, or N (one scale group per image)
 };
 
 // Element access policies: bytes per pixel, a lane's byte offset inside a pixel (four channels per lane), load / store
@@ -91,10 +92,11 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiP p) {
     if (P32) {
         // bilinear taps and bin averages are convex combinations: the output shares the coarsest scale of the four levels
         // and their largest |x|
-        s_out = fminf(fminf(p.meta[0][1], p.meta[1][1]), fminf(p.meta[2][1], p.meta[3][1]));
-        if (roi == 0 && threadIdx.x == 0) {
-            p.out_meta[0] = fmaxf(fmaxf(p.meta[0][0], p.meta[1][0]), fmaxf(p.meta[2][0], p.meta[3][0]));
-            p.out_meta[1] = s_out;
+        const int gi = p.groups > 1 ? 2 * n : 0;
+        s_out = fminf(fminf(p.meta[0][gi + 1], p.meta[1][gi + 1]), fminf(p.meta[2][gi + 1], p.meta[3][gi + 1]));
+        if ((p.groups > 1 ? r == 0 : roi == 0) && threadIdx.x == 0) {
+            p.out_meta[gi] = fmaxf(fmaxf(p.meta[0][gi], p.meta[1][gi]), fmaxf(p.meta[2][gi], p.meta[3][gi]));
+            p.out_meta[gi + 1] = s_out;
         }
     }
     char* out0 = reinterpret_cast<char*>(p.out) + A::HEADER + roi * PP * pixb + A::lane_off(lane);
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiP p) {
     const int H = p.H[lv], W = p.W[lv];
     const float scale = 1.0f / (float)(4 << lv);
     const char* feat = reinterpret_cast<const char*>(p.feat[lv]) + A::HEADER + (long)n * H * W * pixb + A::lane_off(lane);
-    const float inv_s = P32 ? 1.0f / p.meta[lv][1] : 1.f;
+    const float inv_s = P32 ? 1.0f / p.meta[lv][(p.groups > 1 ? 2 * n : 0) + 1] : 1.f;
 
     const float rsw = b.x * scale - 0.5f, rsh = b.y * scale - 0.5f;
     const float rew = b.z * scale - 0.5f, reh = b.w * scale - 0.5f;
@@ -174,6 +176,8 @@ extern "C" int demia_roi_align(const demia_roialign_desc* d, void* stream) {
     p.N = d->N; p.R = d->R; p.C = d->C; p.P = d->P; p.boxes = d->boxes; p.count = d->count; p.out = d->out;
     for (int l = 0; l < 4; ++l) p.meta[l] = d->meta[l];
     p.out_meta = d->out_meta;
+    p.groups = d->groups > 1 ? d->groups : 1;
+    DEMIA_REQUIRE(p.groups == 1 || p.groups == d->N, "scale groups: one per image");
     if (d->dtype == DEMIA_P32) {
         DEMIA_REQUIRE(d->C % 32 == 0 && d->out_meta && d->meta[0] && d->meta[1] && d->meta[2] && d->meta[3], "P32 needs C % 32 == 0 and the meta pointers");
     }

@@ -236,7 +236,9 @@ class MaskRCNNEngine:
         self.p32 = precision == "f16x2"                   # activations travel as P32 planes (deepemia_amd/p32.py)
         self._amax_buf: Optional[torch.Tensor] = None     # f16x2r: per-forward pool of |activation| bounds
         self._amax_i = 0
-        self._meta_pool: Optional[torch.Tensor] = None    # f16x2: {max |x|, s} per activation tensor, zeroed once per forward
+        self._meta_pool: Optional[torch.Tensor] = None    # f16x2: {max |x|, s} per activation tensor and image, zeroed once per forward
+        self._meta_pools: Dict[tuple, torch.Tensor] = {}  # one pool per input shape (captured graphs keep pointers into theirs)
+        self._groups = 1
         self._meta_i = 0
         self._graphs: Dict[tuple, dict] = {}              # captured forwards per input shape (forward_graphed)
         self._arena: Dict[tuple, list] = {}               # intermediate buffers per input shape, reused by later forwards
@@ -369,15 +371,22 @@ class MaskRCNNEngine:
         return int(torch.cuda.current_stream(self.device).cuda_stream)
 
     # ---- f16x2 bookkeeping: intermediate buffers and {max |x|, s} slots -------------------------------------------
-    def _begin_forward(self, key: tuple) -> None:
+    def _begin_forward(self, key: tuple, ph: int, pw: int) -> None:
         """Intermediates of one forward come from an arena keyed by the input shape: the first forward of a shape
         allocates them (P32 headers zeroed once), later ones reuse them in call order -- no allocation, no memset but the
         one that clears the meta pool."""
         self._arena_key, self._arena_i = key, 0
-        if self._meta_pool is None:
-            self._meta_pool = torch.zeros((1024, 2), dtype=torch.float32, device=self.device)
+        # one {max |x|, s} pair per activation tensor and SCALE GROUP = image of the batch: an image's planes, and so its
+        # results, do not depend on its batch neighbours.  The conv epilogue needs >= 128 rows per group; the smallest
+        # tensor with one group per image is p6 (the RPN runs on it), so tiny inputs fall back to one group per tensor.
+        b = key[0]
+        self._groups = b if (b > 1 and ((ph // 32 - 1) // 2 + 1) * ((pw // 32 - 1) // 2 + 1) >= 128) else 1
+        pool = self._meta_pools.get(key)
+        if pool is None:
+            pool = self._meta_pools[key] = torch.zeros((256, self._groups, 2), dtype=torch.float32, device=self.device)
         else:
-            self._meta_pool.zero_()
+            pool.zero_()
+        self._meta_pool = pool
         self._meta_i = 0
 
     def _scratch(self, numel: int, dtype, zero: bool = False, zero_head: int = 0) -> torch.Tensor:
@@ -406,7 +415,7 @@ class MaskRCNNEngine:
         if self._meta_pool is None or self._meta_i >= self._meta_pool.shape[0]:
             if self._arena_key is not None and self._meta_pool is not None:
                 raise RuntimeError("activation meta pool exhausted inside one forward")
-            self._meta_pool = torch.zeros((1024, 2), dtype=torch.float32, device=self.device)
+            self._meta_pool = torch.zeros((256, self._groups, 2), dtype=torch.float32, device=self.device)
             self._meta_i = 0
         m = self._meta_pool[self._meta_i]
         self._meta_i += 1
@@ -462,13 +471,17 @@ class MaskRCNNEngine:
         if ev is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream(self.device))
+        groups = x.groups
+        group_rows = (n * ho * wo) // groups
+        assert groups == 1 or (group_rows * groups == n * ho * wo and (residual is None or residual.groups == groups)), (x.shape, groups)
         for c0, cn in chunks:
             d = _lib.ConvP32Desc(_lib.ptr(x.buf) + c0 * pix_bytes, _lib.ptr(x.meta), _lib.ptr(L.w3), _lib.ptr(L.scale3), _lib.ptr(L.bias),
                                  0 if residual is None else _lib.ptr(residual.buf) + c0 * L.cout * 4,
                                  0 if residual is None else _lib.ptr(residual.meta),
                                  (optr + c0 * (ld if out_f32 else L.cout) * 4) if optr else 0, ometa, L.wbound, L.bbound, cn, h, w, cin,
                                  ho, wo, L.cout, L.cout_pad, L.kh, L.kw, L.stride, L.pad, act, res_mode, 1 if out_f32 else 0, out_ld,
-                                 tile_hint, hw_ptr, hb_ptr, (ho_ptr + c0 * (L.cout // 256) * hld * 4) if ho_ptr else 0, hn, hld, hact)
+                                 tile_hint, hw_ptr, hb_ptr, (ho_ptr + c0 * (L.cout // 256) * hld * 4) if ho_ptr else 0, hn, hld, hact,
+                                 groups, group_rows, c0)
             _lib.check(self.lib.demia_conv2d_p32(C.byref(d), self._stream()), "demia_conv2d_p32")
         if ev is not None:
             e1.record(torch.cuda.current_stream(self.device))
@@ -572,11 +585,11 @@ class MaskRCNNEngine:
     def preprocess(self, images: torch.Tensor):
         """[B, H, W, 3] u8 BGR (device) -> zero-bordered f32 stem input, (newh, neww, PH, PW)."""
         b, h, w, _ = images.shape
-        if self.p32:
-            self._begin_forward((b, h, w))          # the first stage of every forward
         t = self._resize_tables(h, w)
         newh, neww = t["newh"], t["neww"]
         ph, pw = (newh + 31) // 32 * 32, (neww + 31) // 32 * 32
+        if self.p32:
+            self._begin_forward((b, h, w), ph, pw)          # the first stage of every forward
         st = self._stream()
         if t["need_h"]:
             tmp = (self._scratch(b * h * neww * 3, torch.uint8).view(b, h, neww, 3) if self.p32 else
@@ -603,7 +616,7 @@ class MaskRCNNEngine:
                                                 _lib.ptr(self.stem_bias), _lib.ptr(mid), b, ph, pw, F32, st), "demia_stem_conv")
             x = self.new_p32((b, ph // 4, pw // 4, 64))
             _lib.check(self.lib.demia_maxpool3x3s2_p32(_lib.ptr(mid), _lib.ptr(x.buf), _lib.ptr(x.meta), p32.plane_scale(self.stem_bound),
-                                                       b, ph // 2, pw // 2, 64, st), "demia_maxpool3x3s2_p32")
+                                                       b, ph // 2, pw // 2, 64, x.groups, st), "demia_maxpool3x3s2_p32")
         else:
             mid = torch.empty((b, ph // 2, pw // 2, 64), dtype=self.tdt, device=self.device)
             _lib.check(self.lib.demia_stem_conv(_lib.ptr(xin), _lib.ptr(self.stem_w), _lib.ptr(self.stem_scale),
@@ -672,7 +685,7 @@ class MaskRCNNEngine:
                 f = feats[name]
                 d.feat[i], d.meta[i] = _lib.ptr(f.buf), _lib.ptr(f.meta)
                 d.H[i], d.W[i] = f.shape[1], f.shape[2]
-            d.N, d.R, d.C, d.P, d.dtype = b, r, 256, P, _lib.P32
+            d.N, d.R, d.C, d.P, d.dtype, d.groups = b, r, 256, P, _lib.P32, out.groups
             d.boxes, d.count, d.out, d.out_meta = _lib.ptr(boxes), _lib.ptr(count), _lib.ptr(out.buf), _lib.ptr(out.meta)
             _lib.check(self.lib.demia_roi_align(C.byref(d), self._stream()), "demia_roi_align")
             return out

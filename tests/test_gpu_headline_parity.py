@@ -4,9 +4,8 @@ restatement, then the whole per-tile path (class loop, dedup, contours, 12 measu
 (``oracle/tile_parity.py``, the same functions ``bench.py`` uses for its ``parity`` field).
 
 Tolerances (north_star): same instances in the same order, scores within 1e-4, mask IoU >= 0.999, every measurement
-within 1e-4 relative.  Plus the batch behaviour of the f16x2 mode: its operand scales are per tensor per BATCH (exact
-powers of two), so a tile alone and the same tile inside a 16-tile batch must agree -- masks and classes exactly, scores
-to 1e-5 (measured: features agree to 1e-6 of their maximum, scores to 5e-6)."""
+within 1e-4 relative.  Plus the batch behaviour of the f16x2 mode: its operand scales are per tensor per IMAGE (exact
+powers of two), so a tile alone and the same tile inside a 16-tile batch must agree bit for bit."""
 import numpy as np
 import pytest
 import torch
@@ -47,6 +46,16 @@ def test_r101_2048_f16x2_predictor_matches_oracle(env):
     assert tuple(m.shape) == (n, 2048, 2048)
     iou = (m & r).sum((1, 2)).float() / (m | r).sum((1, 2)).float().clamp(min=1)
     assert float(iou.min()) >= 0.999, float(iou.min())
+    # every pixel on which the two disagree is a TIE of the paste threshold: the CPU path's own sampled probability there
+    # is within 1e-4 of 0.5 (scores / mask probabilities agree to ~1e-5; ~30 000 border pixels per tile)
+    from oracle import maskrcnn_ref as R
+    differing = (m != r).flatten(1).any(1).nonzero().flatten().tolist()
+    worst = 0.0
+    for i in differing:
+        soft = R.paste_masks(raw["mask_probs28"][i:i + 1], raw["pred_boxes"][i:i + 1], 2048, 2048, soft=True)[0]
+        worst = max(worst, float((soft[m[i] != r[i]] - 0.5).abs().max()))
+    print("instances with differing pixels:", len(differing), "of", n, "; max |p - 0.5| on a differing pixel:", worst)
+    assert worst <= 1e-4 and len(differing) <= n // 5
 
 
 def test_r101_2048_f16x2_whole_tile_path_matches_oracle(env):
@@ -62,18 +71,21 @@ def test_r101_2048_f16x2_whole_tile_path_matches_oracle(env):
 
 
 def test_f16x2_forward_is_batch_invariant(env):
+    """Scales are kept per IMAGE (one scale group per tile of the batch, ``demia_conv_p32_desc.groups``), the K order of a
+    dot product does not depend on the tile shape, and every other stage works image by image: a tile alone and the same
+    tile inside a 16-tile batch -- next to a much brighter tile -- give the SAME bits."""
     eng, synth, dev = env["eng"], env["synth"], env["dev"]
     tiles = np.stack([synth.em_tile(i, 2048) for i in range(16)])
     tiles[3] = (tiles[3].astype(np.int32) * 5 // 2).clip(0, 255).astype(np.uint8)        # one tile much brighter than the others
     x = torch.from_numpy(tiles).to(dev)
     full = eng.forward(x)
+    full = type(full)(*[t.clone() if torch.is_tensor(t) else t for t in
+                        (full.boxes, full.scores, full.classes, full.valid, full.count, full.packed, full.height, full.width, full.bbox)])
     for i in (0, 3, 15):
         one = eng.forward(x[i:i + 1].contiguous())
         n = int(one.count[0])
         assert n == int(full.count[i]) and n > 10
         assert torch.equal(one.classes[0, :n], full.classes[i, :n])
-        assert float((one.scores[0, :n] - full.scores[i, :n]).abs().max()) <= 1e-5
-        # the scales of a batch and of a single tile differ by exact powers of two: what can change is the low plane of
-        # values below 2^-16 of a tensor's maximum -- at most a couple of threshold-tie pixels on a few masks
-        diff = (eng.unpack(one.packed[0, :n].contiguous(), 2048, 2048) != eng.unpack(full.packed[i, :n].contiguous(), 2048, 2048))
-        assert int(diff.sum((1, 2)).max()) <= 2 and int((diff.sum((1, 2)) > 0).sum()) <= max(3, n // 10), diff.sum((1, 2))
+        assert torch.equal(one.scores[0, :n], full.scores[i, :n])
+        assert torch.equal(one.boxes[0, :n], full.boxes[i, :n])
+        assert torch.equal(one.packed[0, :n], full.packed[i, :n])
