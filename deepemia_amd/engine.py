@@ -411,22 +411,23 @@ class MaskRCNNEngine:
             slots.append(t)
         return t
 
-    def _meta_slot(self) -> torch.Tensor:
-        if self._meta_pool is None or self._meta_i >= self._meta_pool.shape[0]:
-            if self._arena_key is not None and self._meta_pool is not None:
-                raise RuntimeError("activation meta pool exhausted inside one forward")
-            self._meta_pool = torch.zeros((256, self._groups, 2), dtype=torch.float32, device=self.device)
-            self._meta_i = 0
+    def _meta_slot(self, groups: int) -> torch.Tensor:
+        if self._arena_key is None:                    # a stage called on its own (tests): plain allocation
+            return torch.zeros((groups, 2), dtype=torch.float32, device=self.device)
+        if groups != self._groups:                     # not a tensor of the forward the pool was laid out for (tests)
+            return torch.zeros((groups, 2), dtype=torch.float32, device=self.device)
+        if self._meta_i >= self._meta_pool.shape[0]:
+            raise RuntimeError("activation meta pool exhausted inside one forward")
         m = self._meta_pool[self._meta_i]
         self._meta_i += 1
         return m
 
-    def new_p32(self, shape) -> p32.P32:
+    def new_p32(self, shape, groups: Optional[int] = None) -> p32.P32:
         n = 1
         for d in shape:
             n *= int(d)
         buf = self._scratch(p32.HEADER_HALFS + 2 * n, torch.float16, zero_head=p32.HEADER_HALFS)
-        return p32.P32(buf, self._meta_slot(), tuple(int(d) for d in shape))
+        return p32.P32(buf, self._meta_slot(self._groups if groups is None else groups), tuple(int(d) for d in shape))
 
     def dense(self, x) -> torch.Tensor:
         """An activation as a plain f32 tensor (tests / debug dumps; the product path never converts)."""
@@ -453,7 +454,7 @@ class MaskRCNNEngine:
             out = self._scratch(n * ho * wo * ld, torch.float32).view(n, ho, wo, ld)
             optr, ometa = _lib.ptr(out), 0
         else:
-            out = self.new_p32((n, ho, wo, L.cout))
+            out = self.new_p32((n, ho, wo, L.cout), x.groups)
             optr, ometa = _lib.ptr(out.buf), _lib.ptr(out.meta)
         # the kernel addresses its input with 32-bit byte offsets: a pointwise layer over more than 4 GiB of planes (the mask
         # head's last two layers at 64 tiles per forward) goes in pixel chunks -- rows are independent, and without
@@ -680,7 +681,7 @@ class MaskRCNNEngine:
         b, r, _ = boxes.shape
         d = _lib.RoiAlignDesc()
         if isinstance(feats["p2"], p32.P32):
-            out = self.new_p32((b, r, P, P, 256))
+            out = self.new_p32((b, r, P, P, 256), feats["p2"].groups)
             for i, name in enumerate(("p2", "p3", "p4", "p5")):
                 f = feats[name]
                 d.feat[i], d.meta[i] = _lib.ptr(f.buf), _lib.ptr(f.meta)
