@@ -53,6 +53,7 @@ struct ConvQ {
     int act, res_mode, out_f32, out_ld;
     int M, HoWo, ntn, nwg, ksteps, taps;
     unsigned in_bytes, w_bytes;
+    unsigned out_bytes, res_bytes;   // planes epilogue (EPI_PLANES): sizes of the output / residual buffers incl. their headers
     const float* head_w;    // fused 1x1 head (head_n > 0): [head_n][256] f32 weights applied to every 256-channel block of the
     const float* head_b;    // activated output row, + bias, sigmoid -> head_out[(m * ntn + tile_n) * head_ld + j]; the P32
     float* head_out;        // output itself is then not written
@@ -126,8 +127,39 @@ __device__ __forceinline__ void write_acc16(const f32x4 (&r0)[2 * TN], const f32
 // split into planes, 16-byte stores.  All waves have passed a barrier after their last LDS read.
 __device__ __forceinline__ float uniform(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 
+// Scales are per GROUP of rows (one group per image, so that a tile's result does not depend on its batch neighbours).  A
+// tile of <= 256 rows meets at most three groups (group_rows >= 128, checked by the host): g0, g0 + 1, g0 + 2, the second
+// and third starting at local rows b1 and b2.  Everything here is block-uniform and is read at the START of the kernel
+// (scalar loads, hidden behind the K loop; read in the epilogue they were nine dependent memory round trips per tile) and
+// kept in scalar registers -- the 256 x 256 tile has no vector register to spare.
+struct GroupScales {      // plain scalars, no arrays: the struct must dissolve into (scalar) registers
+    int g0, b1, b2;
+    float post0, post1, post2, resi0, resi1, resi2, sout0, sout1, sout2;
+};
+
+__device__ __forceinline__ void load_group_scale(const ConvQ& p, int gi, bool planes_out, float& post, float& resi, float& sout) {
+    gi = min(gi, p.groups - 1);
+    const float amax_in = p.in_meta[2 * gi], s_in = p.in_meta[2 * gi + 1];
+    float amax_res = 0.f, s_res = 1.f;
+    if (p.res_mode != DEMIA_RES_NONE) { amax_res = p.res_meta[2 * gi]; s_res = p.res_meta[2 * gi + 1]; }
+    post = uniform(1.0f / s_in);
+    resi = uniform(p.res_mode != DEMIA_RES_NONE ? 1.0f / s_res : 0.f);
+    sout = uniform(planes_out ? plane_scale(amax_in * p.wbound + p.bbound + amax_res) : 1.f);
+}
+
+__device__ __forceinline__ GroupScales load_group_scales(const ConvQ& p, int m0, bool planes_out) {
+    GroupScales gs;
+    gs.g0 = (m0 + p.row0) / p.group_rows;
+    gs.b1 = (gs.g0 + 1) * p.group_rows - p.row0;
+    gs.b2 = gs.b1 + p.group_rows;
+    load_group_scale(p, gs.g0, planes_out, gs.post0, gs.resi0, gs.sout0);
+    load_group_scale(p, gs.g0 + 1, planes_out, gs.post1, gs.resi1, gs.sout1);
+    load_group_scale(p, gs.g0 + 2, planes_out, gs.post2, gs.resi2, gs.sout2);
+    return gs;
+}
+
 template <int WM, int WN, int TM, int TN, bool HEAD, typename WriteRow>
-__device__ __forceinline__ void p32_epilogue(const ConvQ& p, char* smem, WriteRow&& write_tile_row, int wm, int wn, int m0, int n0) {
+__device__ __forceinline__ void p32_epilogue(const ConvQ& p, const GroupScales& gs, char* smem, WriteRow&& write_tile_row, int wm, int wn, int m0, int n0) {
     constexpr int BN = WN * TN * 32;
     const int tid = threadIdx.x, lane = tid & 63;
     constexpr int EROW = BN * 4 + 16;
@@ -137,25 +169,19 @@ __device__ __forceinline__ void p32_epilogue(const ConvQ& p, char* smem, WriteRo
     constexpr int BM_ = WM * TM * 32;
     static_assert(!HEAD || BN == 256, "the fused head needs a 256-wide tile");
     const bool planes_out = !HEAD && !p.out_f32;
-    // Scales are per GROUP of rows (one group per image, so that a tile's result does not depend on its batch neighbours).
-    // A tile of <= 256 rows meets at most three groups (group_rows >= 128, checked by the host): g0, g0 + 1, g0 + 2, the
-    // second and third starting at local rows b1 and b2.
-    const int g0 = (m0 + p.row0) / p.group_rows;
-    const int b1 = (g0 + 1) * p.group_rows - p.row0, b2 = b1 + p.group_rows;
-    float post3[3], resi3[3], sout3[3];
+    // (taken out of the struct through readfirstlane: selects between plain struct fields get rewritten into an indexed
+    // load of the struct, which then has to live in scratch memory)
+    const int g0 = __builtin_amdgcn_readfirstlane(gs.g0), b1 = __builtin_amdgcn_readfirstlane(gs.b1), b2 = __builtin_amdgcn_readfirstlane(gs.b2);
+    const float post0 = uniform(gs.post0), post1 = uniform(gs.post1), post2 = uniform(gs.post2);
+    const float resi0 = uniform(gs.resi0), resi1 = uniform(gs.resi1), resi2 = uniform(gs.resi2);
+    const float sout0 = uniform(gs.sout0), sout1 = uniform(gs.sout1), sout2 = uniform(gs.sout2);
+    if (planes_out && n0 == 0 && tid == 0) {
+        // the tile (of the first column block) that holds a group's first row publishes the group's scale
 #pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        const int gi = min(g0 + d, p.groups - 1);
-        // block-uniform values: kept in scalar registers (the 256 x 256 tile has no vector register to spare)
-        post3[d] = uniform(1.0f / p.in_meta[2 * gi + 1]);
-        resi3[d] = p.res_mode != DEMIA_RES_NONE ? uniform(1.0f / p.res_meta[2 * gi + 1]) : 0.f;
-        sout3[d] = 1.f;
-        if (planes_out) {
-            const float bound = p.in_meta[2 * gi] * p.wbound + p.bbound + (p.res_mode != DEMIA_RES_NONE ? p.res_meta[2 * gi] : 0.f);
-            sout3[d] = uniform(plane_scale(bound));
-            // the tile (of the first column block) that holds a group's first row publishes the group's scale
+        for (int d = 0; d < 3; ++d) {
             const int first = d == 0 ? g0 * p.group_rows - p.row0 : (d == 1 ? b1 : b2);
-            if (n0 == 0 && tid == 0 && g0 + d < p.groups && first >= m0 && first < m0 + BM_ && first < p.M) p.out_meta[2 * gi + 1] = sout3[d];
+            if (g0 + d < p.groups && first >= m0 && first < m0 + BM_ && first < p.M)
+                p.out_meta[2 * (g0 + d) + 1] = d == 0 ? sout0 : (d == 1 ? sout1 : sout2);
         }
     }
     const int g = tid % GPR, r_first = tid / GPR;
@@ -197,7 +223,13 @@ __device__ __forceinline__ void p32_epilogue(const ConvQ& p, char* smem, WriteRo
     };
     // The residual rows of a pass are requested ONE PASS AHEAD (all of them at once): a short-K layer is otherwise one
     // exposed HBM round trip per item -- sixteen in a row for a 256 x 256 tile.
-    f16x8 rh[ITEMS], rl[ITEMS];
+    // two register sets used in turn (pass i reads set i & 1 while set (i + 1) & 1 is being filled): no copy at the start of a
+    // pass, so the wait for the next pass's residual -- which on this ISA is also a wait for every store issued before it --
+    // sits where the values are first used, a barrier and an LDS round trip after the previous pass's stores were issued
+#ifndef P32_RES_DB
+#define P32_RES_DB 0
+#endif
+    f16x8 rh[2][ITEMS], rl[2][ITEMS];
     const bool has_res = p.res_mode != DEMIA_RES_NONE && co < p.Cout;
     auto load_res = [&](int i) {
 #pragma unroll
@@ -205,8 +237,8 @@ __device__ __forceinline__ void p32_epilogue(const ConvQ& p, char* smem, WriteRo
             const int m = row_of(i, k);
             if (has_res && m < p.M && !(P32_ABLATE & 32)) {
                 const char* rp = resb + res_pix(m) * cbytes + gofs;
-                rh[k] = *reinterpret_cast<const f16x8*>(rp);
-                rl[k] = *reinterpret_cast<const f16x8*>(rp + 64);
+                rh[P32_RES_DB ? (i & 1) : 0][k] = *reinterpret_cast<const f16x8*>(rp);
+                rl[P32_RES_DB ? (i & 1) : 0][k] = *reinterpret_cast<const f16x8*>(rp + 64);
             }
         }
     };
@@ -219,7 +251,7 @@ __device__ __forceinline__ void p32_epilogue(const ConvQ& p, char* smem, WriteRo
         __syncthreads();
         f16x8 ch[ITEMS], cl[ITEMS];
 #pragma unroll
-        for (int k = 0; k < ITEMS; ++k) { ch[k] = rh[k]; cl[k] = rl[k]; }
+        for (int k = 0; k < ITEMS; ++k) { ch[k] = rh[P32_RES_DB ? (i & 1) : 0][k]; cl[k] = rl[P32_RES_DB ? (i & 1) : 0][k]; }
         if (i + 1 < TM) load_res(i + 1);
         if (co < p.Cout) {
 #pragma unroll
@@ -231,11 +263,11 @@ __device__ __forceinline__ void p32_epilogue(const ConvQ& p, char* smem, WriteRo
                 const float4 x1 = *reinterpret_cast<const float4*>(smem + lr * EROW + g * 32 + 16);
                 float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
                 const int gd = (m >= b1) + (m >= b2);
-                const float post = gd == 0 ? post3[0] : (gd == 1 ? post3[1] : post3[2]);     // exact powers of two
+                const float post = gd == 0 ? post0 : (gd == 1 ? post1 : post2);     // exact powers of two
 #pragma unroll
                 for (int q = 0; q < 8; ++q) v[q] = (v[q] * post) * sc[q] + bs[q];
                 if (res_on) {
-                    const float res_inv = gd == 0 ? resi3[0] : (gd == 1 ? resi3[1] : resi3[2]);
+                    const float res_inv = gd == 0 ? resi0 : (gd == 1 ? resi1 : resi2);
 #pragma unroll
                     for (int q = 0; q < 8; ++q) v[q] += ((float)ch[k][q] + (float)cl[k][q]) * res_inv;
                 }
@@ -282,7 +314,7 @@ __device__ __forceinline__ void p32_epilogue(const ConvQ& p, char* smem, WriteRo
                     }
                 } else {
                     f16x8 h, l;
-                    const float s_out = gd == 0 ? sout3[0] : (gd == 1 ? sout3[1] : sout3[2]);
+                    const float s_out = gd == 0 ? sout0 : (gd == 1 ? sout1 : sout2);
                     float vm = 0.f;
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
@@ -321,7 +353,197 @@ __device__ __forceinline__ void p32_epilogue(const ConvQ& p, char* smem, WriteRo
     }
 }
 
-template <int WM, int WN, int TM, int TN, bool M16 = true, bool HEAD = false>
+// ---------------------------------------------------------------------------------------------------------------------
+// Epilogue of a plain P32 layer (planes out, whole 8-channel groups, buffers below 4 GiB): STRAIGHT-LINE code.  Residual
+// loads and plane stores are buffer instructions whose bounds the hardware checks (rows >= M: loads return 0, stores are
+// dropped; a layer without residual loads from an empty buffer and scales by 0), so every pass issues the same number of
+// memory instructions and the waits are counted: a pass waits for ITS residual lines only, not -- as with stores inside
+// `if (m < M)` branches, where the count is unknown and the wait becomes vmcnt(0) -- for the previous pass's stores to be
+// acknowledged by the L2.  That acknowledgement was the longest stall of every short-K (HBM-bound) layer.
+// The accumulator image of a pass (WM x 32 rows) is double-buffered -- one barrier per pass instead of two -- where the second
+// copy is free: the K-loop stages it overlays are larger, or the tile runs one workgroup per CU anyway.
+template <int WM, int WN, int TM, int TN>
+constexpr bool image_double() {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int stages = 2 * (BM + BN) * 128, image = WM * 32 * (BN * 4 + 16);
+    return 2 * image <= 160 * 1024 && (2 * image <= stages || 2 * stages > 160 * 1024);
+}
+
+template <int WM, int WN, int TM, int TN, typename WriteRow>
+__device__ __forceinline__ void p32_epilogue_planes(const ConvQ& p, const GroupScales& gs, char* smem, WriteRow&& write_tile_row, int wm, int wn,
+                                                    int m0, int n0) {
+    constexpr int BN = WN * TN * 32, BM_ = WM * TM * 32;
+    const int tid = threadIdx.x, lane = tid & 63;
+    constexpr int EROW = BN * 4 + 16;
+    constexpr int GPR = BN / 8, RSTEP = 512 / GPR, ITEMS = WM * 32 / RSTEP;
+    static_assert(512 % GPR == 0 && (WM * 32) % RSTEP == 0, "epilogue split");
+    const int g0 = __builtin_amdgcn_readfirstlane(gs.g0), b1 = __builtin_amdgcn_readfirstlane(gs.b1), b2 = __builtin_amdgcn_readfirstlane(gs.b2);
+    const float post0 = uniform(gs.post0), post1 = uniform(gs.post1), post2 = uniform(gs.post2);
+    const float resi0 = uniform(gs.resi0), resi1 = uniform(gs.resi1), resi2 = uniform(gs.resi2);
+    const float sout0 = uniform(gs.sout0), sout1 = uniform(gs.sout1), sout2 = uniform(gs.sout2);
+    if (n0 == 0 && tid == 0) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int first = d == 0 ? g0 * p.group_rows - p.row0 : (d == 1 ? b1 : b2);
+            if (g0 + d < p.groups && first >= m0 && first < m0 + BM_ && first < p.M)
+                p.out_meta[2 * (g0 + d) + 1] = d == 0 ? sout0 : (d == 1 ? sout1 : sout2);
+        }
+    }
+    // FULL-LINE memory instructions.  A P32 line is [h0 h1 h2 h3 | l0 l1 l2 l3] (16 bytes = 8 channels each).  A thread
+    // computes 8 channels of one row, i.e. owns h_j and l_j -- two 16-byte pieces 64 bytes apart, and four lanes together
+    // would touch HALF a line per instruction (the L1 then sends 64-byte requests, and the number of requests a CU may have
+    // in flight is what bounds these layers: ~45 per CU at ~900 cycles each).  So lanes work in groups of EIGHT on a PAIR of
+    // rows (r, r + 1): lane 8 q + j (j < 4) computes chunk j of row r, lane 8 q + 4 + j chunk j of row r + 1, and memory
+    // instruction X of a pair moves the whole line of row r + X, lane 8 q + t taking bytes 16 t .. 16 t + 15.  What a lane
+    // moved for its partner (lane ^ 4) changes hands with one 16-byte lane exchange.
+    constexpr int LPR = BN / 32, RPW = 64 / GPR;             // lines per tile row; rows a wave covers per item
+    const int cj = lane & 3, rs = (lane >> 2) & 1, lg = lane >> 3;
+    const int g = (lg % LPR) * 4 + cj;
+    const int r_first = (tid >> 6) * RPW + (lg / LPR) * 2 + rs;
+    const int co = n0 + g * 8;
+    float sc[8], bs[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        sc[q] = p.scale ? p.scale[co + q] : 1.0f;
+        bs[q] = p.bias ? p.bias[co + q] : 0.0f;
+    }
+    const bool sigmoid_on = p.act == DEMIA_ACT_SIGMOID;
+    const float act_lo = p.act == DEMIA_ACT_RELU ? 0.f : -INFINITY;
+    const bool res_on = p.res_mode != DEMIA_RES_NONE;
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(res_on ? p.res : p.out), 0, res_on ? (int)p.res_bytes : 0, 0x00020000);
+    const unsigned cbytes = (unsigned)p.Cout * 4u;                                     // bytes per P32 pixel
+    const unsigned lofs = 128u + (unsigned)((co >> 5) * 128 + (lane & 7) * 16);   // header + this lane's 16 bytes of the pair's lines
+    auto row_of = [&](int i, int k) { const int lr = r_first + k * RSTEP; return m0 + (lr >> 5) * (TM * 32) + i * 32 + (lr & 31); };
+    auto res_off = [&](int m) -> unsigned {
+        if (p.res_mode != DEMIA_RES_UP2 || (P32_ABLATE & 256)) return (unsigned)m * cbytes + lofs;   // (m < M + 256: no wrap below 4 GiB)
+        const int n = m / p.HoWo;
+        const int rem = m - n * p.HoWo;
+        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+        const int Hr = (p.Ho + 1) >> 1, Wr = (p.Wo + 1) >> 1;
+        return (unsigned)((n * Hr + (ho >> 1)) * Wr + (wo >> 1)) * cbytes + lofs;
+    };
+    // The exchange as two DPP moves per dword, no select: `row_shr:4` hands lanes 4..7 / 12..15 of a row (the lanes of
+    // row r + 1, bank mask 0b1010) the value of the lane four below, `row_shl:4` hands lanes 0..3 / 8..11 (row r, bank mask
+    // 0b0101) the value of the lane four above; the lanes a move does not write keep `own`.
+    auto from_below = [&](u32x4 own, u32x4 theirs) -> u32x4 {   // lanes of row r + 1 take the partner's `theirs`
+        u32x4 r;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) r[c] = (unsigned)__builtin_amdgcn_update_dpp((int)own[c], (int)theirs[c], 0x114, 0xf, 0xa, false);
+        return r;
+    };
+    auto from_above = [&](u32x4 own, u32x4 theirs) -> u32x4 {   // lanes of row r take the partner's `theirs`
+        u32x4 r;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) r[c] = (unsigned)__builtin_amdgcn_update_dpp((int)own[c], (int)theirs[c], 0x104, 0xf, 0x5, false);
+        return r;
+    };
+    u32x4 rh[ITEMS], rl[ITEMS];                              // as loaded: [0] = this lane's piece of row r, [1] = of row r + 1
+    auto load_res = [&](int i) {
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) {
+            const int mp = row_of(i, k) - rs;                // row r of the pair
+            if (P32_ABLATE & 32) { rh[k] = u32x4{0, 0, 0, 0}; rl[k] = rh[k]; continue; }
+            rh[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, res_off(mp), 0, 0);
+            rl[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, res_off(mp + 1), 0, 0);
+        }
+    };
+    float vmax0 = 0.f, vmax1 = 0.f, vmax2 = 0.f;
+    if (P32_ABLATE & 512) return;                            // timing-only: everything but the passes
+    constexpr bool DBI = image_double<WM, WN, TM, TN>();
+    constexpr int IMG = WM * 32 * EROW;
+    char* const smem0 = smem;
+    load_res(0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        // (double-buffered: the barrier of pass i + 1 is passed only when every wave has finished reading pass i's image,
+        // which pass i + 2 overwrites)
+        if (i > 0 && !DBI) __syncthreads();
+        smem = smem0 + (DBI ? (i & 1) * IMG : 0);
+        write_tile_row(i, reinterpret_cast<float*>(smem) + (wm * 32) * (EROW / 4) + wn * TN * 32);
+        __syncthreads();
+        f16x8 ch[ITEMS], cl[ITEMS];
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) {
+            // a lane of row r loaded h_j(r) and h_j(r + 1), its partner l_j(r) and l_j(r + 1)
+            ch[k] = __builtin_bit_cast(f16x8, from_below(rh[k], rl[k]));     // row r: own first load; row r + 1: the partner's second
+            cl[k] = __builtin_bit_cast(f16x8, from_above(rl[k], rh[k]));     // row r: the partner's first; row r + 1: own second
+        }
+        if (i + 1 < TM) load_res(i + 1);
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) {
+            const int lr = r_first + k * RSTEP;
+            const int m = row_of(i, k);
+            const float4 x0 = *reinterpret_cast<const float4*>(smem + lr * EROW + g * 32);
+            const float4 x1 = *reinterpret_cast<const float4*>(smem + lr * EROW + g * 32 + 16);
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            f32x2 v2[4] = {{x0.x, x0.y}, {x0.z, x0.w}, {x1.x, x1.y}, {x1.z, x1.w}};
+            const int gd = (m >= b1) + (m >= b2);
+            const float post = gd == 0 ? post0 : (gd == 1 ? post1 : post2);     // exact powers of two
+            const float res_inv = gd == 0 ? resi0 : (gd == 1 ? resi1 : resi2);  // 0 without a residual
+            const float s_out = gd == 0 ? sout0 : (gd == 1 ? sout1 : sout2);
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                                       // packed f32: two channels per instruction
+                const f32x2 scq = {sc[2 * q], sc[2 * q + 1]}, bsq = {bs[2 * q], bs[2 * q + 1]};
+                const f32x2 t = (v2[q] * post) * scq + bsq;
+                v[2 * q] = t.x;
+                v[2 * q + 1] = t.y;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                // residual (h + l) r as two mixed-precision FMAs (h r and l r are exact: r is a power of two)
+                v[q] = fmaf((float)cl[k][q], res_inv, fmaf((float)ch[k][q], res_inv, v[q]));
+                v[q] = fmaxf(v[q], act_lo);
+            }
+            if (sigmoid_on && !(P32_ABLATE & 256)) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = 1.0f / (1.0f + expf(-v[q]));
+            }
+            f16x8 h, l;
+            float vm = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; q += 2) {
+                vm = fmaxf(vm, fmaxf(fabsf(v[q]), fabsf(v[q + 1])));
+                const f32x2 y = f32x2{v[q], v[q + 1]} * s_out;
+                h[q] = (_Float16)y.x;
+                h[q + 1] = (_Float16)y.y;
+                l[q] = (_Float16)fmaf(-(float)h[q], 1.0f, y.x);
+                l[q + 1] = (_Float16)fmaf(-(float)h[q + 1], 1.0f, y.y);
+            }
+            vm = m < p.M ? vm : 0.f;                                            // rows beyond M hold bias only: not part of the tensor
+            vmax0 = fmaxf(vmax0, gd == 0 ? vm : 0.f);
+            vmax1 = fmaxf(vmax1, gd == 1 ? vm : 0.f);
+            vmax2 = fmaxf(vmax2, gd == 2 ? vm : 0.f);
+            const u32x4 hu = __builtin_bit_cast(u32x4, h), lu = __builtin_bit_cast(u32x4, l);
+            const u32x4 d0 = from_below(hu, lu);      // piece of row r's line: row r lanes their h_j, row r + 1 lanes the partner's l_j
+            const u32x4 d1 = from_above(lu, hu);      // piece of row r + 1's line: row r lanes the partner's h_j, row r + 1 lanes their l_j
+            const unsigned off = (unsigned)(m - rs) * cbytes + lofs;
+            if (P32_ABLATE & 64) {
+                asm volatile("" :: "v"(d0), "v"(d1), "v"(off));
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b128(d0, rs_out, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(d1, rs_out, off + cbytes, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        if (d > 0 && (d == 1 ? b1 : b2) >= m0 + BM_) break;            // this tile has no rows of that group (block-uniform)
+        if (g0 + d >= p.groups) break;
+        float vmax = d == 0 ? vmax0 : (d == 1 ? vmax1 : vmax2);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+        float* slot = p.out_meta + 2 * (g0 + d);
+        if (lane == 0 && vmax > *reinterpret_cast<volatile const float*>(slot))
+            atomicMax(reinterpret_cast<unsigned int*>(slot), __float_as_uint(vmax));
+    }
+}
+
+
+constexpr int EPI_GENERIC = 0, EPI_PLANES = 1, EPI_HEAD = 2;
+
+template <int WM, int WN, int TM, int TN, bool M16 = true, int EPI = EPI_PLANES>
 __global__ __launch_bounds__(512, 2) void conv_p32_kernel(const ConvQ p) {
     static_assert(WM * WN == 8, "eight waves");
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -504,6 +726,8 @@ __global__ __launch_bounds__(512, 2) void conv_p32_kernel(const ConvQ p) {
     // ---- K loop: DMA of step t + 1 in flight under the MFMAs of step t; one barrier per step ----
     issue(0, tap, sdelta, 0u);
     P32_ADVANCE();
+    constexpr bool HEAD = EPI == EPI_HEAD;
+    const GroupScales gs = load_group_scales(p, m0, !HEAD && !p.out_f32);     // scalar loads, behind the first DMA
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     for (int t = 0; t < ((P32_ABLATE & 128) ? 1 : p.ksteps); ++t) {
@@ -520,10 +744,16 @@ __global__ __launch_bounds__(512, 2) void conv_p32_kernel(const ConvQ p) {
     }
 #undef P32_ADVANCE
 
-    if constexpr (M16) {
-        p32_epilogue<WM, WN, TM, TN, HEAD>(p, smem, [&](int i, float* e) { write_acc16<TN, BN + 4>(acc16[2 * i], acc16[2 * i + 1], e, lane); }, wm, wn, m0, n0);
+    if constexpr (EPI == EPI_PLANES) {
+        if constexpr (M16) {
+            p32_epilogue_planes<WM, WN, TM, TN>(p, gs, smem, [&](int i, float* e) { write_acc16<TN, BN + 4>(acc16[2 * i], acc16[2 * i + 1], e, lane); }, wm, wn, m0, n0);
+        } else {
+            p32_epilogue_planes<WM, WN, TM, TN>(p, gs, smem, [&](int i, float* e) { write_acc32<TN, BN + 4>(acc[i], e, lane); }, wm, wn, m0, n0);
+        }
+    } else if constexpr (M16) {
+        p32_epilogue<WM, WN, TM, TN, HEAD>(p, gs, smem, [&](int i, float* e) { write_acc16<TN, BN + 4>(acc16[2 * i], acc16[2 * i + 1], e, lane); }, wm, wn, m0, n0);
     } else {
-        p32_epilogue<WM, WN, TM, TN, HEAD>(p, smem, [&](int i, float* e) { write_acc32<TN, BN + 4>(acc[i], e, lane); }, wm, wn, m0, n0);
+        p32_epilogue<WM, WN, TM, TN, HEAD>(p, gs, smem, [&](int i, float* e) { write_acc32<TN, BN + 4>(acc[i], e, lane); }, wm, wn, m0, n0);
     }
 }
 
@@ -680,6 +910,7 @@ __global__ __launch_bounds__(512, 2) void conv_p32_pp_kernel(const ConvQ p) {
     issue_a(0, 0, QA);
     if (grp == 0) issue_b(0, 0, QB);
     P32_ADVANCE();
+    const GroupScales gs = load_group_scales(p, m0, !p.out_f32);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     P32_PHASE_END();
 
@@ -722,7 +953,7 @@ __global__ __launch_bounds__(512, 2) void conv_p32_pp_kernel(const ConvQ p) {
     }
 #undef P32_ADVANCE
 #undef P32_PHASE_END
-    p32_epilogue<WM, WN, TM, TN, false>(p, smem, [&](int i, float* e) { write_acc32<TN, BN + 4>(acc[i], e, lane); }, wm, wn, m0, n0);
+    p32_epilogue<WM, WN, TM, TN, false>(p, gs, smem, [&](int i, float* e) { write_acc32<TN, BN + 4>(acc[i], e, lane); }, wm, wn, m0, n0);
 }
 
 template <int TM, int TN>
@@ -743,15 +974,15 @@ int launch_pp(ConvQ p, hipStream_t st) {
     return DEMIA_OK;
 }
 
-template <int WM, int WN, int TM, int TN, bool M16 = true, bool HEAD = false>
+template <int WM, int WN, int TM, int TN, bool M16 = true, int EPI = EPI_PLANES>
 int launch_q(ConvQ p, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int stages = 2 * (BM + BN) * 128, image = WM * 32 * (BN * 4 + 16);
+    constexpr int stages = 2 * (BM + BN) * 128, image = WM * 32 * (BN * 4 + 16) * ((EPI == EPI_PLANES && image_double<WM, WN, TM, TN>()) ? 2 : 1);
     constexpr int smem = stages > image ? stages : image;
     p.ntn = p.CoutPad / BN;
     p.nwg = p.ntn * cdiv(p.M, BM);
     p.resident = 256 * (160 * 1024 / smem >= 2 ? 2 : 1);
-    auto k = conv_p32_kernel<WM, WN, TM, TN, M16, HEAD>;
+    auto k = conv_p32_kernel<WM, WN, TM, TN, M16, EPI>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -844,16 +1075,35 @@ extern "C" int demia_conv2d_p32(const demia_conv_p32_desc* d, void* stream) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     // tile_hint: 0 = auto (the model above), else one of the instantiated tiles (dev / tuning: scripts/gpu_conv_p32_check.py)
     int tile = d->tile_hint ? d->tile_hint : choose_tile(p.M, d->CoutPad, p.ksteps, d->res_mode != DEMIA_RES_NONE, d->head_n > 0);
+    const bool n256 = d->CoutPad % 256 == 0, n128 = d->CoutPad % 128 == 0;
     if (d->head_n > 0) {
         // the fused head has its own instantiations: 256 x 256, 128 x 256 and 192 x 256
-        if (tile != 1 && tile != 2) tile = 4;
         switch (tile) {
-            case 1: return launch_q<2, 4, 4, 2, true, true>(p, st);
-            case 2: return launch_q<2, 4, 2, 2, true, true>(p, st);
-            default: return launch_q<1, 8, 6, 1, true, true>(p, st);
+            case 1: return launch_q<2, 4, 4, 2, true, EPI_HEAD>(p, st);
+            case 2: return launch_q<2, 4, 2, 2, true, EPI_HEAD>(p, st);
+            default: return launch_q<1, 8, 6, 1, true, EPI_HEAD>(p, st);
         }
     }
-    const bool n256 = d->CoutPad % 256 == 0, n128 = d->CoutPad % 128 == 0;
+    // The straight-line planes epilogue needs whole tiles of channels (Cout % BN == 0) and buffers below 4 GiB; anything else
+    // (f32 outputs, odd channel counts) runs the guarded epilogue, instantiated for the 128 x 128 and the 64-wide tiles only.
+    const int tile_bn = (tile == 9 || tile == 10 || tile == 11) ? 64 : ((tile >= 6 && tile <= 8) || tile == 26 ? 128 : 256);
+    const long out_bytes = 128 + (long)p.M * d->Cout * 4;
+    long res_bytes = 0;
+    if (d->res_mode == DEMIA_RES_SAME) res_bytes = out_bytes;
+    if (d->res_mode == DEMIA_RES_UP2) res_bytes = 128 + (long)d->N * ((d->Ho + 1) / 2) * ((d->Wo + 1) / 2) * d->Cout * 4;
+    const bool planes = !d->out_f32 && d->Cout % tile_bn == 0 && out_bytes < (1L << 32) - 512 && res_bytes < (1L << 32) - 512 &&
+                        (long)(p.M + 256) * d->Cout * 4 + 256 < (1L << 32);
+    p.out_bytes = (unsigned)out_bytes; p.res_bytes = (unsigned)res_bytes;
+    if (!planes) {
+        if (tile != 7 && tile != 9 && tile != 10 && tile != 11 && tile != 21 && tile != 22 && tile != 26) tile = n128 ? 7 : 11;
+        switch (tile) {
+            case 7: DEMIA_REQUIRE(n128, "tile needs CoutPad % 128 == 0"); return launch_q<4, 2, 1, 2, true, EPI_GENERIC>(p, st);
+            case 9: return launch_q<8, 1, 1, 2, true, EPI_GENERIC>(p, st);
+            case 10: return launch_q<4, 2, 2, 1, true, EPI_GENERIC>(p, st);
+            case 11: return launch_q<4, 2, 1, 1, true, EPI_GENERIC>(p, st);
+            default: break;       // the ping-pong kernels keep the guarded epilogue
+        }
+    }
     switch (tile) {
         case 1: DEMIA_REQUIRE(n256, "tile needs CoutPad % 256 == 0"); return launch_q<2, 4, 4, 2>(p, st);   // 256 x 256
         case 2: DEMIA_REQUIRE(n256, "tile needs CoutPad % 256 == 0"); return launch_q<2, 4, 2, 2>(p, st);   // 128 x 256
