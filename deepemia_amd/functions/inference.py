@@ -89,18 +89,45 @@ def imread_bgr(path: str) -> Optional[np.ndarray]:
 _scale_bar_warned = False
 
 
-def detect_scale_bar(image, roi_config=None, dataset_name=None, draw_debug=False) -> Tuple[str, float]:
-    """The OCR scale-bar reader (``src/utils/scalebar_ocr.py``, EasyOCR) is out of scope
-    (SURVEY.md section 2 row 8); this is its documented fallback contract: ``("0", 1.0)``
-    (``scalebar_ocr.py:362-364``, ``inference.py:768-773``) -- unless the operator supplies the calibration:
-    ``scale_bar.um_per_pixel`` (+ optional ``scale_bar.label``) in the dataset / global config or
-    ``DEEPEMIA_UM_PER_PIXEL``.  Logged once per run either way, because every length / area column is in these units."""
-    global _scale_bar_warned
-    cfg = {}
+def get_scalebar_roi_for_dataset(dataset_name: Optional[str] = None) -> dict:
+    """``scalebar_ocr.py:28-70``: ``scale_bar_rois[<dataset>]``, else ``scale_bar_rois.default``, else the built-in ROI."""
+    default_roi = {"x_start_factor": 0.7, "y_start_factor": 0.05, "width_factor": 1, "height_factor": 0.05}
     try:
-        cfg = (get_config(dataset_name=dataset_name) if dataset_name else get_config()).get("scale_bar", {}) or {}
+        rois = get_config(dataset_name=dataset_name).get("scale_bar_rois", {}) or {}
+        if dataset_name and dataset_name in rois:
+            return rois[dataset_name]
+        return rois.get("default", default_roi)
+    except Exception as e:                                                   # same fallback as the reference
+        system_logger.error(f"Error loading scale bar ROI config: {e}")
+        return default_roi
+
+
+def _scale_bar_settings(dataset_name):
+    try:
+        return (get_config(dataset_name=dataset_name) if dataset_name else get_config()).get("scale_bar", {}) or {}
     except Exception:
-        cfg = {}
+        return {}
+
+
+def scale_bar_needs_image(dataset_name=None) -> bool:
+    """True when the bar's LINE has to be found in the image (a label is configured, the calibration is not)."""
+    cfg = _scale_bar_settings(dataset_name)
+    return os.environ.get("DEEPEMIA_UM_PER_PIXEL", cfg.get("um_per_pixel")) is None and cfg.get("label") is not None
+
+
+def detect_scale_bar(image, roi_config=None, intensity_threshold=200, proximity_threshold=50, dataset_name=None,
+                     draw_debug=False) -> Tuple[str, float]:
+    """``scalebar_ocr.py:72-364`` without EasyOCR (out of scope).  Three cases:
+
+    * ``scale_bar.um_per_pixel`` (or ``DEEPEMIA_UM_PER_PIXEL``): the calibration is configured, nothing is detected;
+    * ``scale_bar.label`` (+ optional ``scale_bar.text_center``): the label the OCR would have read is configured and the
+      bar's LINE is found as the reference finds it -- Canny 50/150, HoughLinesP, horizontal / margin / brightness /
+      proximity filters, collinear merge, longest survivor (``deepemia_amd/utils/scalebar.py``, SURVEY 8 f2);
+      ``um_pix = label / length``; thresholds from ``scalebar_thresholds`` with the reference's override rule (:102-115);
+      ``draw_debug`` draws ROI, candidates and the selected line into ``image`` (for ``<img>_scalebar_debug.png``);
+    * neither: the reference's own fallback when the OCR finds nothing, ``("0", 1.0)`` (:362-364), logged once."""
+    global _scale_bar_warned
+    cfg = _scale_bar_settings(dataset_name)
     um = os.environ.get("DEEPEMIA_UM_PER_PIXEL", cfg.get("um_per_pixel"))
     if um is not None:
         um = float(um)
@@ -111,11 +138,58 @@ def detect_scale_bar(image, roi_config=None, dataset_name=None, draw_debug=False
             system_logger.info(f"Scale bar: using the configured calibration {um} um/pixel (label {psum!r}); no OCR")
             _scale_bar_warned = True
         return psum, um
+    if cfg.get("label") is not None and image is not None:
+        from ..utils.scalebar import find_scale_bar_line
+
+        if roi_config is None:
+            roi_config = get_scalebar_roi_for_dataset(dataset_name)
+        merge_gap, min_line_length, edge_margin_factor = 15, 30, 0.1
+        try:
+            th = get_config(dataset_name=dataset_name).get("scalebar_thresholds", {}) or {}
+            if "intensity" in th and intensity_threshold == 200:
+                intensity_threshold = th["intensity"]
+            if "proximity" in th and proximity_threshold == 50:
+                proximity_threshold = th["proximity"]
+            merge_gap = th.get("merge_gap", 15)
+            min_line_length = th.get("min_line_length", 30)
+            edge_margin_factor = th.get("edge_margin_factor", 0.1)
+        except Exception as e:
+            system_logger.warning(f"Could not load thresholds from config: {e}")
+        res = find_scale_bar_line(image, roi_config, cfg["label"], cfg.get("text_center"), intensity_threshold, proximity_threshold,
+                                  merge_gap, min_line_length, edge_margin_factor)
+        if draw_debug:
+            _draw_scale_bar_debug(image, res)
+        if res["line"] is not None:
+            system_logger.info(f"Detected scale bar: {res['psum']} units, {res['length']:.2f} pixels, {res['um_pix']:.4f} units/pixel")
+        else:
+            system_logger.warning("No scale bar line detected near the configured label position.")
+        return res["psum"], res["um_pix"]
     if not _scale_bar_warned:
         system_logger.warning("Scale bar not read (EasyOCR is out of scope): um_pix = 1.0, every length / area column of "
-                              "measurements_results.csv is in PIXELS; set scale_bar.um_per_pixel or DEEPEMIA_UM_PER_PIXEL")
+                              "measurements_results.csv is in PIXELS; set scale_bar.label, scale_bar.um_per_pixel or DEEPEMIA_UM_PER_PIXEL")
         _scale_bar_warned = True
     return "0", 1.0
+
+
+def _draw_scale_bar_debug(image: np.ndarray, res: dict) -> None:
+    """The debug drawing of ``scalebar_ocr.py:139-143,289-300,351-356`` (BGR colours as there: ROI green, candidates cyan, near
+    the ROI edge grey, the selected line red) into ``image`` in place; Pillow rasterises, not OpenCV (no pixel parity)."""
+    from PIL import Image, ImageDraw
+
+    pil = Image.fromarray(np.ascontiguousarray(image[..., ::-1]))
+    d = ImageDraw.Draw(pil)
+    x0, y0, x1, y1 = res["roi"]
+    d.rectangle([x0, y0, x1 - 1, y1 - 1], outline=(0, 255, 0), width=2)
+    for k, sg in enumerate(res["segments"]):
+        col = (128, 128, 128) if sg["near_edge"] else (0, 255, 255)
+        d.line([x0 + sg["x1"], y0 + sg["y1"], x0 + sg["x2"], y0 + sg["y2"]], fill=col, width=1)
+        d.text((x0 + sg["x1"], y0 + sg["y1"] - 12), f"M{k}: {sg['length']:.0f}px, I:{sg['intensity']:.0f}, D:{sg['dist_to_text']:.0f}", fill=col)
+    if res["line"] is not None:
+        d.line(list(res["line"]), fill=(255, 0, 0), width=3)
+        d.text((res["line"][0], res["line"][1] - 24), f"SELECTED: {res['length']:.0f}px", fill=(255, 0, 0))
+    else:
+        d.text((x0, y0 + 30), "SCALE BAR DETECTION FAILED", fill=(255, 0, 0))
+    image[...] = np.asarray(pil)[..., ::-1]
 
 
 def calculate_image_quality_score(image: np.ndarray) -> float:
@@ -183,6 +257,15 @@ class InferencePipeline:
         # N3: weights always come from the import-time GLOBAL config, dict order R50, R101
         self.ensemble_weights = list(gens.get("weights", {"R50": 0.6, "R101": 0.4}).values())
         self.class_specific_settings = inf_settings.get("class_specific_settings", {})
+        # f4, flagged NON-parity: `merge_mode: soft_nms` replaces the 0.4 hard merge of full-image + tile results
+        self.merge_mode = str(inf_settings.get("merge_mode", "smart"))
+        snm = inf_settings.get("soft_nms", {}) or {}
+        self.soft_nms_sigma = float(snm.get("sigma", 0.5))
+        self.soft_nms_score_threshold = float(snm.get("score_threshold", 0.001))
+        if self.merge_mode not in ("smart", "soft_nms"):
+            raise ValueError(f"inference_settings.merge_mode must be 'smart' or 'soft_nms', got {self.merge_mode!r}")
+        if self.merge_mode == "soft_nms":
+            system_logger.warning("merge_mode: soft_nms -- NON-PARITY mode: the reference has no soft-NMS (hard greedy dedup only)")
         self._cache: Dict[Tuple[int, str], List[_Detections]] = {}
         # images per batched forward: l4_performance_optimizations.forward_batch_size / DEEPEMIA_FORWARD_BATCH (default 16:
         # fills 256 CUs on the 50^2 feature maps, 8.6 GiB of activations per 2048^2-tile batch)
@@ -447,6 +530,109 @@ class InferencePipeline:
             self.ops.set_frame_width(w)
         return full_masks, full_scores, full_classes, tile_masks, tile_scores, tile_classes, tile_units
 
+    # ------------------------------------------------------------------ f4: flagged NON-parity modes
+    def soft_nms_merge(self, packed: Optional[torch.Tensor], scores: Sequence[float], classes: Sequence[int],
+                       sigma: float = 0.5, score_threshold: float = 0.001):
+        """Gaussian soft-NMS on MASK IoU (Bodla et al. 2017), per class -- a merge mode that exists in north_star but NOT
+        in the reference (its live path only has hard NMS / hard greedy dedup), so it is opt-in
+        (``inference_settings.merge_mode: soft_nms``) and claims no parity with the reference.  Repeatedly the remaining
+        mask with the highest score is kept and every other remaining mask of its class has its score multiplied by
+        ``exp(-IoU^2 / sigma)``; masks whose score falls below ``score_threshold`` are dropped.  Ties: lower index first.
+        IoUs come from ONE pair-intersection launch over the box-overlapping pairs.  Returns (masks, scores, classes) in
+        the order of selection, scores decayed."""
+        if packed is None or packed.shape[0] == 0:
+            return None, [], []
+        alg = DeviceMaskAlgebra(self.ops, packed)
+        n = alg.n
+        sc = np.asarray(scores, dtype=np.float64).copy()
+        cl = np.asarray(classes)
+        alg.prefetch_overlapping_pairs([[i for i in range(n) if cl[i] == c] for c in sorted(set(cl.tolist()))])
+        alive = sc >= score_threshold
+        order = []
+        while alive.any():
+            cand = np.nonzero(alive)[0]
+            i = int(cand[np.argmax(sc[cand])])           # first maximum = lower index on ties
+            order.append(i)
+            alive[i] = False
+            for j in np.nonzero(alive & (cl == cl[i]))[0]:
+                v = alg.iou(i, int(j))
+                if v > 0.0:
+                    sc[j] *= math.exp(-(v * v) / sigma)
+                    if sc[j] < score_threshold:
+                        alive[j] = False
+        sel = torch.tensor(order, dtype=torch.long, device=self.dev)
+        return packed[sel].contiguous(), [float(sc[i]) for i in order], [int(cl[i]) for i in order]
+
+    def run_adaptive_multiscale_inference(self, model_idx: int, image_key: str, image_dev: torch.Tensor, target_class: int,
+                                          confidence_threshold: float = 0.3, small_classes=frozenset(), iou_threshold: float = 0.7):
+        """The semantics of ``inference.py:1833-1984`` (``run_adaptive_multiscale_inference``) + ``:1986-2064``
+        (``process_single_scale``) as a flagged NON-parity mode: that code is never reached from the reference's
+        ``run_inference``, and its per-scale step is the iterative masking loop, which this build replaces by ONE
+        class pass per scale (a6 + a9..a12).  Kept from the reference: the baseline scales 0.7 / 1.0 / 1.5, the 10 % benefit
+        rule that unlocks 2.0 / 2.5 and 0.5 / 0.6, the 5 % low-yield stop, ``cv2.resize(INTER_LINEAR)`` of the image to
+        ``int(h s) x int(w s)``, the scale-invariant minimum size (``max(3, int(A 5e-6))`` / ``max(25, int(A 1e-4))`` of the
+        ORIGINAL area, times s^2), ``INTER_NEAREST`` back to the original frame and the greedy cross-scale dedup at mask IoU
+        0.4 in descending score order.  Everything runs on the device: resize, predictor, class pass, nearest resize, IoUs."""
+        h, w = int(image_dev.shape[0]), int(image_dev.shape[1])
+        eng = self.predictors[model_idx].engine
+        is_small = target_class in small_classes
+        area0 = h * w
+        base_min = max(3, int(area0 * 0.000005)) if is_small else max(25, int(area0 * 0.0001))
+
+        def single_scale(scale: float):
+            sh, sw = (h, w) if scale == 1.0 else (int(h * scale), int(w * scale))
+            img = image_dev[None] if scale == 1.0 else eng.resize_linear_u8(image_dev[None].contiguous(), sh, sw)
+            det = self._predict_batch(model_idx, f"{image_key}|scale{scale}", img)[0]
+            self.ops.set_frame_width(sw)
+            masks, sc, _ = self._single_model_class_pass(det, target_class, small_classes, confidence_threshold, iou_threshold)
+            if masks is None or masks.shape[0] == 0:
+                return None, []
+            area, _ = self.ops.area_bbox(masks)
+            keep = np.nonzero(area.cpu().numpy() >= int(base_min * (scale ** 2)))[0]
+            if len(keep) == 0:
+                return None, []
+            masks = masks[torch.from_numpy(keep).to(self.dev)].contiguous()
+            if scale != 1.0:
+                masks = self.ops.place_tiles(masks, [0] * len(keep), [0] * len(keep), h, w, h, w, src_w=sw)
+            return masks, [sc[i] for i in keep]
+
+        parts, scores, found = [], [], {}
+
+        def add(scale):
+            m, sc = single_scale(scale)
+            found[scale] = len(sc)
+            return m, sc
+
+        for scale in (0.7, 1.0, 1.5):
+            m, sc = add(scale)
+            if m is not None:
+                parts.append(m)
+                scores.extend(sc)
+        base = found.get(1.0, 0)
+        for unlocked, extra in ((found.get(1.5, 0) > base * 0.1, (2.0, 2.5)), (found.get(0.7, 0) > base * 0.1, (0.5, 0.6))):
+            if not unlocked:
+                continue
+            for scale in extra:
+                m, sc = add(scale)
+                if len(sc) < base * 0.05:
+                    break
+                if m is not None:
+                    parts.append(m)
+                    scores.extend(sc)
+        self.ops.set_frame_width(w)
+        if not parts:
+            return None, [], []
+        packed = torch.cat(parts, dim=0)
+        alg = DeviceMaskAlgebra(self.ops, packed)
+        order = np.argsort(-np.asarray(scores, dtype=np.float64), kind="stable")
+        alg.prefetch_overlapping_pairs([list(range(alg.n))])
+        kept: List[int] = []
+        for idx in order:
+            if not any(alg.iou(int(idx), k) > 0.4 for k in kept):
+                kept.append(int(idx))
+        sel = torch.tensor(kept, dtype=torch.long, device=self.dev)
+        return packed[sel].contiguous(), [scores[i] for i in kept], [target_class] * len(kept)
+
     def _merge_full_and_tiles(self, full_masks, full_scores, full_classes, tile_masks, tile_scores, tile_classes):
         """``inference.py:2452-2472``: full-image results + tile results -> ``deduplicate_masks_smart`` at 0.4 (N4 included)."""
         if isinstance(full_masks, str):        # N4: ndarray + list
@@ -457,6 +643,9 @@ class InferencePipeline:
         if not parts:
             return None, [], []
         packed = torch.cat(parts, dim=0)
+        if self.merge_mode == "soft_nms":        # flagged non-parity mode (f4)
+            return self.soft_nms_merge(packed, list(full_scores) + list(tile_scores), list(full_classes) + list(tile_classes),
+                                       self.soft_nms_sigma, self.soft_nms_score_threshold)
         return self.deduplicate_masks_smart(packed, list(full_scores) + list(tile_scores), list(full_classes) + list(tile_classes), 0.4)
 
     def gather_and_merge(self, locals_by_class: Dict[int, tuple], hw: Tuple[int, int], ensemble_by_class: Dict[int, bool]):
@@ -1136,7 +1325,21 @@ def write_measurements(ops: MaskOps, dedup_results: Dict[str, dict], test_img_pa
             data = dedup_results.get(test_img)
             if data is None:
                 continue   # skipped image: the reference finds no masks for it (dedup_results.get(..., {}))
-            psum, um_pix = detect_scale_bar(None, roi_config=None, dataset_name=dataset_name)   # N8: the second call's values
+            # N8: the values of the measurement phase's own call (inference.py:1046-1057) are the ones the CSV uses
+            im = None
+            if draw_scalebar or scale_bar_needs_image(dataset_name):
+                im = imread_bgr(os.path.join(test_img_path, test_img))
+            if draw_scalebar and im is not None:
+                debug_image = im.copy()
+                psum, um_pix = detect_scale_bar(debug_image, roi_config=None, dataset_name=dataset_name, draw_debug=True)
+                debug_path = os.path.join(output_dir, f"{test_img}_scalebar_debug.png")
+                if not os.path.exists(debug_path):
+                    from PIL import Image
+                    Image.fromarray(np.ascontiguousarray(debug_image[..., ::-1])).save(debug_path)
+                    system_logger.info(f"Saved scalebar debug visualization to {debug_path}")
+                del debug_image
+            else:
+                psum, um_pix = detect_scale_bar(im, roi_config=None, dataset_name=dataset_name)
             packed, classes = data["masks"], data["classes"]
             if packed is None or packed.shape[0] == 0:
                 continue
@@ -1144,7 +1347,8 @@ def write_measurements(ops: MaskOps, dedup_results: Dict[str, dict], test_img_pa
             ops.set_frame_width(wd)
             min_area = max(5, h * wd * 0.000005 * 0.05)
             recs = ops.contours(packed, max_contours=256, um_pix=um_pix)
-            im = imread_bgr(os.path.join(test_img_path, test_img)) if (visualize or measure_contrast) else None
+            if im is None and (visualize or measure_contrast):
+                im = imread_bgr(os.path.join(test_img_path, test_img))
             contrast = [(None, None, None)] * int(packed.shape[0])
             if measure_contrast and im is not None:
                 # measurements.py:195-215: gray levels under the whole instance mask; the histogram is a device reduction

@@ -8,6 +8,7 @@ elsewhere.  Dataset blocks are folded into the global dict as the reference does
   ``inference_overrides``  -> deep-merged into ``inference_settings``
   ``scale_bar_roi``        -> ``scale_bar_rois[<dataset>]``
   ``scalebar_thresholds``  -> deep-merged
+  ``scale_bar``            -> deep-merged (not in the reference: the label / calibration that replaces the OCR)
   ``spatial_constraints``  -> ``inference_settings.spatial_constraints[<dataset>]``
   ``rcnn_hyperparameters.best_R50 / best_R101`` -> ``rcnn_hyperparameters.best.R50 / R101``
 """
@@ -87,6 +88,8 @@ def get_config(dataset_name: str = None) -> Dict[str, Any]:
         merged["scale_bar_rois"][dataset_name] = ds["scale_bar_roi"]
     if "scalebar_thresholds" in ds:
         merged["scalebar_thresholds"] = deep_merge(merged.get("scalebar_thresholds", {}), ds["scalebar_thresholds"])
+    if "scale_bar" in ds:        # this build's extension (no OCR): label / text_center / um_per_pixel per dataset
+        merged["scale_bar"] = deep_merge(merged.get("scale_bar", {}) or {}, ds["scale_bar"])
     if "spatial_constraints" in ds:
         inf = merged.setdefault("inference_settings", {})
         if "spatial_constraints" not in inf:

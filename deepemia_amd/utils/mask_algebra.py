@@ -127,6 +127,11 @@ class DeviceMaskAlgebra:
     def union(self, i: int, j: int) -> int:
         return int(self.area[i]) + int(self.area[j]) - self.inter(i, j)
 
+    def iou(self, i: int, j: int) -> float:
+        """``iou`` of inference.py:422-435 from the integer counts."""
+        u = self.union(i, j)
+        return self.inter(i, j) / u if u > 0 else 0
+
 
 class AlgebraView:
     """Index-translated window on a :class:`DeviceMaskAlgebra` (what the spatial-constraint pass needs of it)."""

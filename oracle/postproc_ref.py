@@ -917,3 +917,44 @@ def apply_spatial_constraints(masks, scores, classes, cfg: dict):
         keep = [i for i in range(len(masks)) if i not in rem]
         masks, scores, classes = [masks[i] for i in keep], [scores[i] for i in keep], [classes[i] for i in keep]
     return masks, scores, classes
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# f4: dense twins of the two flagged NON-parity modes of the product (they exist in north_star, not in the reference's
+# live path -- SURVEY N1 / N2); checkers of the product's device versions, nothing else.
+def soft_nms_masks(masks: Sequence[np.ndarray], scores: Sequence[float], classes: Sequence[int], sigma: float = 0.5,
+                   score_threshold: float = 0.001):
+    """Gaussian soft-NMS on mask IoU, per class (Bodla et al. 2017); ties: lower index first.  Returns the kept indices in
+    the order of selection and their decayed scores."""
+    import math
+    sc = [float(s) for s in scores]
+    alive = [s >= score_threshold for s in sc]
+    order = []
+    while any(alive):
+        i = max((k for k in range(len(sc)) if alive[k]), key=lambda k: (sc[k], -k))
+        order.append(i)
+        alive[i] = False
+        for j in range(len(sc)):
+            if alive[j] and classes[j] == classes[i]:
+                v = iou(np.asarray(masks[i]) > 0, np.asarray(masks[j]) > 0)
+                if v > 0:
+                    sc[j] *= math.exp(-(v * v) / sigma)
+                    if sc[j] < score_threshold:
+                        alive[j] = False
+    return order, [sc[i] for i in order]
+
+
+def multiscale_merge(per_scale: Dict[float, Tuple[List[np.ndarray], List[float]]], order_of_scales: Sequence[float]):
+    """The cross-scale step of inference.py:1951-1977: all masks (already in the original frame) in descending score order
+    (stable), a mask is kept unless its IoU with an already kept one exceeds 0.4."""
+    masks, scores = [], []
+    for s in order_of_scales:
+        m, sc = per_scale[s]
+        masks += list(m)
+        scores += list(sc)
+    order = np.argsort(-np.asarray(scores, dtype=np.float64), kind="stable")
+    kept = []
+    for idx in order:
+        if not any(iou(masks[idx], masks[k]) > 0.4 for k in kept):
+            kept.append(int(idx))
+    return [masks[k] for k in kept], [scores[k] for k in kept]

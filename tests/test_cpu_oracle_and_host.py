@@ -425,3 +425,89 @@ def test_p32_planes_roundtrip_and_weight_tiling():
     assert tuple(tiled.shape) == (2, 2, 9, 64, 2, 32)
     for (p, co, kh, kw, ci) in [(0, 0, 0, 0, 0), (1, 5, 2, 1, 31), (0, 64, 1, 2, 32), (1, 127, 2, 2, 63), (0, 70, 0, 1, 40)]:
         assert tiled[co // 64, ci // 32, kh * 3 + kw, co % 64, p, ci % 32] == planes[p, co, kh, kw, ci]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the scale bar's LINE without OCR (Canny + HoughLinesP + collinear merge, label from the configuration)
+def _scalebar_roi_image(seed=0, w=180, h=56, bar=(30, 34, 96, 5), noise=6.0):
+    """A dark SEM-like strip with a bright bar (x, y, length, thickness), a blocky 'label' and a faint diagonal scratch."""
+    g = np.random.default_rng(seed)
+    img = np.full((h, w), 40.0) + g.normal(0.0, noise, (h, w))
+    x, y, L, t = bar
+    img[y:y + t, x:x + L] = 235.0 + g.normal(0.0, 2.0, (t, L))
+    for k, cx in enumerate(range(60, 100, 9)):                      # digits as small bright blocks above the bar
+        img[12:22, cx:cx + 5 + (k & 1)] = 225.0
+    for k in range(40):                                             # a scratch that must not win
+        img[5 + k // 2, 130 + k] = 140.0
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def test_scalebar_canny_and_houghlinesp_numpy_versions_equal_the_literal_loops():
+    from deepemia_amd.utils import scalebar as S
+    from oracle import scalebar_ref as R
+
+    for seed, noise in ((0, 6.0), (1, 12.0), (2, 0.0)):
+        roi = _scalebar_roi_image(seed, noise=noise)
+        e_prod, e_ref = S.canny(roi, 50, 150), R.canny(roi, 50, 150)
+        np.testing.assert_array_equal(e_prod, e_ref)
+        assert 50 < int((e_prod > 0).sum()) < roi.size // 4
+        l_prod = S.hough_lines_p(e_prod, 1, np.pi / 180, 50, 20, 10)
+        l_ref = R.hough_lines_p(e_ref, 1, np.pi / 180, 50, 20, 10)
+        assert l_prod == l_ref and len(l_prod) >= 2                 # same segments in the same order of discovery
+    # thresholds given in the wrong order are swapped (canny.cpp), a flat image has no edges, and so no lines
+    np.testing.assert_array_equal(S.canny(roi, 150, 50), S.canny(roi, 50, 150))
+    flat = np.full((20, 30), 77, dtype=np.uint8)
+    assert not S.canny(flat, 50, 150).any() and S.hough_lines_p(S.canny(flat, 50, 150)) == []
+    # cv::RNG((uint64)-1): the multiply-with-carry recurrence, first draws written out by hand
+    r = S.CvRNG()
+    s1 = (0xFFFFFFFF * 4164903690 + 0xFFFFFFFF) & 0xFFFFFFFFFFFFFFFF
+    assert r.next() == s1 & 0xFFFFFFFF and r.state == s1
+    assert S.CvRNG().uniform(0, 1000) == (s1 & 0xFFFFFFFF) % 1000 and S.CvRNG().uniform(5, 5) == 5
+
+
+def test_scalebar_line_selection_merge_and_calibration(monkeypatch):
+    from deepemia_amd.utils import scalebar as S
+    from deepemia_amd.functions import inference as I
+    from oracle import scalebar_ref as R
+
+    # merge_collinear_segments: product vs the reference transcription, and a hand case
+    segs = [dict(x1=10, y1=20, x2=40, y2=21, length=30.0, intensity=200.0, dist_to_text=12.0, line_idx=0),
+            dict(x1=48, y1=22, x2=90, y2=22, length=42.0, intensity=220.0, dist_to_text=30.0, line_idx=1),
+            dict(x1=120, y1=22, x2=150, y2=22, length=30.0, intensity=90.0, dist_to_text=70.0, line_idx=2),
+            dict(x1=60, y1=40, x2=20, y2=40, length=40.0, intensity=50.0, dist_to_text=5.0, line_idx=3)]
+    got, want = S.merge_collinear_segments(segs, 15), R.merge_collinear_segments(segs, 15)
+    assert got == want and len(got) == 4                            # sorted by left end: 10 | 20 | 48 | 120; y offsets / gaps split them
+    two = S.merge_collinear_segments(segs[:2], 15)
+    assert len(two) == 1 and (two[0]["x1"], two[0]["x2"], two[0]["y1"], two[0]["y2"]) == (10, 90, 21, 21)
+    assert abs(two[0]["length"] - 80.0) < 1e-12 and abs(two[0]["intensity"] - (200 * 30 + 220 * 42) / 72) < 1e-12
+
+    # the whole detector on a synthetic micrograph: bar of 96 px labelled "500" in the ROI of the default config
+    H, W = 400, 600
+    img = np.full((H, W, 3), 35, dtype=np.uint8)
+    roi_cfg = {"x_start_factor": 0.7, "y_start_factor": 0.05, "width_factor": 1, "height_factor": 0.14}
+    x0, y0 = int(W * 0.7), int(H * 0.05)
+    roi = _scalebar_roi_image(3, w=W - x0, h=int(H * 0.14))
+    img[y0:y0 + roi.shape[0], x0:, :] = roi[:, :, None]
+    res = S.find_scale_bar_line(img, roi_cfg, "500 nm", text_center=(80, 17), intensity_threshold=100, proximity_threshold=100)
+    assert res["psum"] == "500" and res["line"] is not None
+    lx1, ly1, lx2, ly2 = res["line"]
+    assert abs(abs(lx2 - lx1) - 96) <= 3 and abs(ly1 - ly2) <= 1 and y0 + 32 <= ly1 <= y0 + 41 and x0 + 27 <= min(lx1, lx2) <= x0 + 33
+    assert abs(res["um_pix"] - 500.0 / res["length"]) < 1e-12 and 4.9 < res["um_pix"] < 5.5
+    # too strict a brightness threshold or a label without digits: the reference's fallback
+    assert S.find_scale_bar_line(img, roi_cfg, "500", (80, 17), intensity_threshold=250)["line"] is None
+    assert S.find_scale_bar_line(img, roi_cfg, "nm", (80, 17))["psum"] == "0"
+
+    # detect_scale_bar: configured label -> line detection (+ debug drawing); configured calibration wins; neither -> ("0", 1.0)
+    monkeypatch.delenv("DEEPEMIA_UM_PER_PIXEL", raising=False)
+    monkeypatch.setattr(I, "get_scalebar_roi_for_dataset", lambda name=None: roi_cfg)
+    monkeypatch.setattr(I, "_scale_bar_settings", lambda name: {"label": "500", "text_center": [80, 17]})
+    assert I.scale_bar_needs_image("x")
+    psum, um = I.detect_scale_bar(img.copy(), dataset_name=None, intensity_threshold=100, proximity_threshold=100)
+    assert psum == "500" and abs(um - res["um_pix"]) < 1e-12
+    dbg = img.copy()
+    I.detect_scale_bar(dbg, intensity_threshold=100, proximity_threshold=100, draw_debug=True)
+    assert (dbg != img).any() and tuple(dbg[ly1, (lx1 + lx2) // 2]) == (0, 0, 255)          # the selected line, red in BGR
+    monkeypatch.setattr(I, "_scale_bar_settings", lambda name: {"label": "500", "um_per_pixel": 0.25})
+    assert I.detect_scale_bar(None) == ("500", 0.25) and not I.scale_bar_needs_image("x")
+    monkeypatch.setattr(I, "_scale_bar_settings", lambda name: {})
+    assert I.detect_scale_bar(img) == ("0", 1.0)

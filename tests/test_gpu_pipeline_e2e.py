@@ -199,6 +199,57 @@ def test_cli_inference_matches_oracle_pipeline(case, tmp_path, monkeypatch, gpu_
     _compare(split, images, ref_rows, ref_masks, contrast=auto)
 
 
+def test_cli_scale_bar_line_with_configured_label_scales_the_csv(tmp_path, monkeypatch, gpu_device):
+    """SURVEY 8 f2 + a20: the label is configured (`scale_bar.label`), the bar's line is found in the image (Canny + HoughLinesP
+    + merge, deepemia_amd/utils/scalebar.py), `um_pix = label / length` scales every length column, the scale-bar column
+    carries the label, and `--draw-scalebar` writes <img>_scalebar_debug.png."""
+    import main as cli
+    from deepemia_amd.utils import config as C
+    from deepemia_amd.functions import inference as I
+
+    tile = {"tile_size": 512, "overlap_ratio": 0.0, "upscale_factor": 1.0, "edge_filter_enabled": True}
+    inf = {"confidence_mode": "manual",
+           "class_specific_settings": {"class_0": {"confidence_threshold": 0.3, "iou_threshold": 0.6, "min_size": 25},
+                                       "class_1": {"confidence_threshold": 0.35, "iou_threshold": 0.5, "min_size": 5}},
+           "tile_settings": tile, "spatial_constraints": {"enabled": False}}
+
+    def run(root, ds_cfg, extra):
+        cfgdir, split, _, images = _write_tree(root, [50], 0.5, 6.0, 1, 512, ds_cfg)
+        inf_dir = root / "DATASET" / "INFERENCE"
+        for name, img in images.items():                     # paint a 120-px bar and a blocky label into the ROI
+            img = img.copy()
+            img[24:64, 300:500] = 30
+            img[46:51, 330:450] = 240
+            for cx in range(360, 420, 10):
+                img[30:40, cx:cx + 6] = 230
+            Image.fromarray(img[:, :, ::-1]).save(inf_dir / name)
+        monkeypatch.setenv("DEEPEMIA_CONFIG_DIR", str(cfgdir))
+        monkeypatch.setenv("DEEPEMIA_OFFLINE", "1")
+        monkeypatch.chdir(root)
+        C.reset_cache()
+        I._scale_bar_warned = False
+        assert cli.main(["--task", "inference", "--dataset_name", DATASET, "--threshold", "0.3", "--no-gpu-check"] + extra) == 0
+        C.reset_cache()
+        return split, list(csv.reader(open(split / "measurements_results.csv")))[1:]
+
+    roi = {"x_start_factor": 0.55, "y_start_factor": 0.04, "width_factor": 1, "height_factor": 0.1}
+    (tmp_path / "a").mkdir()
+    (tmp_path / "b").mkdir()
+    _, plain = run(tmp_path / "a", {"inference_overrides": inf, "scale_bar_roi": roi}, [])
+    split, scaled = run(tmp_path / "b", {"inference_overrides": inf, "scale_bar_roi": roi,
+                                         "scalebar_thresholds": {"intensity": 100, "proximity": 100},
+                                         "scale_bar": {"label": "600 nm", "text_center": [110, 14]}}, ["--draw-scalebar"])
+    assert len(plain) == len(scaled) > 3
+    assert all(r[18] == "0" for r in plain) and all(r[18] == "600" for r in scaled)
+    ratios = [float(b[6]) / float(a[6]) for a, b in zip(plain, scaled) if float(a[6]) > 0]          # C. Length: pixels vs units
+    um = ratios[0]
+    assert 600.0 / 123 <= um <= 600.0 / 117 and max(abs(r - um) for r in ratios) < 1e-9 * um      # the 120-px bar, one factor for all rows
+    for a, b in zip(plain, scaled):                                                                 # shape ratios do not scale
+        assert abs(float(a[9]) - float(b[9])) < 1e-9 and abs(float(a[10]) - float(b[10])) < 1e-9
+    dbg = np.asarray(Image.open(split / "em_0.tif_scalebar_debug.png"))
+    assert dbg.shape == (512, 512, 3) and (dbg[48, 340:440] == (255, 0, 0)).all()                  # the selected line, drawn red
+
+
 @pytest.mark.parametrize("models", ["single_r50", "ensemble_r50_r101"])
 def test_batched_tile_pipeline_equals_tile_by_tile(gpu_device, models):
     """process_tile_batch launches every kernel once for all tiles (segment-aware); it must give exactly what the
