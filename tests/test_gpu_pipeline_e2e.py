@@ -243,9 +243,11 @@ def test_cli_scale_bar_line_with_configured_label_scales_the_csv(tmp_path, monke
     assert all(r[18] == "0" for r in plain) and all(r[18] == "600" for r in scaled)
     ratios = [float(b[6]) / float(a[6]) for a, b in zip(plain, scaled) if float(a[6]) > 0]          # C. Length: pixels vs units
     um = ratios[0]
-    assert 600.0 / 123 <= um <= 600.0 / 117 and max(abs(r - um) for r in ratios) < 1e-9 * um      # the 120-px bar, one factor for all rows
-    for a, b in zip(plain, scaled):                                                                 # shape ratios do not scale
-        assert abs(float(a[9]) - float(b[9])) < 1e-9 and abs(float(a[10]) - float(b[10])) < 1e-9
+    assert 600.0 / 123 <= um <= 600.0 / 117 and max(abs(r - um) for r in ratios) < 2e-6 * um      # the 120-px bar, one factor for all rows
+    for a, b in zip(plain, scaled):
+        # aspect ratio and roundness do not scale; circularity and sphericity DO, bug for bug (`* um_pix`, measurements.py:165-175)
+        assert abs(float(a[9]) - float(b[9])) < 1e-6 * max(1.0, abs(float(a[9]))) and abs(float(a[13]) - float(b[13])) < 1e-6
+        assert abs(float(b[10]) - um * float(a[10])) < 2e-6 * um and abs(float(b[14]) - um * float(a[14])) < 2e-6 * um
     dbg = np.asarray(Image.open(split / "em_0.tif_scalebar_debug.png"))
     assert dbg.shape == (512, 512, 3) and (dbg[48, 340:440] == (255, 0, 0)).all()                  # the selected line, drawn red
 
