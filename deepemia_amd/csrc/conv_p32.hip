@@ -543,8 +543,9 @@ __device__ __forceinline__ void p32_epilogue_planes(const ConvQ& p, const GroupS
 
 constexpr int EPI_GENERIC = 0, EPI_PLANES = 1, EPI_HEAD = 2;
 
-template <int WM, int WN, int TM, int TN, bool M16 = true, int EPI = EPI_PLANES>
+template <int WM, int WN, int TM, int TN, bool M16 = true, int EPI = EPI_PLANES, int NST = 2>
 __global__ __launch_bounds__(512, 2) void conv_p32_kernel(const ConvQ p) {
+    static_assert(NST == 2 || NST == 3, "two or three LDS stages");
     static_assert(WM * WN == 8, "eight waves");
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int STAGE = (BM + BN) * 128;
@@ -723,24 +724,49 @@ __global__ __launch_bounds__(512, 2) void conv_p32_kernel(const ConvQ p) {
         }
     };
 
-    // ---- K loop: DMA of step t + 1 in flight under the MFMAs of step t; one barrier per step ----
+    // ---- K loop: DMA of step t + 1 (NST = 3: also t + 2) in flight under the MFMAs of step t; one barrier per step ----
+    // NST = 3 (tiles whose three stages fit the 160 KiB): the request for step t + 2 goes out at step t, so an operand has
+    // TWO steps of MFMA time to arrive -- a 1x1 layer touches every line for the first time, and on a 160 x 256 tile one
+    // step (~0.6 us) is shorter than an HBM round trip under load.  Loads complete in order, so `s_waitcnt vmcnt(n)` with
+    // n = the DMA instructions this wave issued LAST leaves exactly the newest request outstanding.
+    constexpr int N_LAST = QB + QA, N_LAST_SHORT = QB + QA - 1;          // per wave and issue (the last A round is partial)
+    const bool short_wave = !A_EVEN && wave + 8 * (QA - 1) >= NIA;
+    auto wait_all_but_last_issue = [&]() {
+        if (short_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_LAST_SHORT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_LAST) : "memory");
+    };
     issue(0, tap, sdelta, 0u);
     P32_ADVANCE();
+    bool two_ahead = false;
+    if (NST == 3 && p.ksteps > 1 && !(P32_ABLATE & 128)) {
+        issue(1, tap, sdelta, (unsigned)tstep * 8192u);
+        P32_ADVANCE();
+        two_ahead = true;
+    }
     constexpr bool HEAD = EPI == EPI_HEAD;
     const GroupScales gs = load_group_scales(p, m0, !HEAD && !p.out_f32);     // scalar loads, behind the first DMA
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (two_ahead) wait_all_but_last_issue();
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    int st = 0;
     for (int t = 0; t < ((P32_ABLATE & 128) ? 1 : p.ksteps); ++t) {
-        const int st = t & 1;
-        if (t + 1 < p.ksteps) {                   // that stage was last read before the previous barrier
-            issue(st ^ 1, tap, sdelta, (unsigned)tstep * 8192u);
+        const int st_issue = NST == 2 ? (st ^ 1) : (st == 0 ? 2 : st - 1);      // (t + NST - 1) % NST
+        const bool more = t + NST - 1 < p.ksteps;
+        if (more) {                               // that stage was last read before the previous barrier
+            issue(st_issue, tap, sdelta, (unsigned)tstep * 8192u);
             P32_ADVANCE();
         }
         compute(st);
         // Before the barrier every wave has (a) seen its own DMA pieces of step t + 1 land and (b) got ALL its fragment
         // reads of this stage back: the barrier is what allows the other waves to start refilling the stage, and a read
         // still queued in the LDS when a fast DMA from L2 lands would return the step-after-next's operands.
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (NST == 3 && more) {
+            wait_all_but_last_issue();
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        st = NST == 2 ? (st ^ 1) : (st == 2 ? 0 : st + 1);
     }
 #undef P32_ADVANCE
 
@@ -974,15 +1000,16 @@ int launch_pp(ConvQ p, hipStream_t st) {
     return DEMIA_OK;
 }
 
-template <int WM, int WN, int TM, int TN, bool M16 = true, int EPI = EPI_PLANES>
+template <int WM, int WN, int TM, int TN, bool M16 = true, int EPI = EPI_PLANES, int NST = 2>
 int launch_q(ConvQ p, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int stages = 2 * (BM + BN) * 128, image = WM * 32 * (BN * 4 + 16) * ((EPI == EPI_PLANES && image_double<WM, WN, TM, TN>()) ? 2 : 1);
+    constexpr int stages = NST * (BM + BN) * 128, image = WM * 32 * (BN * 4 + 16) * ((EPI == EPI_PLANES && image_double<WM, WN, TM, TN>()) ? 2 : 1);
+    static_assert(stages <= 160 * 1024, "LDS");
     constexpr int smem = stages > image ? stages : image;
     p.ntn = p.CoutPad / BN;
     p.nwg = p.ntn * cdiv(p.M, BM);
     p.resident = 256 * (160 * 1024 / smem >= 2 ? 2 : 1);
-    auto k = conv_p32_kernel<WM, WN, TM, TN, M16, EPI>;
+    auto k = conv_p32_kernel<WM, WN, TM, TN, M16, EPI, NST>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -1086,7 +1113,7 @@ extern "C" int demia_conv2d_p32(const demia_conv_p32_desc* d, void* stream) {
     }
     // The straight-line planes epilogue needs whole tiles of channels (Cout % BN == 0) and buffers below 4 GiB; anything else
     // (f32 outputs, odd channel counts) runs the guarded epilogue, instantiated for the 128 x 128 and the 64-wide tiles only.
-    const int tile_bn = (tile == 9 || tile == 10 || tile == 11) ? 64 : ((tile >= 6 && tile <= 8) || tile == 26 ? 128 : 256);
+    const int tile_bn = (tile == 9 || tile == 10 || tile == 11 || tile == 49) ? 64 : ((tile >= 6 && tile <= 8) || tile == 26 ? 128 : 256);
     const long out_bytes = 128 + (long)p.M * d->Cout * 4;
     long res_bytes = 0;
     if (d->res_mode == DEMIA_RES_SAME) res_bytes = out_bytes;
@@ -1118,6 +1145,12 @@ extern "C" int demia_conv2d_p32(const demia_conv_p32_desc* d, void* stream) {
         case 11: return launch_q<4, 2, 1, 1>(p, st);                                                          // 128 x 64
         case 12: DEMIA_REQUIRE(n256, "tile needs CoutPad % 256 == 0"); return launch_q<1, 8, 5, 1>(p, st);   // 160 x 256
         case 13: DEMIA_REQUIRE(n256, "tile needs CoutPad % 256 == 0"); return launch_q<1, 8, 7, 1>(p, st);   // 224 x 256
+        // three LDS stages (request two K-steps ahead): measured within +-3 % of the two-stage tiles on every R101 layer --
+        // the K loop of the short-K layers is bound by LDS bandwidth (every wave of a 1 x 8 wave grid reads ALL A rows), not
+        // by how far ahead the operands are requested; kept as tile hints for A/B only
+        case 42: DEMIA_REQUIRE(n256, "tile needs CoutPad % 256 == 0"); return launch_q<2, 4, 2, 2, true, EPI_PLANES, 3>(p, st);   // 128 x 256
+        case 52: DEMIA_REQUIRE(n256, "tile needs CoutPad % 256 == 0"); return launch_q<1, 8, 5, 1, true, EPI_PLANES, 3>(p, st);   // 160 x 256
+        case 49: return launch_q<8, 1, 1, 2, true, EPI_PLANES, 3>(p, st);                                                           // 256 x 64
         case 31: DEMIA_REQUIRE(n256, "tile needs CoutPad % 256 == 0"); return launch_q<2, 4, 4, 2, false>(p, st);  // 256 x 256, 32x32x16 MFMAs (A/B)
         case 34: DEMIA_REQUIRE(n256, "tile needs CoutPad % 256 == 0"); return launch_q<1, 8, 6, 1, false>(p, st);  // 192 x 256, 32x32x16 MFMAs (A/B)
         case 21: DEMIA_REQUIRE(n256, "tile needs CoutPad % 256 == 0"); return launch_pp<4, 2>(p, st);        // 256 x 256, ping-pong
