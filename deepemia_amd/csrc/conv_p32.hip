@@ -1145,6 +1145,7 @@ extern "C" int demia_conv2d_p32(const demia_conv_p32_desc* d, void* stream) {
         case 11: return launch_q<4, 2, 1, 1>(p, st);                                                          // 128 x 64
         case 12: DEMIA_REQUIRE(n256, "tile needs CoutPad % 256 == 0"); return launch_q<1, 8, 5, 1>(p, st);   // 160 x 256
         case 13: DEMIA_REQUIRE(n256, "tile needs CoutPad % 256 == 0"); return launch_q<1, 8, 7, 1>(p, st);   // 224 x 256
+        case 14: DEMIA_REQUIRE(n256, "tile needs CoutPad % 256 == 0"); return launch_q<2, 4, 3, 2>(p, st);   // 192 x 256, 2 x 4 waves
         // three LDS stages (request two K-steps ahead): measured within +-3 % of the two-stage tiles on every R101 layer --
         // the K loop of the short-K layers is bound by LDS bandwidth (every wave of a 1 x 8 wave grid reads ALL A rows), not
         // by how far ahead the operands are requested; kept as tile hints for A/B only

@@ -18,8 +18,11 @@ pmc() { # name, counters...
     timeout -k 10 240 rocprofv3 --pmc "$@" --output-format csv -d $O/pmc_$n -o p -- python3 $R/bench.py --forward-only --eager --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_$n.json 2> $O/pmc_$n.err || { tail -5 $O/pmc_$n.err; return 1; }
 }
 pmc fetch FETCH_SIZE && pmc write WRITE_SIZE && pmc sq SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE \
-    && pmc tcc TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE
+    && pmc tcc TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE \
+    && pmc lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
 rc=$?
+echo "[collect] per-layer conv timings"
+( cd $R && timeout -k 10 200 python3 scripts/gpu_conv_layers.py f16x2 16 $O/conv_layers.csv > $O/conv_layers.err 2>&1 ) || tail -3 $O/conv_layers.err
 # keep what travels back small: the per-dispatch counter tables and the stats tables only
 find $O -name "*.csv" -size +30M -delete
 find $O -type f ! -name "*.csv" ! -name "*.json" ! -name "*.err" -delete

@@ -1,4 +1,5 @@
-"""Dev script: per-conv-launch achieved TFLOP/s (R101, 2048^2, B tiles)."""
+"""Per-layer-shape conv timings (HIP events around every launch of three forwards, R101, 2048^2, B tiles): achieved
+TFLOP/s f32-equivalent and algorithmic GB/s.  usage: gpu_conv_layers.py <precision> <batch> [csv path]"""
 import sys, numpy as np, torch
 sys.path.insert(0, '.')
 from deepemia_amd import synth, engine as E, _lib
@@ -37,3 +38,15 @@ for key, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     bm, bn = 128, (128 if co >= 128 else (64 if co >= 64 else 32))
     blocks = -(-M // bm) * -(-((co + 31) // 32 * 32) // bn)
     print(f'M={M:7d} Cout={co:5d} K={K:6d} k{kh} s{st} x{a[0]:3d} time={a[1]:7.3f} ms ({a[1]/tot_t*100:4.1f}%) {a[2]/a[1]/1e9:7.1f} TF/s blocks={blocks}')
+if len(sys.argv) > 3:
+    import csv
+    with open(sys.argv[3], 'w', newline='') as f:
+        w = csv.writer(f)
+        w.writerow(['M_rows', 'Cout', 'K', 'kernel', 'stride', 'launches_per_forward', 'us_per_launch', 'share_of_conv_time', 'tflops_f32_equivalent',
+                    'frac_of_833_roof', 'algorithmic_GB_per_s'])
+        for key, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            M, co, K, kh, st = key
+            by = (M * st * st * (K // (kh * kh)) + M * co) * 4.0      # input pixels once (stride^2 x the output rows) + output once; weights negligible
+            w.writerow([M, co, K, f'{kh}x{kh}', st, a[0], round(a[1] / a[0] * 1e3, 1), round(a[1] / tot_t, 4), round(a[2] / a[1] / 1e9, 1),
+                        round(a[2] / a[1] / 1e9 / 833.33, 3), round(by * a[0] / a[1] / 1e6, 0)])
+        w.writerow(['total', '', '', '', '', sum(a[0] for a in agg.values()), '', 1.0, round(tot_f / tot_t / 1e9, 1), round(tot_f / tot_t / 1e9 / 833.33, 3), ''])

@@ -67,7 +67,17 @@ rec = {"kernel": kernel, "head": head, "launches": n,
 if tcc:
     h, m = sum(d.get("TCC_HIT_sum", 0.0) for d in tcc.values()), sum(d.get("TCC_MISS_sum", 0.0) for d in tcc.values())
     rec["l2_hit_frac"] = h / max(h + m, 1.0)
+lds = table("lds")
+if lds:
+    t = {k: sum(d.get(k, 0.0) for d in lds.values()) for k in ("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS",
+                                                              "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR")}
+    rec["lds_bank_conflict_frac"] = t["SQ_LDS_BANK_CONFLICT"] / max(t["SQ_LDS_IDX_ACTIVE"], 1.0)
+    rec["lds_idx_active_frac"] = t["SQ_LDS_IDX_ACTIVE"] / (cyc * 256.0)        # LDS pipe busy cycles per CU and GPU cycle
+    rec["insts_per_launch"] = {k[9:].lower(): v / len(lds) for k, v in t.items() if k.startswith("SQ_INSTS_")}
+    rec["command_lds"] = "--pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR (same command)"
 (DST / f"{tag}_conv_{prec}_sq.json").write_text(json.dumps(rec, indent=1) + "\n")
+if (SRC / "conv_layers.csv").exists():
+    shutil.copy(SRC / "conv_layers.csv", DST / f"{tag}_conv_layers_{prec}.csv")
 
 # per kernel instantiation and grid: dispatch ids are the same sequence in every pass (same command, same order of launches)
 groups = defaultdict(lambda: defaultdict(float))
