@@ -298,6 +298,40 @@ __global__ __launch_bounds__(256) void crop_copy_kernel(uint32_t* masks, const i
     }
 }
 
+// dst[i] = src[index[i]] for masks that are zero outside their bbox: the destination plane is WRITTEN once (zeros outside the
+// box, the source words inside it) and only the box is READ -- half the traffic of a plane-to-plane gather (512 KiB read +
+// 512 KiB written per 2048^2 mask), and no torch index kernel between two stages of the mask path.
+// grid (M, row chunks); a thread writes four words (16 bytes) at a time.
+__global__ __launch_bounds__(256) void gather_regions_kernel(const uint32_t* __restrict__ src, const long* __restrict__ index,
+                                                             const int* __restrict__ bbox, uint32_t* __restrict__ dst, int H, int wpr,
+                                                             int rows_per_block) {
+    const int m = blockIdx.x;
+    const int y0 = bbox[m * 4 + 0], x0 = bbox[m * 4 + 1], y1 = bbox[m * 4 + 2], x1 = bbox[m * 4 + 3];
+    const int c0 = x0 >> 5, c1 = x1 >> 5;
+    const uint32_t* sp = src + index[m] * (long)H * wpr;
+    uint32_t* dp = dst + (long)m * H * wpr;
+    const int q4 = (wpr + 3) >> 2;                          // 4-word groups per row
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(r0 + rows_per_block, H);
+    const bool vec = (wpr & 3) == 0;
+    for (int t = threadIdx.x; t < (r1 - r0) * q4; t += blockDim.x) {
+        const int ry = r0 + t / q4, cq = (t % q4) * 4;
+        const bool row_in = y0 >= 0 && ry >= y0 && ry <= y1;
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+        if (row_in && cq <= c1 && cq + 3 >= c0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (cq + k >= c0 && cq + k <= c1 && cq + k < wpr) w[k] = sp[(long)ry * wpr + cq + k];
+        }
+        if (vec) {
+            *reinterpret_cast<uint4*>(dp + (long)ry * wpr + cq) = make_uint4(w[0], w[1], w[2], w[3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (cq + k < wpr) dp[(long)ry * wpr + cq + k] = w[k];
+        }
+    }
+}
+
 inline int grid_for(long total, int block) {
     long g = (total + block - 1) / block;
     return (int)(g > 32768 ? 32768 : (g < 1 ? 1 : g));
@@ -424,6 +458,23 @@ extern "C" int demia_mask_crop_unpack(const uint32_t* payload, const int32_t* bb
     hipLaunchKernelGGL(crop_copy_kernel<false>, dim3((int)M), dim3(256), 0, (hipStream_t)stream, masks, bbox,
                        reinterpret_cast<const long*>(offsets), H, W, const_cast<uint32_t*>(payload));
     DEMIA_CHECK_LAUNCH("crop_copy_kernel<unpack>");
+    return DEMIA_OK;
+}
+
+extern "C" int demia_mask_gather_regions(const uint32_t* src, const int64_t* index, const int32_t* bbox, int64_t M, int H, int W,
+                                         uint32_t* dst, void* stream) {
+    DEMIA_REQUIRE(src && index && bbox && dst && W > 0 && H > 0, "args");
+    if (M == 0) return DEMIA_OK;
+    DEMIA_REQUIRE(M <= 0x7fffffffL, "M");
+    const int wpr = (W + 31) >> 5;
+    // ~16 KiB of destination per workgroup: enough blocks for a handful of masks, few enough for tens of thousands
+    int rows_per_block = (4096 + wpr - 1) / wpr;
+    if (rows_per_block > H) rows_per_block = H;
+    const int chunks = (H + rows_per_block - 1) / rows_per_block;
+    DEMIA_REQUIRE(chunks <= 65535, "H");
+    hipLaunchKernelGGL(gather_regions_kernel, dim3((unsigned)M, (unsigned)chunks), dim3(256), 0, (hipStream_t)stream, src,
+                       reinterpret_cast<const long*>(index), bbox, dst, H, wpr, rows_per_block);
+    DEMIA_CHECK_LAUNCH("gather_regions_kernel");
     return DEMIA_OK;
 }
 

@@ -760,19 +760,21 @@ class InferencePipeline:
                     t1 += 1
                 gi = np.concatenate([dets[u].base_idx[sels[u]] for u in range(t, t1)])
                 if len(gi):
+                    # the masks of a forward are zero outside their paste boxes: copy the boxes, write the planes once
                     gt = torch.from_numpy(gi).to(dev)
-                    torch.index_select(dets[t].base, 0, gt, out=packed[pos:pos + len(gi)])
                     torch.index_select(dets[t].base_bbox, 0, gt, out=bbox[pos:pos + len(gi)])
+                    self.ops.gather_regions(dets[t].base, gt, bbox[pos:pos + len(gi)], out=packed[pos:pos + len(gi)])
                 pos += len(gi)
                 t = t1
             else:
                 if lens[t]:
                     si = torch.from_numpy(sels[t]).to(dev)
-                    torch.index_select(dets[t].packed, 0, si, out=packed[pos:pos + lens[t]])
                     if dets[t].bbox is None:
                         have_hint = False
+                        torch.index_select(dets[t].packed, 0, si, out=packed[pos:pos + lens[t]])
                     else:
                         torch.index_select(dets[t].bbox, 0, si, out=bbox[pos:pos + lens[t]])
+                        self.ops.gather_regions(dets[t].packed.contiguous(), si, bbox[pos:pos + lens[t]], out=packed[pos:pos + lens[t]])
                 pos += lens[t]
                 t += 1
         if not have_hint:
@@ -1027,7 +1029,7 @@ class InferencePipeline:
                 pos += len(kept)
                 scores_all.extend(sc)
             classes_all.extend([cls] * len(src))
-            torch.index_select(big, 0, torch.tensor(src, dtype=torch.long, device=dev), out=allp[off:off + len(src)])
+            self.ops.gather_regions(big, src, calg.bbox[src], out=allp[off:off + len(src)])   # tight boxes of the class pass
             area_parts.append(calg.area[src])           # already reduced by the class pass
             bbox_parts.append(calg.bbox[src])
             off += len(src)
@@ -1072,7 +1074,7 @@ class InferencePipeline:
         flat = [i for gl in final_idx for i in gl]
         if not flat:
             return out
-        finalp = allp[torch.tensor(flat, dtype=torch.long, device=dev)].contiguous()
+        finalp = self.ops.gather_regions(allp, flat, alg.bbox[flat])
         recs = cset.records(um_pix=um_pix, measure=True, select=flat)
         pos = 0
         # pixel counts / tight boxes of the final masks, per tile (what an instance table needs; already reduced)

@@ -161,6 +161,24 @@ class MaskOps:
         """``label(mask).max() > 1`` per mask (the masks are not changed)."""
         return self.program_(packed, ["flag_multi"], bbox)[2]
 
+    def gather_regions(self, src: torch.Tensor, index, bbox, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``src[index]`` for masks that are zero outside ``bbox`` (a superset of their tight boxes; -1 = empty): reads the
+        boxes only, writes each destination plane once.  ``index``: int sequence / array (or an i64 device tensor), ``bbox``
+        [n, 4] numpy or i32 device tensor, row i belonging to ``index[i]``."""
+        idx = index if torch.is_tensor(index) else torch.as_tensor(np.asarray(index, dtype=np.int64), device=self.device)
+        idx = idx.to(device=self.device, dtype=torch.int64).contiguous()
+        bb = bbox if torch.is_tensor(bbox) else torch.as_tensor(np.ascontiguousarray(bbox, dtype=np.int32), device=self.device)
+        bb = bb.to(device=self.device, dtype=torch.int32).contiguous()
+        n = int(idx.shape[0])
+        assert bb.shape == (n, 4) and src.is_contiguous() and src.dtype == torch.int32
+        _, H, wpr = src.shape
+        if out is None:
+            out = torch.empty((n, H, wpr), dtype=torch.int32, device=self.device)
+        assert out.is_contiguous() and tuple(out.shape) == (n, H, wpr)
+        _lib.check(self.lib.demia_mask_gather_regions(_lib.ptr(src), _lib.ptr(idx), _lib.ptr(bb), n, H, self._w(src), _lib.ptr(out),
+                                                      self._stream()), "demia_mask_gather_regions")
+        return out
+
     def place_tiles(self, src: torch.Tensor, x_off: Sequence[int], y_off: Sequence[int], tile_h: int, tile_w: int,
                     H: int, W: int, src_w: Optional[int] = None) -> torch.Tensor:
         """``cv2.resize(mask, (tile_w, tile_h), INTER_NEAREST)`` + paste at (x_off, y_off) into a zero (H, W) frame.

@@ -336,6 +336,12 @@ int demia_mask_place_tiles(const uint32_t* src, uint32_t* dst, const int32_t* x_
  * the regions into `masks`, which the caller has zeroed.                                                           */
 int demia_mask_crop_pack(const uint32_t* masks, const int32_t* bbox, const int64_t* offsets, int64_t M, int H, int W,
                          uint32_t* payload, void* stream);
+/* dst[i] = src[index[i]] for masks that are ZERO OUTSIDE their bbox (every mask of this path is: paste hint, program
+ * output): replaces the plane-to-plane gathers between the stages of the class loop (`masks[sel]` copies of the dense
+ * reference, inference.py:1405-1440, 2452-2472).  Only the box is read; the destination plane is written once (zeros
+ * outside the box).  index [M] i64 into src [*, H, W/32]; bbox [M, 4] (-1: empty -> a zero plane); dst [M, H, W/32]. */
+int demia_mask_gather_regions(const uint32_t* src, const int64_t* index, const int32_t* bbox, int64_t M, int H, int W,
+                              uint32_t* dst, void* stream);
 int demia_mask_crop_unpack(const uint32_t* payload, const int32_t* bbox, const int64_t* offsets, int64_t M, int H, int W,
                            uint32_t* masks, void* stream);
 

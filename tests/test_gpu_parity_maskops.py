@@ -492,3 +492,34 @@ def test_gray_histogram_and_contrast_percentiles_vs_oracle(ops, shape):
             ref = P.contrast_distribution(gray, masks[i])
             got = contrast_percentiles(hist[i])
             assert (ref[0] is None and got[0] is None) or all(abs(float(a) - b) <= 1e-9 * max(abs(b), 1.0) for a, b in zip(ref, got))
+
+
+@pytest.mark.parametrize("size", [(64, 200), (300, 2048), (33, 96)])
+def test_gather_regions_equals_plane_gather(gpu_device, size):
+    """demia_mask_gather_regions: dst[i] = src[index[i]] for masks that are zero outside their (superset) boxes -- the boxes
+    are read, the planes written once; widths whose rows are / are not a multiple of four words, empty masks, repeats."""
+    from deepemia_amd.maskset import MaskOps
+
+    H, W = size
+    ops = MaskOps(gpu_device)
+    ops.set_frame_width(W)
+    g = np.random.default_rng(H * W)
+    n = 23
+    dense = np.zeros((n, H, W), dtype=bool)
+    bbox = np.full((n, 4), -1, dtype=np.int32)
+    for i in range(n):
+        if i % 7 == 3:
+            continue                                            # an empty mask, box -1
+        y0, x0 = int(g.integers(0, H - 4)), int(g.integers(0, W - 4))
+        y1, x1 = int(g.integers(y0, min(H, y0 + 40))), int(g.integers(x0, min(W, x0 + 150)))
+        dense[i, y0:y1 + 1, x0:x1 + 1] = g.random((y1 - y0 + 1, x1 - x0 + 1)) < 0.6
+        pad = int(g.integers(0, 3))                             # the box may be a superset of the tight one
+        bbox[i] = (max(y0 - pad, 0), max(x0 - pad, 0), min(y1 + pad, H - 1), min(x1 + pad, W - 1))
+    src = ops.from_dense(dense)
+    index = g.integers(0, n, 41)
+    out = ops.gather_regions(src, index, bbox[index])
+    assert torch.equal(out, src[torch.from_numpy(index).to(gpu_device)])
+    # into a dirty destination: every word of the planes is written
+    dirty = torch.full((41, H, src.shape[2]), -1, dtype=torch.int32, device=gpu_device)
+    ops.gather_regions(src, torch.from_numpy(index).to(gpu_device), torch.from_numpy(bbox[index]).to(gpu_device), out=dirty)
+    assert torch.equal(dirty, out)
