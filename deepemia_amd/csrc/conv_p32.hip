@@ -33,7 +33,9 @@
 #include "common.h"
 #ifndef P32_ABLATE
 #define P32_ABLATE 0      // timing-only dev builds: 1 = no A DMA after the first two steps, 2 = no B DMA, 4 = no MFMAs,
-                          // 32 = no residual loads, 64 = no global stores in the epilogue, 128 = one K-step only
+                          // 32 = no residual loads, 64 = no global stores in the epilogue, 128 = one K-step only,
+                          // 256 = sigmoid / nearest-2x paths compiled out (instruction counting), 512 = no epilogue passes,
+                          // 1024 = no fragment reads (scripts/build_variant.sh, scripts/gpu_ablate.sh)
 #endif
 
 namespace {
@@ -676,18 +678,25 @@ __global__ __launch_bounds__(512, 2) void conv_p32_kernel(const ConvQ p) {
         const char* sb = smem + st * STAGE;
         if constexpr (M16) {
             f16x8 bh[2 * TN], bl[2 * TN];
+            f16x8 fake;                                  // timing-only builds (P32_ABLATE & 1024): no fragment reads
+#pragma unroll
+            for (int q = 0; q < 8; ++q) fake[q] = (_Float16)(float)(lane + q);
 #pragma unroll
             for (int j = 0; j < 2 * TN; ++j) {
-                bh[j] = *reinterpret_cast<const f16x8*>(sb + fb16[0] + j * 2048);
-                bl[j] = *reinterpret_cast<const f16x8*>(sb + fb16[1] + j * 2048);
+                bh[j] = (P32_ABLATE & 1024) ? fake : *reinterpret_cast<const f16x8*>(sb + fb16[0] + j * 2048);
+                bl[j] = (P32_ABLATE & 1024) ? fake : *reinterpret_cast<const f16x8*>(sb + fb16[1] + j * 2048);
             }
 #pragma unroll
             for (int i = 0; i < 2 * TM; ++i) {
-                const f16x8 ah = *reinterpret_cast<const f16x8*>(sb + fa16[0] + i * 2048);
-                const f16x8 al = *reinterpret_cast<const f16x8*>(sb + fa16[1] + i * 2048);
+                const f16x8 ah = (P32_ABLATE & 1024) ? fake : *reinterpret_cast<const f16x8*>(sb + fa16[0] + i * 2048);
+                const f16x8 al = (P32_ABLATE & 1024) ? fake : *reinterpret_cast<const f16x8*>(sb + fa16[1] + i * 2048);
 #pragma unroll
                 for (int j = 0; j < 2 * TN; ++j) {
                     f32x4 c = acc16[i][j];
+                    if (P32_ABLATE & 4) {
+                        asm volatile("" :: "v"(ah), "v"(al), "v"(bh[j]), "v"(bl[j]));
+                        continue;
+                    }
                     c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[j], c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[j], c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[j], c, 0, 0, 0);
