@@ -374,11 +374,11 @@ constexpr bool image_double() {
 template <int WM, int WN, int TM, int TN, typename WriteRow>
 __device__ __forceinline__ void p32_epilogue_planes(const ConvQ& p, const GroupScales& gs, char* smem, WriteRow&& write_tile_row, int wm, int wn,
                                                     int m0, int n0) {
-    constexpr int BN = WN * TN * 32, BM_ = WM * TM * 32;
+    constexpr int BN = WN * TN * 32, BM_ = WM * TM * 32, NT = WM * WN * 64;
     const int tid = threadIdx.x, lane = tid & 63;
     constexpr int EROW = BN * 4 + 16;
-    constexpr int GPR = BN / 8, RSTEP = 512 / GPR, ITEMS = WM * 32 / RSTEP;
-    static_assert(512 % GPR == 0 && (WM * 32) % RSTEP == 0, "epilogue split");
+    constexpr int GPR = BN / 8, RSTEP = NT / GPR, ITEMS = WM * 32 / RSTEP;
+    static_assert(NT % GPR == 0 && (WM * 32) % RSTEP == 0, "epilogue split");
     const int g0 = __builtin_amdgcn_readfirstlane(gs.g0), b1 = __builtin_amdgcn_readfirstlane(gs.b1), b2 = __builtin_amdgcn_readfirstlane(gs.b2);
     const float post0 = uniform(gs.post0), post1 = uniform(gs.post1), post2 = uniform(gs.post2);
     const float resi0 = uniform(gs.resi0), resi1 = uniform(gs.resi1), resi2 = uniform(gs.resi2);
@@ -546,9 +546,12 @@ __device__ __forceinline__ void p32_epilogue_planes(const ConvQ& p, const GroupS
 constexpr int EPI_GENERIC = 0, EPI_PLANES = 1, EPI_HEAD = 2;
 
 template <int WM, int WN, int TM, int TN, bool M16 = true, int EPI = EPI_PLANES, int NST = 2>
-__global__ __launch_bounds__(512, 2) void conv_p32_kernel(const ConvQ p) {
+__global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 2 : 1) void conv_p32_kernel(const ConvQ p) {
     static_assert(NST == 2 || NST == 3, "two or three LDS stages");
-    static_assert(WM * WN == 8, "eight waves");
+    // eight waves (two per SIMD, <= 256 registers each), or FOUR waves of a larger wave tile (one per SIMD, the whole
+    // register file): a third less fragment traffic out of the LDS per output and half the barrier participants
+    static_assert(WM * WN == 8 || (WM * WN == 4 && EPI == EPI_PLANES), "eight waves, or four (planes epilogue only)");
+    constexpr int NW = WM * WN;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int STAGE = (BM + BN) * 128;
     constexpr int NIA = BM / 8, NIB = BN / 8;                     // 1-KiB DMA pieces (8 rows) per K-step
@@ -576,13 +579,13 @@ __global__ __launch_bounds__(512, 2) void conv_p32_kernel(const ConvQ p) {
     const unsigned lds0 = (unsigned)(__SIZE_TYPE__)((lds_void*)smem);
 
     // ---- DMA bookkeeping: wave w moves pieces w, w + 8, ... (8 rows = 1 KiB each) of the A tile and of the B tile ----
-    constexpr int QA = (NIA + 7) / 8, QB = NIB / 8;
-    constexpr bool A_EVEN = NIA % 8 == 0;       // else the last round of A pieces is issued by the first NIA % 8 waves only
-    static_assert(NIB % 8 == 0, "tile width is a multiple of 64");
+    constexpr int QA = (NIA + NW - 1) / NW, QB = NIB / NW;
+    constexpr bool A_EVEN = NIA % NW == 0;      // else the last round of A pieces is issued by the first NIA % NW waves only
+    static_assert(NIB % NW == 0, "tile width is a multiple of 64");
     unsigned a_off[QA], a_msk[QA], b_off[QB];
 #pragma unroll
     for (int q = 0; q < QA; ++q) {
-        const int row = (wave + 8 * q) * 8 + (lane >> 3);
+        const int row = (wave + NW * q) * 8 + (lane >> 3);
         const int csw = (lane & 7) ^ ((row >> 1) & 7);
         const int m = m0 + row;
         const bool vm = m < p.M && row < BM;
@@ -602,7 +605,7 @@ __global__ __launch_bounds__(512, 2) void conv_p32_kernel(const ConvQ p) {
     }
 #pragma unroll
     for (int q = 0; q < QB; ++q) {
-        const int row = (wave + 8 * q) * 8 + (lane >> 3);
+        const int row = (wave + NW * q) * 8 + (lane >> 3);
         const int csw = (lane & 7) ^ ((row >> 1) & 7);
         const int co = n0 + row;
         b_off[q] = (unsigned)(((co >> 6) * p.ksteps) * 8192 + (co & 63) * 128 + csw * 16);
@@ -616,15 +619,15 @@ __global__ __launch_bounds__(512, 2) void conv_p32_kernel(const ConvQ p) {
 #pragma unroll
         for (int q = 0; q < QA; ++q) {
             if ((P32_ABLATE & 1) && !first) break;
-            if (!A_EVEN && q == QA - 1 && wave + 8 * q >= NIA) break;
+            if (!A_EVEN && q == QA - 1 && wave + NW * q >= NIA) break;
             const bool ok = (a_msk[q] >> tp) & 1u;
             const unsigned vo = ok ? a_off[q] + sd : (a_off[q] & 0x70u);     // padding taps / rows beyond M: the zero header
-            dma16(rsrc_a, sbase + q * 8192, vo, 0u);
+            dma16(rsrc_a, sbase + q * (NW * 1024), vo, 0u);
         }
 #pragma unroll
         for (int q = 0; q < QB; ++q) {
             if ((P32_ABLATE & 2) && !first) break;
-            dma16(rsrc_b, sbase + BM * 128 + q * 8192, b_off[q], bd);
+            dma16(rsrc_b, sbase + BM * 128 + q * (NW * 1024), b_off[q], bd);
         }
     };
     const unsigned pixb = (unsigned)(p.Cin * 4), rowb = (unsigned)(p.W * p.Cin * 4);
@@ -739,7 +742,7 @@ __global__ __launch_bounds__(512, 2) void conv_p32_kernel(const ConvQ p) {
     // step (~0.6 us) is shorter than an HBM round trip under load.  Loads complete in order, so `s_waitcnt vmcnt(n)` with
     // n = the DMA instructions this wave issued LAST leaves exactly the newest request outstanding.
     constexpr int N_LAST = QB + QA, N_LAST_SHORT = QB + QA - 1;          // per wave and issue (the last A round is partial)
-    const bool short_wave = !A_EVEN && wave + 8 * (QA - 1) >= NIA;
+    const bool short_wave = !A_EVEN && wave + NW * (QA - 1) >= NIA;
     auto wait_all_but_last_issue = [&]() {
         if (short_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_LAST_SHORT) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_LAST) : "memory");
@@ -1024,7 +1027,7 @@ int launch_q(ConvQ p, hipStream_t st) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_done = true;
     }
-    hipLaunchKernelGGL(k, dim3(p.nwg), dim3(512), smem, st, p);
+    hipLaunchKernelGGL(k, dim3(p.nwg), dim3(WM * WN * 64), smem, st, p);
     DEMIA_CHECK_LAUNCH("conv_p32_kernel");
     return DEMIA_OK;
 }
@@ -1155,6 +1158,9 @@ extern "C" int demia_conv2d_p32(const demia_conv_p32_desc* d, void* stream) {
         case 12: DEMIA_REQUIRE(n256, "tile needs CoutPad % 256 == 0"); return launch_q<1, 8, 5, 1>(p, st);   // 160 x 256
         case 13: DEMIA_REQUIRE(n256, "tile needs CoutPad % 256 == 0"); return launch_q<1, 8, 7, 1>(p, st);   // 224 x 256
         case 14: DEMIA_REQUIRE(n256, "tile needs CoutPad % 256 == 0"); return launch_q<2, 4, 3, 2>(p, st);   // 192 x 256, 2 x 4 waves
+        // (four waves of 128 x 128 / 64 x 128 -- `launch_q<2, 2, 4, 4>`, `<2, 2, 2, 4>`, the kernel supports WM * WN == 4 -- were
+        //  measured 14-20 % SLOWER than the eight-wave tiles: with one wave per SIMD nothing hides the fragment-read latency
+        //  unless the reads are interleaved with the MFMAs by hand; not instantiated)
         // three LDS stages (request two K-steps ahead): measured within +-3 % of the two-stage tiles on every R101 layer --
         // the K loop of the short-K layers is bound by LDS bandwidth (every wave of a 1 x 8 wave grid reads ALL A rows), not
         // by how far ahead the operands are requested; kept as tile hints for A/B only
