@@ -263,6 +263,10 @@ def main() -> None:
         launches = len(dom)
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         peak = PEAK_TFLOPS[args.precision]
+        # the same launches against the roof that bounds EACH of them: a launch cannot take less than its FLOPs at the MFMA
+        # roof or its algorithmic bytes at the HBM roof (8 TB/s, MI355X_MICROARCH.md), whichever is longer
+        attainable_ms = sum(max(e[2] / (peak * 1e12), e[4] / 8.0e12) for e in dom) * 1e3
+        hbm_bound = sum(1 for e in dom if e[4] / 8.0e12 > e[2] / (peak * 1e12))
         # HBM bytes per conv launch from the PMC passes committed under profiles/ (collected with separate
         # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this workload; FETCH_SIZE doubled per the gfx950 note)
         # a STORED value, not measured in this run: it is only reported when the stored pass was taken on this kernel
@@ -309,6 +313,9 @@ def main() -> None:
                          "measured_over": ("two instrumented eager steps after the timed region (the timed steps replay hipGraphs)" if instrumented_s
                                            else "the timed region"),
                          "frac_of_native_peak": achieved * 3.0 / 2500.0 if args.precision in ("f16x2", "f16x2r", "bf16x2") else None,
+                         "frac_of_per_launch_roof": attainable_ms / conv_ms if conv_ms > 0 else None,
+                         "per_launch_roof": f"sum over launches of max(FLOP / {peak:.0f} TFLOP/s, algorithmic bytes / 8 TB/s) / measured time; "
+                                            f"{hbm_bound} of {launches} launches are HBM-bound by that measure",
                          "traffic": traffic, "traffic_source": traffic_source,
                          "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)"},
         }
