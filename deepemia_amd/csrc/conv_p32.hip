@@ -362,23 +362,19 @@ __device__ __forceinline__ void p32_epilogue(const ConvQ& p, const GroupScales& 
 // memory instructions and the waits are counted: a pass waits for ITS residual lines only, not -- as with stores inside
 // `if (m < M)` branches, where the count is unknown and the wait becomes vmcnt(0) -- for the previous pass's stores to be
 // acknowledged by the L2.  That acknowledgement was the longest stall of every short-K (HBM-bound) layer.
-// The accumulator image of a pass (WM x 32 rows) is double-buffered -- one barrier per pass instead of two -- where the second
-// copy is free: the K-loop stages it overlays are larger, or the tile runs one workgroup per CU anyway.
-template <int WM, int WN, int TM, int TN>
-constexpr bool image_double() {
-    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int stages = 2 * (BM + BN) * 128, image = WM * 32 * (BN * 4 + 16);
-    return 2 * image <= 160 * 1024 && (2 * image <= stages || 2 * stages > 160 * 1024);
-}
-
 template <int WM, int WN, int TM, int TN, typename WriteRow>
 __device__ __forceinline__ void p32_epilogue_planes(const ConvQ& p, const GroupScales& gs, char* smem, WriteRow&& write_tile_row, int wm, int wn,
                                                     int m0, int n0) {
-    constexpr int BN = WN * TN * 32, BM_ = WM * TM * 32, NT = WM * WN * 64;
+    constexpr int BM_ = WM * TM * 32;
     const int tid = threadIdx.x, lane = tid & 63;
-    constexpr int EROW = BN * 4 + 16;
-    constexpr int GPR = BN / 8, RSTEP = NT / GPR, ITEMS = WM * 32 / RSTEP;
-    static_assert(NT % GPR == 0 && (WM * 32) % RSTEP == 0, "epilogue split");
+    // WAVE-LOCAL passes: a wave takes the 32 x (TN * 32) block of ITS OWN accumulators through ITS OWN piece of LDS and
+    // finishes it -- no workgroup barrier anywhere in the epilogue (an LDS read of a wave sees that wave's earlier writes:
+    // its LDS instructions execute in order), so the eight waves drift apart and one wave's memory waits are another's
+    // arithmetic.  (With all 512 threads sharing one image every pass was a barrier, and the passes ran in lockstep.)
+    constexpr int LDW = TN * 32 + 4;                         // floats per row of the wave's block (+4: conflict-free writes)
+    constexpr int PPW = 8 / TN, RPI = 2 * PPW, ITEMS = 32 / RPI;   // row pairs / rows per memory instruction; items per pass
+    static_assert(TN == 1 || TN == 2 || TN == 4, "TN");
+    char* const wsm = smem + (tid >> 6) * (32 * LDW * 4);
     const int g0 = __builtin_amdgcn_readfirstlane(gs.g0), b1 = __builtin_amdgcn_readfirstlane(gs.b1), b2 = __builtin_amdgcn_readfirstlane(gs.b2);
     const float post0 = uniform(gs.post0), post1 = uniform(gs.post1), post2 = uniform(gs.post2);
     const float resi0 = uniform(gs.resi0), resi1 = uniform(gs.resi1), resi2 = uniform(gs.resi2);
@@ -398,11 +394,10 @@ __device__ __forceinline__ void p32_epilogue_planes(const ConvQ& p, const GroupS
     // rows (r, r + 1): lane 8 q + j (j < 4) computes chunk j of row r, lane 8 q + 4 + j chunk j of row r + 1, and memory
     // instruction X of a pair moves the whole line of row r + X, lane 8 q + t taking bytes 16 t .. 16 t + 15.  What a lane
     // moved for its partner (lane ^ 4) changes hands with one 16-byte lane exchange.
-    constexpr int LPR = BN / 32, RPW = 64 / GPR;             // lines per tile row; rows a wave covers per item
     const int cj = lane & 3, rs = (lane >> 2) & 1, lg = lane >> 3;
-    const int g = (lg % LPR) * 4 + cj;
-    const int r_first = (tid >> 6) * RPW + (lg / LPR) * 2 + rs;
-    const int co = n0 + g * 8;
+    const int line = lg % TN;                                // which of the wave's TN lines (32 channels) per row
+    const int r_first = (lg / TN) * 2 + rs;                  // row of item 0 inside the wave's 32-row block
+    const int co = n0 + ((wn * TN + line) * 4 + cj) * 8;
     float sc[8], bs[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -416,7 +411,7 @@ __device__ __forceinline__ void p32_epilogue_planes(const ConvQ& p, const GroupS
     const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(res_on ? p.res : p.out), 0, res_on ? (int)p.res_bytes : 0, 0x00020000);
     const unsigned cbytes = (unsigned)p.Cout * 4u;                                     // bytes per P32 pixel
     const unsigned lofs = 128u + (unsigned)((co >> 5) * 128 + (lane & 7) * 16);   // header + this lane's 16 bytes of the pair's lines
-    auto row_of = [&](int i, int k) { const int lr = r_first + k * RSTEP; return m0 + (lr >> 5) * (TM * 32) + i * 32 + (lr & 31); };
+    auto row_of = [&](int i, int k) { return m0 + wm * (TM * 32) + i * 32 + r_first + k * RPI; };
     auto res_off = [&](int m) -> unsigned {
         if (p.res_mode != DEMIA_RES_UP2 || (P32_ABLATE & 256)) return (unsigned)m * cbytes + lofs;   // (m < M + 256: no wrap below 4 GiB)
         const int n = m / p.HoWo;
@@ -452,18 +447,15 @@ __device__ __forceinline__ void p32_epilogue_planes(const ConvQ& p, const GroupS
     };
     float vmax0 = 0.f, vmax1 = 0.f, vmax2 = 0.f;
     if (P32_ABLATE & 512) return;                            // timing-only: everything but the passes
-    constexpr bool DBI = image_double<WM, WN, TM, TN>();
-    constexpr int IMG = WM * 32 * EROW;
-    char* const smem0 = smem;
     load_res(0);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        // (double-buffered: the barrier of pass i + 1 is passed only when every wave has finished reading pass i's image,
-        // which pass i + 2 overwrites)
-        if (i > 0 && !DBI) __syncthreads();
-        smem = smem0 + (DBI ? (i & 1) * IMG : 0);
-        write_tile_row(i, reinterpret_cast<float*>(smem) + (wm * 32) * (EROW / 4) + wn * TN * 32);
-        __syncthreads();
+        // (compiler barriers only: the reads of pass i - 1 are issued before these writes, the writes before the reads below)
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        write_tile_row(i, reinterpret_cast<float*>(wsm));
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
         f16x8 ch[ITEMS], cl[ITEMS];
 #pragma unroll
         for (int k = 0; k < ITEMS; ++k) {
@@ -474,10 +466,10 @@ __device__ __forceinline__ void p32_epilogue_planes(const ConvQ& p, const GroupS
         if (i + 1 < TM) load_res(i + 1);
 #pragma unroll
         for (int k = 0; k < ITEMS; ++k) {
-            const int lr = r_first + k * RSTEP;
+            const int lr = r_first + k * RPI;
             const int m = row_of(i, k);
-            const float4 x0 = *reinterpret_cast<const float4*>(smem + lr * EROW + g * 32);
-            const float4 x1 = *reinterpret_cast<const float4*>(smem + lr * EROW + g * 32 + 16);
+            const float4 x0 = *reinterpret_cast<const float4*>(wsm + lr * (LDW * 4) + (line * 4 + cj) * 32);
+            const float4 x1 = *reinterpret_cast<const float4*>(wsm + lr * (LDW * 4) + (line * 4 + cj) * 32 + 16);
             typedef float f32x2 __attribute__((ext_vector_type(2)));
             f32x2 v2[4] = {{x0.x, x0.y}, {x0.z, x0.w}, {x1.x, x1.y}, {x1.z, x1.w}};
             const int gd = (m >= b1) + (m >= b2);
@@ -784,9 +776,9 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 2 : 1) void conv_p32_k
 
     if constexpr (EPI == EPI_PLANES) {
         if constexpr (M16) {
-            p32_epilogue_planes<WM, WN, TM, TN>(p, gs, smem, [&](int i, float* e) { write_acc16<TN, BN + 4>(acc16[2 * i], acc16[2 * i + 1], e, lane); }, wm, wn, m0, n0);
+            p32_epilogue_planes<WM, WN, TM, TN>(p, gs, smem, [&](int i, float* e) { write_acc16<TN, TN * 32 + 4>(acc16[2 * i], acc16[2 * i + 1], e, lane); }, wm, wn, m0, n0);
         } else {
-            p32_epilogue_planes<WM, WN, TM, TN>(p, gs, smem, [&](int i, float* e) { write_acc32<TN, BN + 4>(acc[i], e, lane); }, wm, wn, m0, n0);
+            p32_epilogue_planes<WM, WN, TM, TN>(p, gs, smem, [&](int i, float* e) { write_acc32<TN, TN * 32 + 4>(acc[i], e, lane); }, wm, wn, m0, n0);
         }
     } else if constexpr (M16) {
         p32_epilogue<WM, WN, TM, TN, HEAD>(p, gs, smem, [&](int i, float* e) { write_acc16<TN, BN + 4>(acc16[2 * i], acc16[2 * i + 1], e, lane); }, wm, wn, m0, n0);
@@ -1015,7 +1007,8 @@ int launch_pp(ConvQ p, hipStream_t st) {
 template <int WM, int WN, int TM, int TN, bool M16 = true, int EPI = EPI_PLANES, int NST = 2>
 int launch_q(ConvQ p, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int stages = NST * (BM + BN) * 128, image = WM * 32 * (BN * 4 + 16) * ((EPI == EPI_PLANES && image_double<WM, WN, TM, TN>()) ? 2 : 1);
+    // LDS: the K-loop stages, overlaid in the epilogue by the accumulator image (planes epilogue: one 32-row block per wave)
+    constexpr int stages = NST * (BM + BN) * 128, image = EPI == EPI_PLANES ? WM * WN * 32 * (TN * 128 + 16) : WM * 32 * (BN * 4 + 16);
     static_assert(stages <= 160 * 1024, "LDS");
     constexpr int smem = stages > image ? stages : image;
     p.ntn = p.CoutPad / BN;
