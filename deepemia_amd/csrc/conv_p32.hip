@@ -124,9 +124,11 @@ __device__ __forceinline__ void write_acc16(const f32x4 (&r0)[2 * TN], const f32
         }
 }
 
-// Epilogue shared by the conv_p32 kernels: TM passes; in pass i every wave hands tile-row i of its accumulators to LDS,
-// then the 512 threads walk the WM * 32 rows x BN columns in 8-channel groups: scale / bias / residual / activation,
-// split into planes, 16-byte stores.  All waves have passed a barrier after their last LDS read.
+// Epilogues.  The guarded one (p32_epilogue: f32 outputs, fused head, odd channel counts): TM passes; in pass i every wave
+// hands tile-row i of its accumulators to LDS, then the 512 threads walk the WM * 32 rows x BN columns in 8-channel
+// groups: scale / bias / residual / activation, split into planes, 16-byte stores.  The planes one (p32_epilogue_planes,
+// every ordinary P32 layer) does the same wave by wave without workgroup barriers, in straight-line code with hardware
+// bounded buffer accesses of whole 128-byte lines.  All waves have passed a barrier after their last LDS read.
 __device__ __forceinline__ float uniform(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 
 // Scales are per GROUP of rows (one group per image, so that a tile's result does not depend on its batch neighbours).  A
