@@ -122,6 +122,73 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiP p) {
     const float bin_h = rh / (float)p.P, bin_w = rw / (float)p.P;
     const int gh = (int)ceilf(rh / (float)p.P), gw = (int)ceilf(rw / (float)p.P);
     const float cnt = (float)max(gh * gw, 1);
+
+    // Separable form (the common case: at most 8 rows and 8 columns of feature pixels under one bin).  A bin's value is
+    // sum_samples sum_taps w f with w = (hy | ly) (hx | lx) and a sample dropped when its y OR its x is out of range, i.e.
+    // sum_y sum_x Wy[y] Wx[x] f[y][x] with Wy / Wx the per-row / per-column sums of the samples' weights: every feature
+    // pixel under the bin is loaded ONCE instead of once per sample that touches it ((g + 1)^2 instead of 4 g^2 loads for a
+    // g x g sample grid -- the kernel was bound by L1 bandwidth).  The tables are built once per ROI by the first threads.
+    __shared__ float s_w[2][14 * 8];
+    __shared__ int s_lo[2][14], s_n[2][14];
+    const bool tables = p.P <= 14 && gh >= 1 && gw >= 1 && gh <= 7 && gw <= 7;        // (block-uniform)
+    if (tables) {
+        if (threadIdx.x < 2 * p.P) {
+            const int dim = threadIdx.x / p.P, b = threadIdx.x - dim * p.P;          // dim 0: rows (y), 1: columns (x)
+            const int g = dim == 0 ? gh : gw, size = dim == 0 ? H : W;
+            const float start = dim == 0 ? rsh : rsw, bsz = dim == 0 ? bin_h : bin_w;
+            float w8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            int lo0 = 0, hi_last = -1;
+            bool any = false;
+            for (int pass = 0; pass < 2; ++pass) {                                   // pass 0: the range; pass 1: the weights
+                for (int i = 0; i < g; ++i) {
+                    float v = start + (float)b * bsz + ((float)i + 0.5f) * bsz / (float)g;
+                    if ((v < -1.0f) || (v > (float)size)) continue;
+                    if (v <= 0.f) v = 0.f;
+                    int lo = (int)v, hi;
+                    if (lo >= size - 1) { lo = hi = size - 1; v = (float)lo; } else { hi = lo + 1; }
+                    const float l = v - (float)lo, h = 1.0f - l;
+                    if (pass == 0) {
+                        if (!any) { lo0 = lo; any = true; }
+                        hi_last = hi;
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) w8[k] += (lo - lo0 == k ? h : 0.f) + (hi - lo0 == k ? l : 0.f);
+                    }
+                }
+            }
+            const int n = any ? hi_last - lo0 + 1 : 0;
+            s_lo[dim][b] = lo0;
+            s_n[dim][b] = n;                                                         // n <= g + 1 <= 8
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s_w[dim][b * 8 + k] = w8[k];
+        }
+        __syncthreads();
+        if (!lane_on) return;
+        for (int bin = wave; bin < PP; bin += 4) {
+            const int ph = bin / p.P, pw = bin - ph * p.P;
+            const int y0 = s_lo[0][ph], ny = s_n[0][ph], x0 = s_lo[1][pw], nx = s_n[1][pw];
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int yy = 0; yy < ny; ++yy) {
+                const float wy = s_w[0][ph * 8 + yy];
+                const char* rowp = feat + ((long)(y0 + yy) * W + x0) * pixb;
+                float t[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int xx = 0; xx < nx; ++xx) {
+                    const float wx = s_w[1][pw * 8 + xx];
+                    float v[4];
+                    A::load(rowp + (long)xx * pixb, inv_s, v);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) t[c] += wx * v[c];
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c] += wy * t[c];
+            }
+            float o[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] = acc[c] / cnt;
+            A::store(out0 + (long)bin * pixb, s_out, o);
+        }
+        return;
+    }
     if (!lane_on) return;
 
     for (int bin = wave; bin < PP; bin += 4) {
