@@ -88,7 +88,7 @@ def cpu_baseline(depth: int, size: int, thr: float, sd, tiles: int = 3):
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="tiles per GPU per step")
     ap.add_argument("--precision", choices=["f32", "f32x3", "f16x2", "f16x2r", "bf16x2", "bf16"], default="f16x2")
