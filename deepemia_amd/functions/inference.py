@@ -1279,38 +1279,65 @@ def run_inference(dataset_name, output_dir, visualize=True, threshold=0.65, draw
     return dedup_results
 
 
-def write_predictions_png(path: str, image_bgr: np.ndarray, crops, classes: Sequence[int], contours, thing_classes) -> None:
-    """``<img>_predictions.png`` (``inference.py:1080-1145``): per mask a 50 % colour overlay (``addWeighted(vis, 1, colour, .5)``),
-    its external contours in the class colour, instance number and class name at the centroid.  Output formatting only --
-    drawn with Pillow (OpenCV's Hershey font / line rasteriser are not reproduced).  ``crops`` = ``mask_crops(...)``: the
-    masks arrive as bounding-box crops, never as dense frames."""
+def _polyline_pixels(pts: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """Pixels of the closed polyline through ``pts`` [n, 2] (x, y): ``cv2.drawContours(..., thickness=1)`` on a
+    CHAIN_APPROX_SIMPLE contour, whose segments all run in one of the eight chain directions (every pixel of such a
+    segment is on the integer lattice, so any line rasteriser sets the same pixels)."""
+    xs, ys = [], []
+    n = len(pts)
+    for k in range(n):
+        (xa, ya), (xb, yb) = pts[k], pts[(k + 1) % n]
+        steps = int(max(abs(int(xb) - int(xa)), abs(int(yb) - int(ya))))
+        t = np.arange(steps + 1)
+        xs.append(np.rint(xa + (int(xb) - int(xa)) * t / max(steps, 1)).astype(np.int64))
+        ys.append(np.rint(ya + (int(yb) - int(ya)) * t / max(steps, 1)).astype(np.int64))
+    if not xs:
+        return np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64)
+    return np.concatenate(xs), np.concatenate(ys)
+
+
+def write_predictions_png(path: str, image_bgr: np.ndarray, crops, classes: Sequence[int], contours, thing_classes) -> List[Tuple[int, int, int, int]]:
+    """``<img>_predictions.png`` (``inference.py:1080-1145``), mask by mask IN ORDER as the reference draws it: a 50 % colour
+    overlay (``cv2.addWeighted(vis, 1.0, coloured_mask, 0.5, 0)``: inside the mask ``saturate(round(v + 0.5 colour))``, ties to
+    even), the external contours in the class colour (``drawContours`` thickness 1), then the instance number and the class
+    name at the centroid ``(int(m10 / m00), int(m01 / m00))`` -- so a later mask blends over an earlier one's outline and
+    text.  Overlay and outlines are pixel-exact restatements (checked against ``oracle/pipeline_ref.py::overlay_without_text``);
+    the TEXT is drawn with Pillow's font, not OpenCV's Hershey strokes: the boxes it may touch are returned so that a
+    checker can leave them out.  ``crops`` = ``mask_crops(...)``: masks arrive as bounding-box crops, never as dense frames."""
     from PIL import Image, ImageDraw
 
-    vis = image_bgr.astype(np.float32)
-    for c, cls in zip(crops, classes):
+    vis = np.ascontiguousarray(image_bgr[:, :, :3]).copy()
+    H, W = vis.shape[:2]
+    text_boxes: List[Tuple[int, int, int, int]] = []
+    probe = ImageDraw.Draw(Image.new("RGB", (8, 8)))
+    for i, (c, cls, recs) in enumerate(zip(crops, classes, contours)):
+        color = CLASS_COLORS[int(cls) % len(CLASS_COLORS)]                       # BGR, as the reference's class_colors
+        if c is not None:
+            y0, x0, sub = c
+            win = vis[y0:y0 + sub.shape[0], x0:x0 + sub.shape[1]]
+            win[sub] = np.clip(np.rint(win[sub].astype(np.float32) + 0.5 * np.asarray(color, dtype=np.float32)), 0, 255).astype(np.uint8)
+        for rec in recs:
+            px, py = _polyline_pixels(np.asarray(rec["points"]).reshape(-1, 2))
+            ok = (px >= 0) & (px < W) & (py >= 0) & (py < H)
+            vis[py[ok], px[ok]] = color
         if c is None:
             continue
-        y0, x0, sub = c
-        color = np.asarray(CLASS_COLORS[int(cls) % len(CLASS_COLORS)], dtype=np.float32)
-        win = vis[y0:y0 + sub.shape[0], x0:x0 + sub.shape[1]]
-        win[sub] = np.clip(np.rint(win[sub] + 0.5 * color), 0, 255)
-    im = Image.fromarray(vis.astype(np.uint8)[:, :, ::-1].copy())       # BGR -> RGB for Pillow
-    draw = ImageDraw.Draw(im)
-    for i, (c, cls, recs) in enumerate(zip(crops, classes, contours)):
-        b, g, r = CLASS_COLORS[int(cls) % len(CLASS_COLORS)]
-        for rec in recs:
-            pts = [tuple(int(v) for v in p) for p in rec["points"]]
-            if len(pts) > 1:
-                draw.line(pts + [pts[0]], fill=(r, g, b), width=1)
-            elif pts:
-                draw.point(pts, fill=(r, g, b))
-        ys, xs = np.nonzero(c[2]) if c is not None else ((), ())
-        if len(ys):
-            cx, cy = int((xs.sum() + c[1] * len(xs)) / len(xs)), int((ys.sum() + c[0] * len(ys)) / len(ys))
-            cname = thing_classes[int(cls)] if int(cls) < len(thing_classes) else f"class_{int(cls)}"
-            draw.text((cx, cy - 18), f"{i + 1}", fill=(255, 255, 255))
-            draw.text((cx, cy + 6), cname, fill=(255, 255, 255))
-    im.save(path)
+        ys, xs = np.nonzero(c[2])
+        if len(ys) == 0:
+            continue
+        cx, cy = int((xs.sum() + c[1] * len(xs)) / len(xs)), int((ys.sum() + c[0] * len(ys)) / len(ys))
+        cname = thing_classes[int(cls)] if int(cls) < len(thing_classes) else f"class_{int(cls)}"
+        for text, (tx, ty) in ((f"{i + 1}", (cx, cy - 18)), (cname, (cx, cy + 6))):
+            l, t, r, b = probe.textbbox((tx, ty), text)
+            l, t, r, b = max(l - 1, 0), max(t - 1, 0), min(r + 1, W), min(b + 1, H)
+            if r <= l or b <= t:
+                continue
+            patch = Image.fromarray(np.ascontiguousarray(vis[t:b, l:r, ::-1]))
+            ImageDraw.Draw(patch).text((tx - l, ty - t), text, fill=(255, 255, 255))
+            vis[t:b, l:r] = np.asarray(patch)[:, :, ::-1]
+            text_boxes.append((l, t, r, b))
+    Image.fromarray(np.ascontiguousarray(vis[:, :, ::-1])).save(path)
+    return text_boxes
 
 
 def write_measurements(ops: MaskOps, dedup_results: Dict[str, dict], test_img_path: str, output_dir: str, metadata,

@@ -177,3 +177,26 @@ def measurement_rows(name: str, masks, classes, thing_classes, um_pix=1.0, psum=
                          r["Feret_diam"], r["Roundness"], r["Sphericity"], r["contrast_d10"], r["contrast_d50"], r["contrast_d90"],
                          psum, name, r["_ellipse_unstable"]])
     return rows
+
+
+def overlay_without_text(image_bgr: np.ndarray, masks, classes, class_colors) -> np.ndarray:
+    """The ``--visualize`` overlay of inference.py:1080-1101 without the putText calls, mask by mask in order:
+    ``cv2.addWeighted(vis, 1.0, coloured_mask, 0.5, 0)`` (u8 saturating, cvRound = ties to even; outside the mask
+    ``v * 1 + 0 * 0.5`` is v) and ``cv2.drawContours(vis, findContours(mask, RETR_EXTERNAL, CHAIN_APPROX_SIMPLE), -1, colour, 1)``
+    (the eight-direction segments between consecutive contour points, every lattice pixel on them)."""
+    vis = image_bgr[:, :, :3].copy()
+    for m, cls in zip(masks, classes):
+        m = np.asarray(m) > 0
+        color = np.asarray(class_colors[int(cls) % len(class_colors)], dtype=np.float64)
+        vis[m] = np.clip(np.rint(vis[m].astype(np.float64) + 0.5 * color), 0, 255).astype(np.uint8)
+        for c in P.find_external_contours(m):
+            pts = np.asarray(c).reshape(-1, 2)
+            n = len(pts)
+            for k in range(n):
+                (xa, ya), (xb, yb) = (int(v) for v in pts[k]), (int(v) for v in pts[(k + 1) % n])
+                steps = max(abs(xb - xa), abs(yb - ya))
+                for t in range(steps + 1):
+                    x = xa + (xb - xa) * t // max(steps, 1) if steps else xa
+                    y = ya + (yb - ya) * t // max(steps, 1) if steps else ya
+                    vis[y, x] = color.astype(np.uint8)
+    return vis

@@ -523,3 +523,44 @@ def test_gather_regions_equals_plane_gather(gpu_device, size):
     dirty = torch.full((41, H, src.shape[2]), -1, dtype=torch.int32, device=gpu_device)
     ops.gather_regions(src, torch.from_numpy(index).to(gpu_device), torch.from_numpy(bbox[index]).to(gpu_device), out=dirty)
     assert torch.equal(dirty, out)
+
+
+def test_predictions_overlay_matches_the_reference_drawing_order(gpu_device, tmp_path):
+    """a20: `<img>_predictions.png` = per mask, in order, the 50 % colour blend (u8 saturating, ties to even), then the external
+    contours in the class colour, then the labels -- a later mask blends over an earlier one's outline.  Overlay and outlines
+    are compared pixel by pixel with the dense restatement (oracle/pipeline_ref.py::overlay_without_text) outside the boxes
+    the writer reports for its (Pillow-drawn, not comparable) text."""
+    from PIL import Image
+    from deepemia_amd.functions.inference import CLASS_COLORS, write_predictions_png
+    from deepemia_amd.maskset import MaskOps
+    from deepemia_amd.utils.mask_utils import mask_crops
+    from oracle import pipeline_ref as PR
+
+    H = W = 320
+    g = np.random.default_rng(5)
+    yy, xx = np.mgrid[0:H, 0:W]
+    masks = np.zeros((9, H, W), dtype=bool)
+    for i in range(9):
+        cx, cy = (60 + 45 * (i % 5), 70 + 90 * (i // 5)) if i < 8 else (150, 120)        # neighbours overlap; the last one covers several
+        a, b = (40, 28) if i < 8 else (95, 60)
+        masks[i] = ((xx - cx) / a) ** 2 + ((yy - cy) / b) ** 2 <= 1.0
+    masks[3, 60:80, 180:200] = False                                                      # a hole: external contours only
+    masks[6] = False                                                                       # an empty mask draws nothing
+    classes = [0, 1, 2, 0, 1, 7, 3, 9, 4]
+    img = g.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    img[:40] = 250                                                                         # the blend saturates here
+    ops = MaskOps(gpu_device)
+    ops.set_frame_width(W)
+    packed = ops.from_dense(masks)
+    recs = ops.contours(packed, max_contours=64)
+    out = tmp_path / "x_predictions.png"
+    boxes = write_predictions_png(str(out), img, mask_crops(ops, packed), classes, recs, ["pore", "grain", "void"])
+    got = np.asarray(Image.open(out))[:, :, ::-1]
+    want = PR.overlay_without_text(img, list(masks), classes, CLASS_COLORS)
+    text = np.zeros((H, W), dtype=bool)
+    for (l, t, r, b) in boxes:
+        text[t:b, l:r] = True
+    assert len(boxes) == 16 and 0 < text.sum() < H * W // 6
+    assert (got[~text] == want[~text]).all()
+    assert (got[text] == 255).all(axis=-1).any()                                           # something white was written there
+    assert (got != img).any() and (got[masks.any(0) == 0] == img[masks.any(0) == 0])[~text[masks.any(0) == 0]].all()
