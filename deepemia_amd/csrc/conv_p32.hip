@@ -227,13 +227,7 @@ __device__ __forceinline__ void p32_epilogue(const ConvQ& p, const GroupScales& 
     };
     // The residual rows of a pass are requested ONE PASS AHEAD (all of them at once): a short-K layer is otherwise one
     // exposed HBM round trip per item -- sixteen in a row for a 256 x 256 tile.
-    // two register sets used in turn (pass i reads set i & 1 while set (i + 1) & 1 is being filled): no copy at the start of a
-    // pass, so the wait for the next pass's residual -- which on this ISA is also a wait for every store issued before it --
-    // sits where the values are first used, a barrier and an LDS round trip after the previous pass's stores were issued
-#ifndef P32_RES_DB
-#define P32_RES_DB 0
-#endif
-    f16x8 rh[2][ITEMS], rl[2][ITEMS];
+    f16x8 rh[ITEMS], rl[ITEMS];
     const bool has_res = p.res_mode != DEMIA_RES_NONE && co < p.Cout;
     auto load_res = [&](int i) {
 #pragma unroll
@@ -241,8 +235,8 @@ __device__ __forceinline__ void p32_epilogue(const ConvQ& p, const GroupScales& 
             const int m = row_of(i, k);
             if (has_res && m < p.M && !(P32_ABLATE & 32)) {
                 const char* rp = resb + res_pix(m) * cbytes + gofs;
-                rh[P32_RES_DB ? (i & 1) : 0][k] = *reinterpret_cast<const f16x8*>(rp);
-                rl[P32_RES_DB ? (i & 1) : 0][k] = *reinterpret_cast<const f16x8*>(rp + 64);
+                rh[k] = *reinterpret_cast<const f16x8*>(rp);
+                rl[k] = *reinterpret_cast<const f16x8*>(rp + 64);
             }
         }
     };
@@ -255,7 +249,7 @@ __device__ __forceinline__ void p32_epilogue(const ConvQ& p, const GroupScales& 
         __syncthreads();
         f16x8 ch[ITEMS], cl[ITEMS];
 #pragma unroll
-        for (int k = 0; k < ITEMS; ++k) { ch[k] = rh[P32_RES_DB ? (i & 1) : 0][k]; cl[k] = rl[P32_RES_DB ? (i & 1) : 0][k]; }
+        for (int k = 0; k < ITEMS; ++k) { ch[k] = rh[k]; cl[k] = rl[k]; }
         if (i + 1 < TM) load_res(i + 1);
         if (co < p.Cout) {
 #pragma unroll
