@@ -138,11 +138,13 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
     const int q = tid >> 2;
     const int row = q >> 2;
     const int col0 = (q & 3) * 4;
-    float acc[4][16];
+    // accumulators as pairs: v_pk_fma_f32 does two f32 FMAs per lane and instruction (same fused arithmetic per element)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 acc2[4][8];
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
-        for (int c = 0; c < 16; ++c) acc[p][c] = 0.f;
+        for (int c = 0; c < 8; ++c) acc2[p][c] = f32x2{0.f, 0.f};
     for (int kh = 0; kh < 7; ++kh) {
         const float4* irow = sIn + (2 * row + kh) * ST_IW + 2 * col0;
 #pragma unroll
@@ -153,17 +155,19 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
             const float4* wp = sW + ((kh * 7 + kw) * 4) * 16 + cg * 4;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                float wv[16];
+                f32x2 wv[8];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float4 t = wp[c * 16 + j];
-                    wv[4 * j + 0] = t.x; wv[4 * j + 1] = t.y; wv[4 * j + 2] = t.z; wv[4 * j + 3] = t.w;
+                    wv[2 * j] = f32x2{t.x, t.y};
+                    wv[2 * j + 1] = f32x2{t.z, t.w};
                 }
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
-                    const float xv = c == 0 ? x[p].x : (c == 1 ? x[p].y : x[p].z);
+                    const float xs = c == 0 ? x[p].x : (c == 1 ? x[p].y : x[p].z);
+                    const f32x2 xv = {xs, xs};
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) acc[p][j] = fmaf(xv, wv[j], acc[p][j]);
+                    for (int j = 0; j < 8; ++j) acc2[p][j] = __builtin_elementwise_fma(xv, wv[j], acc2[p][j]);
                 }
             }
         }
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
         TO* o = out + (((long)n * Ho + ho) * Wo + wo) * 64 + cg * 16;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            float v = acc[p][j] * sc[j] + bs[j];
+            float v = acc2[p][j >> 1][j & 1] * sc[j] + bs[j];
             o[j] = from_f32<TO>(v > 0.f ? v : 0.f);
         }
     }
