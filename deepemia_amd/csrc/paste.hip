@@ -27,6 +27,7 @@ struct PasteP {
 };
 
 constexpr int PASTE_ROWS = 16;   // rows per block: 4 KiB of packed output at 2048 px (most blocks only write zeros)
+constexpr int PASTE_COLS = 2048; // widest box whose per-column sampling table fits the workgroup's LDS (wider boxes: per pixel)
 
 __global__ __launch_bounds__(256) void paste_kernel(const PasteP p) {
     __shared__ float sm[28 * 28];
@@ -93,6 +94,24 @@ __global__ __launch_bounds__(256) void paste_kernel(const PasteP p) {
     }
     __syncthreads();
     const float invw = x1 - x0, invh = y1 - y0;
+    // The column part of the sampling (grid coordinate, west / east taps and weights) is the same for every row of the
+    // mask: worked out once per workgroup for the box's columns -- same operations in the same order as per pixel, so the
+    // bits do not change -- instead of once per pixel (the division alone was a third of the per-pixel work).
+    __shared__ float s_we[PASTE_COLS];
+    __shared__ short s_xi[PASTE_COLS];
+    const int ncol = x1i - x0i;
+    const bool col_table = ncol <= PASTE_COLS;
+    if (col_table) {
+        for (int cix = tid; cix < ncol; cix += 256) {
+            const int X = x0i + cix;
+            float gx = ((float)X + 0.5f - x0) / invw * 2.0f - 1.0f;
+            const float ix = ((gx + 1.0f) * 28.0f - 1.0f) / 2.0f;
+            const float xw = floorf(ix);
+            s_we[cix] = ix - xw;
+            s_xi[cix] = (short)(int)xw;
+        }
+        __syncthreads();
+    }
     for (int w = tid; w < nrows * wpr; w += 256) {
         const int ry = w / wpr, wx = w - ry * wpr;
         const int Y = row0 + ry;
@@ -110,11 +129,20 @@ __global__ __launch_bounds__(256) void paste_kernel(const PasteP p) {
             for (int bx = 0; bx < 32; ++bx) {
                 const int X = xa + bx;
                 if (X < x0i || X >= x1i) continue;
-                float gx = ((float)X + 0.5f - x0) / invw * 2.0f - 1.0f;
-                const float ix = ((gx + 1.0f) * 28.0f - 1.0f) / 2.0f;
-                const float xw = floorf(ix);
-                const float we = ix - xw, ww = 1.0f - we;
-                const int xi0 = (int)xw, xi1 = xi0 + 1;
+                float we;
+                int xi0;
+                if (col_table) {
+                    we = s_we[X - x0i];
+                    xi0 = s_xi[X - x0i];
+                } else {
+                    float gx = ((float)X + 0.5f - x0) / invw * 2.0f - 1.0f;
+                    const float ix = ((gx + 1.0f) * 28.0f - 1.0f) / 2.0f;
+                    const float xw = floorf(ix);
+                    we = ix - xw;
+                    xi0 = (int)xw;
+                }
+                const float ww = 1.0f - we;
+                const int xi1 = xi0 + 1;
                 const bool vx0 = (unsigned)xi0 < 28u, vx1 = (unsigned)xi1 < 28u;
                 const float nw = (vy0 && vx0) ? r0[xi0] : 0.f;
                 const float ne = (vy0 && vx1) ? r0[xi1] : 0.f;
