@@ -254,11 +254,12 @@ class ContourSet:
         -1 where a mask has no contour -- what ``deduplicate_masks_smart``'s compactness test reads."""
         count, info, red, _ = self.host()
         out = np.full(self.M, -1.0)
-        for m in range(self.M):
+        one = count == 1                                          # the usual case: no choice to make
+        out[one] = red[one, 0, 1]
+        for m in np.nonzero(count > 1)[0]:
             c = int(count[m])
-            if c:
-                k = np.lexsort((info[m, :c, 0], info[m, :c, 1]))[-1]
-                out[m] = red[m, k, 1]
+            k = np.lexsort((info[m, :c, 0], info[m, :c, 1]))[-1]
+            out[m] = red[m, k, 1]
         return out
 
     def measure(self, um_pix: float = 1.0, select: Optional[Sequence[int]] = None) -> np.ndarray:
@@ -292,10 +293,11 @@ class ContourSet:
                 sx, sy, n, off = (int(v) for v in info[m, c])
                 rec = dict(start=(sx, sy), area=float(red[m, c, 0]), perimeter=float(red[m, c, 1]))
                 if pts is not None:
-                    rec["points"] = pts[off: off + n].copy()
+                    rec["points"] = pts[off: off + n]             # views of this call's own host copies
                 if vals is not None:
-                    rec["values"] = vals[m, c].copy()
+                    rec["values"] = vals[m, c]
                 recs.append(rec)
-            recs.sort(key=lambda r: (r["start"][1], r["start"][0]), reverse=True)
+            if len(recs) > 1:
+                recs.sort(key=lambda r: (r["start"][1], r["start"][0]), reverse=True)
             out.append(recs)
         return out
