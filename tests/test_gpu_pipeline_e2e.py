@@ -147,8 +147,9 @@ def _compare(split, images, ref_rows, ref_masks, contrast=False):
         assert vis.shape == img.shape and (vis != img[:, :, ::-1]).any()
 
 
+# (exact-f32 and the default f16x2 run every configuration; the legacy f32x3 mode keeps the odd-sized-tile case -- each case
+# costs ~40 s of CPU pipeline, and the round-end GPU tier has a time limit)
 @pytest.mark.parametrize("case", ["single_r50_blobby_upscale2", "ensemble_r50_r101_upscale1",
-                                  "single_r50_blobby_upscale2_f32x3", "ensemble_r50_r101_upscale1_f32x3",
                                   "single_r50_tile200_upscale1p5_f32x3",
                                   "single_r50_blobby_upscale2_f16x2", "ensemble_r50_r101_upscale1_f16x2",
                                   "single_r50_tile200_upscale1p5_f16x2"])
