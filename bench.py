@@ -100,7 +100,11 @@ def main() -> None:
     ap.add_argument("--max-size-test", type=int, default=1333)
     ap.add_argument("--total-tiles", type=int, default=0, help="BASELINE configs[4]: a job of this many DISTINCT tiles per GPU (e.g. 256), "
                     "walked in steps of --batch; overrides --steps")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the timed CPU sample AND the parity leg")
+    ap.add_argument("--parity-only", action="store_true", help="run the CPU path on tile 0 only: the parity check of the timed result "
+                    "without the 3-tile cpu_baseline timing (the -m gpu configs[4] job)")
+    ap.add_argument("--no-h2d-leg", action="store_true", help="skip the second timed leg that uploads every step's tiles from pinned "
+                    "host memory on a copy stream (reported as `h2d`, never as `value`)")
     ap.add_argument("--no-overlap", action="store_true", help="do not overlap batch i+1's network with batch i's post-processing")
     ap.add_argument("--forward-only", action="store_true", help="time predictor(tile) only, without the per-tile post-processing")
     ap.add_argument("--post-priority", choices=["default", "high", "low"], default="default", help="(experiment) priority of the post-processing stream")
@@ -150,19 +154,14 @@ def main() -> None:
     x = torch.from_numpy(tiles).to(dev)
     xs = [x]
     if args.total_tiles:
-        # configs[4]: every step sees different tiles.  Generating 256 tiles takes minutes on the host, so steps 1.. are the
-        # eight dihedral images of the 16 base tiles, plain and intensity-inverted (distinct content, same statistics class)
+        # configs[4]: every step sees DIFFERENT tiles.  Step 0 holds the numpy tiles (tile 0 is the parity check's tile); the
+        # other steps' tiles are generated on the device with the same recipe and their own seeds (synth.em_tiles_device:
+        # 1.4 s of host numpy per tile otherwise) -- total_tiles distinct tiles per GPU, resident before the timed region
         assert args.total_tiles % args.batch == 0, "--total-tiles must be a multiple of --batch"
         args.steps = args.total_tiles // args.batch
-        base = torch.from_numpy(tiles).to(dev)
-        xs = []
-        for k in range(args.steps):
-            t = base if (k // 8) % 2 == 0 else 255 - base
-            d = k % 8
-            t = torch.rot90(t, d % 4, dims=(1, 2))
-            if d >= 4:
-                t = torch.flip(t, dims=(2,))
-            xs.append(t.contiguous())
+        for k in range(1, args.steps):
+            first = 100000 + (rank * args.steps + k) * args.batch
+            xs.append(synth.em_tiles_device(range(first, first + args.batch), args.size, dev))
 
     def sync_all():
         torch.cuda.synchronize()
@@ -234,19 +233,76 @@ def main() -> None:
     sync_all()
     dt = time.perf_counter() - t0
     events, eng.conv_events = eng.conv_events or [], None
-    instrumented_s = None
+
+    def snapshot(res):
+        """Tile 0 of a step's result as host data (dense masks, scores, classes, contour records)."""
+        packed, scores, classes, recs = res[0]
+        dense = pipe.ops.to_dense(packed, args.size) if packed is not None else np.zeros((0, args.size, args.size), dtype=bool)
+        return np.array(dense, copy=True), [float(v) for v in scores], [int(c) for c in classes], recs
+
+    # what the parity leg checks is the TIMED path's own result (graph replay in the default mode): taken here, before
+    # anything else runs through the pipeline (total-tiles mode: step 0, the step whose tile 0 is synthetic tile 0)
+    want_parity = rank == 0 and world == 1 and not args.no_cpu_baseline and not args.forward_only
+    timed_snap = snapshot(last["res"]) if (want_parity and "res" in last) else None
+    instrumented_s, eager_snap = None, None
+    n_instr = 2
     if args.graph and not args.no_conv_events:
         # per-kernel HIP events cannot be taken inside a replayed graph: two eager, instrumented passes of the same path
         pipe.use_graphs = False
+        last.pop("res", None)
         step(0)
         sync_all()
+        if want_parity and "res" in last:
+            eager_snap = snapshot(last["res"])      # same input as the timed snapshot: eager launch vs graph replay
         eng.conv_events = []
         ti = time.perf_counter()
-        for i in range(2):
+        for i in range(n_instr):
             step(i)
         sync_all()
         instrumented_s = time.perf_counter() - ti
         events, eng.conv_events = eng.conv_events, None
+        pipe.use_graphs = True
+    h2d = None
+    if world == 1 and not args.no_h2d_leg and not args.forward_only and not args.no_overlap:
+        # second leg: the same K passes with every step's tiles UPLOADED from pinned host memory on a copy stream (two device
+        # slots; the forward waits for its upload, the upload of step i+1 runs under the forward of step i)
+        pinned = [t_.cpu().pin_memory() for t_ in xs]
+        slots_dev = [torch.empty_like(x), torch.empty_like(x)]
+        copy_stream = torch.cuda.Stream(device=dev)
+        slot_free = [None, None]
+        h2d_events = []
+
+        def launch_up(i):
+            sl = i % 2
+            with torch.cuda.stream(copy_stream):
+                if slot_free[sl] is not None:
+                    copy_stream.wait_event(slot_free[sl])
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(copy_stream)
+                slots_dev[sl].copy_(pinned[i % len(pinned)], non_blocking=True)
+                e1.record(copy_stream)
+            h2d_events.append((e0, e1))
+            with torch.cuda.stream(net_stream):
+                net_stream.wait_event(e1)
+                hd = pipe.forward_async(0, slots_dev[sl])
+            slot_free[sl] = hd[1]
+            return hd
+
+        sync_all()
+        th = time.perf_counter()
+        handle = launch_up(0)
+        for i in range(args.steps):
+            nxt = launch_up(i + 1) if i + 1 < args.steps else None
+            step(i, handle)
+            handle = nxt
+        sync_all()
+        dth = time.perf_counter() - th
+        up_ms = [a.elapsed_time(b) for a, b in h2d_events]
+        h2d = {"value_with_upload": args.batch * args.steps / dth, "ms_per_step_with_upload": dth / args.steps * 1e3,
+               "h2d_ms_per_step": float(np.median(up_ms)), "bytes_per_step": int(x.numel()),
+               "gbps": float(x.numel() / (np.median(up_ms) * 1e-3) / 1e9),
+               "note": "same K passes, tiles uploaded from pinned host memory on a copy stream, overlapped with the previous "
+                       "step's forward; reported beside `value` (inputs resident), never as `value`"}
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -272,7 +328,8 @@ def main() -> None:
         # a STORED value, not measured in this run: it is only reported when the stored pass was taken on this kernel
         traffic, traffic_source = None, None
         kernel_name = "conv_p32_kernel" if args.precision == "f16x2" else ("conv_igemm_split_kernel" if args.precision in ("f16x2r", "f32x3", "bf16x2") else "conv_igemm_kernel")
-        tf = ROOT / "profiles" / f"r02_conv_{args.precision}_b{args.batch}_pmc_traffic.json"
+        cands = sorted((ROOT / "profiles").glob(f"r*_conv_{args.precision}_b{args.batch}_pmc_traffic.json"))
+        tf = cands[-1] if cands else ROOT / "profiles" / "none.json"          # the newest round's stored pass
         native = (args.min_size_test, args.max_size_test) != (800, 1333)
         if native:
             args.no_cpu_baseline = True        # the oracle sample below is the 800-pixel workload
@@ -305,11 +362,14 @@ def main() -> None:
                                                      "the K loop, 3 fp16 MFMAs per product; peak = fp16 dense peak / 3)" if args.precision == "f16x2r" else
                                                      "conv_igemm_kernel (implicit-GEMM conv)") + ", all tile configs",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "launches_per_step": launches // max(2 if instrumented_s else args.steps, 1),
+                         "launches_per_step": launches // max(n_instr if instrumented_s else args.steps, 1),
                          "avg_launch_us": conv_ms * 1e3 / max(launches, 1),
                          "algorithmic_gflop_per_launch": conv_flops / max(launches, 1) / 1e9,
                          "algorithmic_bytes_per_launch": conv_bytes / max(launches, 1),
-                         "share_of_step_time": conv_ms * 1e-3 / (instrumented_s or dt), "all_conv_share_of_step_time": all_conv_ms * 1e-3 / (instrumented_s or dt),
+                         # conv time per step (from the instrumented passes) over the TIMED step; the eager figure beside it
+                         "share_of_step_time": (conv_ms / (n_instr if instrumented_s else args.steps)) / (dt / args.steps * 1e3),
+                         "all_conv_share_of_step_time": (all_conv_ms / (n_instr if instrumented_s else args.steps)) / (dt / args.steps * 1e3),
+                         "share_of_eager_instrumented_step_time": conv_ms * 1e-3 / (instrumented_s or dt),
                          "measured_over": ("two instrumented eager steps after the timed region (the timed steps replay hipGraphs)" if instrumented_s
                                            else "the timed region"),
                          "frac_of_native_peak": achieved * 3.0 / 2500.0 if args.precision in ("f16x2", "f16x2r", "bf16x2") else None,
@@ -319,30 +379,47 @@ def main() -> None:
                          "traffic": traffic, "traffic_source": traffic_source,
                          "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)"},
         }
-        sq = ROOT / "profiles" / f"r02_conv_{args.precision}_sq.json"
+        cands = sorted((ROOT / "profiles").glob(f"r*_conv_{args.precision}_sq.json"))
+        sq = cands[-1] if cands else ROOT / "profiles" / "none.json"
+        if h2d is not None:
+            line["h2d"] = h2d
         if sq.exists():
             rec = json.loads(sq.read_text())
             if rec.get("kernel") == kernel_name:
                 line["roofline"]["mfma_busy_frac"] = rec.get("mfma_busy_frac")
                 line["roofline"]["mfma_busy_source"] = f"stored SQ counter pass profiles/{sq.name}; not re-measured by this run"
         ok = True
-        if world == 1 and not args.no_cpu_baseline and not args.forward_only:
-            # parity is checked on every run before a throughput number is accepted -- tile 0 of the
-            # LAST TIMED step against the CPU path's result for the same tile
+        if want_parity:
+            # parity is checked on every run before a throughput number is accepted -- tile 0 of a
+            # TIMED step (snapshot taken right after the timed region) against the CPU path's result for the same tile
             from oracle import tile_parity as TP
-            line["cpu_baseline"], ref0 = cpu_baseline(args.depth, args.size, args.threshold, sd)
-            packed, scores, classes, recs = last["res"][0]
-            dense = pipe.ops.to_dense(packed, args.size) if packed is not None else np.zeros((0, args.size, args.size), dtype=bool)
+            if args.parity_only:
+                from deepemia_amd import synth as _synth
+                ref0 = TP.reference_tile(_synth.em_tile(0, args.size), sd, args.depth, args.threshold, CLASS_THRESHOLDS, SMALL_CLASSES)
+            else:
+                line["cpu_baseline"], ref0 = cpu_baseline(args.depth, args.size, args.threshold, sd)
+            dense, scores, classes, recs = timed_snap
             par = TP.compare_tile(ref0, dense, scores, classes, recs)
-            line["parity"] = {k: par[k] for k in ("mask_iou_min", "csv_max_rel_err", "csv_max_rel_err_all", "score_max_abs_err", "instances",
-                                                  "instances_ref", "masks_identical", "masks_with_tie_pixels", "tie_pixels_max", "csv_rows",
+            line["parity"] = {k: par[k] for k in ("mask_iou_min", "csv_max_rel_err", "csv_max_rel_err_own_mask", "csv_max_rel_err_all",
+                                                  "score_max_abs_err", "instances", "instances_ref", "masks_identical",
+                                                  "masks_with_tie_pixels", "tie_pixels_max", "csv_rows", "csv_rows_own_mask",
                                                   "ellipse_rows_skipped", "ok")}
-            line["parity"]["checked"] = (("tile 0 of the first timed step vs" if args.total_tiles else "tile 0 of the last timed step vs") + " oracle/tile_parity.py; bar: every mask IoU >= 0.999, CSV within 1e-4 "
-                                         "relative on the instances whose mask equals the reference's bit for bit, the others differ by <= 8 "
-                                         "threshold-tie pixels (csv_max_rel_err_all includes them)")
+            line["parity"]["checked"] = (("tile 0 of the first timed step" if args.total_tiles else "tile 0 of the last timed step") +
+                                         (" (hipGraph replay)" if args.graph else " (eager launches)") +
+                                         ", snapshot taken before any other pass, vs oracle/tile_parity.py; bar: every mask IoU >= 0.999, CSV "
+                                         "within 1e-4 relative on the instances whose mask equals the reference's bit for bit; the others "
+                                         "differ by <= 8 threshold-tie pixels and their CSV rows are within 1e-4 of the oracle's measurement "
+                                         "of the product's OWN mask (csv_max_rel_err_own_mask); csv_max_rel_err_all = vs the reference's masks")
             if "why" in par:
                 line["parity"]["why"] = par["why"]
             ok = bool(par["ok"])
+            if eager_snap is not None:
+                # the eager launch sequence and its captured replay must give the same bits on the same input
+                same = (eager_snap[0].shape == dense.shape and bool((eager_snap[0] == dense).all()) and eager_snap[1] == scores
+                        and eager_snap[2] == classes)
+                line["parity"]["eager_equals_replay"] = bool(same)
+                ok = ok and same
+                line["parity"]["ok"] = ok
             if not ok:
                 line["value_rejected"] = line["value"]
                 line["value"] = None          # a fast path whose results differ from the reference's is not measured

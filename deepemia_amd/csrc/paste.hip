@@ -108,7 +108,9 @@ __global__ __launch_bounds__(256) void paste_kernel(const PasteP p) {
             const float ix = ((gx + 1.0f) * 28.0f - 1.0f) / 2.0f;
             const float xw = floorf(ix);
             s_we[cix] = ix - xw;
-            s_xi[cix] = (short)(int)xw;
+            // clamped before narrowing: for a box clipped to a sliver |ix| can exceed what a short holds, and a wrapped
+            // value could land on a valid tap; anything <= -2 or >= 29 has both taps outside the 28-wide mask either way
+            s_xi[cix] = (short)(int)fminf(fmaxf(xw, -2.0f), 29.0f);
         }
         __syncthreads();
     }

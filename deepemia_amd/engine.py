@@ -244,6 +244,12 @@ class MaskRCNNEngine:
         self._arena: Dict[tuple, list] = {}               # intermediate buffers per input shape, reused by later forwards
         self._arena_key: Optional[tuple] = None
         self._arena_i = 0
+        # arenas, meta pools and captured graphs are per input shape and GBs each (16 x 2048^2 R101: 8.6 GiB): at most this
+        # many shapes stay resident, least recently used first out -- a folder of differently sized micrographs must not
+        # accumulate one arena per size (the reference handles arbitrary sizes, inference.py:2299-2485)
+        self.max_cached_shapes = max(1, int(os.environ.get("DEEPEMIA_MAX_CACHED_SHAPES", "3")))
+        self._shape_lru: List[tuple] = []
+        self.evictions = 0
         self.dt = BF16 if precision == "bf16" else F32
         self.tdt = torch.bfloat16 if precision == "bf16" else torch.float32
         self._tables: Dict[Tuple[int, int], dict] = {}
@@ -375,6 +381,7 @@ class MaskRCNNEngine:
         """Intermediates of one forward come from an arena keyed by the input shape: the first forward of a shape
         allocates them (P32 headers zeroed once), later ones reuse them in call order -- no allocation, no memset but the
         one that clears the meta pool."""
+        self._touch_shape(key)
         self._arena_key, self._arena_i = key, 0
         # one {max |x|, s} pair per activation tensor and SCALE GROUP = image of the batch: an image's planes, and so its
         # results, do not depend on its batch neighbours.  The conv epilogue needs >= 128 rows per group; the smallest
@@ -388,6 +395,32 @@ class MaskRCNNEngine:
             pool.zero_()
         self._meta_pool = pool
         self._meta_i = 0
+
+    def _touch_shape(self, key: tuple) -> None:
+        """LRU bookkeeping of the per-shape caches.  An eviction drops the shape's arena, meta pool and graphs TOGETHER
+        (the graphs hold raw pointers into the other two) after a device synchronize -- it only happens when a new shape
+        arrives, never inside a capture (the eager warm-up forward has touched the key before)."""
+        lru = self._shape_lru
+        if lru and lru[-1] == key:
+            return
+        if key in lru:
+            lru.remove(key)
+        lru.append(key)
+        while len(lru) > self.max_cached_shapes:
+            self._evict_shape(lru.pop(0))
+
+    def _evict_shape(self, key: tuple) -> None:
+        torch.cuda.synchronize(self.device)
+        self._graphs.pop(key, None)
+        self._arena.pop(key, None)
+        self._meta_pools.pop(key, None)
+        self.evictions += 1
+
+    def release_cached_shapes(self) -> None:
+        """Drop every per-shape cache (arenas, meta pools, graphs)."""
+        while self._shape_lru:
+            self._evict_shape(self._shape_lru.pop(0))
+        self._arena_key = None
 
     def _scratch(self, numel: int, dtype, zero: bool = False, zero_head: int = 0) -> torch.Tensor:
         """Flat intermediate buffer number ``_arena_i`` of the current forward.  ``zero`` / ``zero_head``: zeroed (whole /
@@ -787,6 +820,7 @@ class MaskRCNNEngine:
             return self.forward(images)
         images = images.contiguous()
         key = tuple(int(d) for d in images.shape[:3])
+        self._touch_shape(key)                        # may evict ANOTHER shape's arena + graphs (LRU)
         st = self._graphs.get(key)
         cur = torch.cuda.current_stream(self.device)
         if st is None:

@@ -133,7 +133,9 @@ def detect_scale_bar(image, roi_config=None, intensity_threshold=200, proximity_
         um = float(um)
         if not (um > 0.0 and math.isfinite(um)):
             raise ValueError(f"um_per_pixel must be a positive number, got {um!r}")
-        psum = str(cfg.get("label", "0"))
+        # the `Detected scale bar` column holds the label's DIGITS in every mode (scalebar_ocr.py:163-166 keeps the digits of
+        # the OCR text; the line-detection branch below does the same)
+        psum = "".join(ch for ch in str(cfg.get("label", "0")) if ch.isdigit()) or "0"
         if not _scale_bar_warned:
             system_logger.info(f"Scale bar: using the configured calibration {um} um/pixel (label {psum!r}); no OCR")
             _scale_bar_warned = True
@@ -266,6 +268,13 @@ class InferencePipeline:
             raise ValueError(f"inference_settings.merge_mode must be 'smart' or 'soft_nms', got {self.merge_mode!r}")
         if self.merge_mode == "soft_nms":
             system_logger.warning("merge_mode: soft_nms -- NON-PARITY mode: the reference has no soft-NMS (hard greedy dedup only)")
+        # f4, flagged NON-parity: `multiscale_settings.enabled: true` makes the classes whose class_specific_settings carry
+        # the reference's own (never read there) `use_multiscale: true` take their full-image pass through
+        # run_adaptive_multiscale_inference (reference inference.py:1816-2064, dead code there: SURVEY N2)
+        msc = inf_settings.get("multiscale_settings", {}) or {}
+        self.multiscale_enabled = bool(msc.get("enabled", False))
+        if self.multiscale_enabled:
+            system_logger.warning("multiscale_settings.enabled -- NON-PARITY mode: the reference never reaches its multi-scale code")
         self._cache: Dict[Tuple[int, str], List[_Detections]] = {}
         # images per batched forward: l4_performance_optimizations.forward_batch_size / DEEPEMIA_FORWARD_BATCH (default 16:
         # fills 256 CUs on the 50^2 feature maps, 8.6 GiB of activations per 2048^2-tile batch)
@@ -482,8 +491,13 @@ class InferencePipeline:
         mine = parallel.shard_indices(len(offs), rank, world)
         full_masks, full_scores, full_classes = None, [], []
         if rank == 0:
-            full = [self._predict_batch(m, image_key + "|full", image_dev[None])[0] for m in model_ids]
-            full_masks, full_scores, full_classes = class_pass(full)
+            if self.uses_multiscale(target_class):      # flagged NON-parity mode (f4): the full-image pass at several scales
+                full_masks, full_scores, full_classes = self.run_adaptive_multiscale_inference(
+                    list(model_ids), image_key, image_dev, target_class, confidence_threshold, small_classes, iou_threshold)
+                self.ops.set_frame_width(w)
+            else:
+                full = [self._predict_batch(m, image_key + "|full", image_dev[None])[0] for m in model_ids]
+                full_masks, full_scores, full_classes = class_pass(full)
         tile_masks, tile_scores, tile_classes, tile_units = [], [], [], []
         if mine:
             my_tiles = tiles[torch.tensor(mine, dtype=torch.long, device=self.dev)]
@@ -563,7 +577,10 @@ class InferencePipeline:
         sel = torch.tensor(order, dtype=torch.long, device=self.dev)
         return packed[sel].contiguous(), [float(sc[i]) for i in order], [int(cl[i]) for i in order]
 
-    def run_adaptive_multiscale_inference(self, model_idx: int, image_key: str, image_dev: torch.Tensor, target_class: int,
+    def uses_multiscale(self, target_class: int) -> bool:
+        return self.multiscale_enabled and bool(self.class_specific_settings.get(f"class_{target_class}", {}).get("use_multiscale", False))
+
+    def run_adaptive_multiscale_inference(self, model_idx, image_key: str, image_dev: torch.Tensor, target_class: int,
                                           confidence_threshold: float = 0.3, small_classes=frozenset(), iou_threshold: float = 0.7):
         """The semantics of ``inference.py:1833-1984`` (``run_adaptive_multiscale_inference``) + ``:1986-2064``
         (``process_single_scale``) as a flagged NON-parity mode: that code is never reached from the reference's
@@ -572,9 +589,12 @@ class InferencePipeline:
         rule that unlocks 2.0 / 2.5 and 0.5 / 0.6, the 5 % low-yield stop, ``cv2.resize(INTER_LINEAR)`` of the image to
         ``int(h s) x int(w s)``, the scale-invariant minimum size (``max(3, int(A 5e-6))`` / ``max(25, int(A 1e-4))`` of the
         ORIGINAL area, times s^2), ``INTER_NEAREST`` back to the original frame and the greedy cross-scale dedup at mask IoU
-        0.4 in descending score order.  Everything runs on the device: resize, predictor, class pass, nearest resize, IoUs."""
+        0.4 in descending score order.  Everything runs on the device: resize, predictor, class pass, nearest resize, IoUs.
+        ``model_idx`` may be a list of model indices: the per-scale step is then the ensemble class pass (a10 + a14) on
+        the scaled image (BASELINE configs[3]: ensemble + multi-scale)."""
         h, w = int(image_dev.shape[0]), int(image_dev.shape[1])
-        eng = self.predictors[model_idx].engine
+        model_ids = [int(model_idx)] if isinstance(model_idx, (int, np.integer)) else [int(m) for m in model_idx]
+        eng = self.predictors[model_ids[0]].engine
         is_small = target_class in small_classes
         area0 = h * w
         base_min = max(3, int(area0 * 0.000005)) if is_small else max(25, int(area0 * 0.0001))
@@ -582,10 +602,13 @@ class InferencePipeline:
         def single_scale(scale: float):
             sh, sw = (h, w) if scale == 1.0 else (int(h * scale), int(w * scale))
             img = image_dev[None] if scale == 1.0 else eng.resize_linear_u8(image_dev[None].contiguous(), sh, sw)
-            det = self._predict_batch(model_idx, f"{image_key}|scale{scale}", img)[0]
+            dets = [self._predict_batch(m, image_key + ("|full" if scale == 1.0 else f"|scale{scale}"), img)[0] for m in model_ids]
             self.ops.set_frame_width(sw)
-            masks, sc, _ = self._single_model_class_pass(det, target_class, small_classes, confidence_threshold, iou_threshold)
-            if masks is None or masks.shape[0] == 0:
+            if len(model_ids) > 1:
+                masks, sc, _ = self._ensemble_class_pass(dets, target_class, small_classes, confidence_threshold, iou_threshold)
+            else:
+                masks, sc, _ = self._single_model_class_pass(dets[0], target_class, small_classes, confidence_threshold, iou_threshold)
+            if masks is None or isinstance(masks, str) or masks.shape[0] == 0:
                 return None, []
             area, _ = self.ops.area_bbox(masks)
             keep = np.nonzero(area.cpu().numpy() >= int(base_min * (scale ** 2)))[0]

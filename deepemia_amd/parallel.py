@@ -8,8 +8,8 @@ Instance table (what crosses xGMI instead of N x H x W masks):
                          bbox y0, x0, y1, x1 (global frame, inclusive; -1 for an empty mask), area, flags
   payload [sum] int32  : each mask's bit-packed words cropped to its bbox rows and word columns
 A 2048^2 tile with 100 instances is a few hundred KB at most; the collective is latency-bound, so it is
-a single ``all_gather`` of sizes followed by one padded ``all_gather`` (direct, one hop on the fully
-connected xGMI mesh) -- no ring of per-instance sends.  Every rank ends with the same global table in
+ONE padded ``all_gather`` per exchange (direct, one hop on the fully connected xGMI mesh; the per-rank capacity
+is agreed without talking, see ``all_gather_instance_tables``) -- no ring of per-instance sends.  Every rank ends with the same global table in
 the same order (unit id, then detector order), so the greedy filters that follow are deterministic and
 identical on all ranks.
 """
@@ -89,7 +89,9 @@ def encode_instance_table(packed: Optional[torch.Tensor], scores: Sequence[float
 def decode_instance_table(header: torch.Tensor, payload: torch.Tensor, H: int, W: int, device=None):
     """-> (packed [n, H, W/32] int32, scores list, classes list, unit ids list)."""
     device = torch.device(header.device if device is None else device)
-    hdr = header.cpu().numpy()
+    hdr = getattr(header, "_host", None)          # the exchange has already brought the headers to the host
+    if hdr is None or hdr.shape[0] != header.shape[0]:
+        hdr = header.cpu().numpy()
     n = hdr.shape[0]
     wpr = (W + 31) // 32
     lens = _payload_lengths(hdr)
@@ -116,51 +118,98 @@ def decode_instance_table(header: torch.Tensor, payload: torch.Tensor, H: int, W
     return packed, scores, [int(v) for v in hdr[:, 1]], [int(v) for v in hdr[:, 0]]
 
 
+_caps: dict = {}          # (backend, world) -> (header rows, payload words) every rank reserves per rank in the next exchange
+stats = {"exchanges": 0, "size_exchanges": 0, "host_syncs": 0}
+
+
+def _grow(v: int, q: int) -> int:
+    """Capacity for the next exchange: half as much again as this one's largest table, in steps of ``q``."""
+    return (int(v * 1.5) // q + 1) * q
+
+
 def all_gather_instance_tables(header: torch.Tensor, payload: torch.Tensor, group=None) -> Tuple[torch.Tensor, torch.Tensor]:
     """All ranks contribute their table; every rank returns the GLOBAL table ordered by (unit id, local
-    order).  Works with RCCL (device tensors) and gloo (host tensors)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    order).  Works with RCCL (device tensors) and gloo (host tensors).
+
+    ONE collective and ONE device-to-host wait per call in the steady state: every rank reserves the same per-rank capacity
+    (1.5 x the largest table of the previous exchange -- all ranks saw the same sizes, so they agree without talking), each
+    rank's true sizes travel in the first two words of its slot, and the sizes + headers of all ranks come to the host in
+    one copy (the greedy filters that follow run there).  Only the first exchange of a job, and one whose table outgrew the
+    reserved capacity (every rank sees that in the same words and repeats it together), pay a separate size exchange."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1 and dist.get_backend(group) != "nccl":
         return _merge_tables([header], [payload])
     world = dist.get_world_size(group)
     backend = dist.get_backend(group)
     comm_dev = header.device if backend == "nccl" else torch.device("cpu")
     h = header.to(comm_dev).contiguous()
     p = payload.to(comm_dev).contiguous()
-    sizes = torch.tensor([h.shape[0], p.shape[0]], dtype=torch.int64, device=comm_dev)
-    all_sizes = torch.zeros((world, 2), dtype=torch.int64, device=comm_dev)
-    dist.all_gather_into_tensor(all_sizes, sizes, group=group) if backend == "nccl" else \
-        dist.all_gather(list(all_sizes.unbind(0)), sizes, group=group)
-    all_sizes = all_sizes.cpu().numpy()
-    max_n, max_p = int(all_sizes[:, 0].max()), int(all_sizes[:, 1].max())
-    buf = torch.zeros((max_n * HDR + max_p,), dtype=torch.int32, device=comm_dev)
-    buf[: h.numel()] = h.reshape(-1)
-    buf[max_n * HDR: max_n * HDR + p.numel()] = p
-    gathered = torch.empty((world, buf.numel()), dtype=torch.int32, device=comm_dev)
-    if backend == "nccl":
-        dist.all_gather_into_tensor(gathered, buf, group=group)      # one direct all-gather over the xGMI mesh
-    else:
-        dist.all_gather(list(gathered.unbind(0)), buf, group=group)
-    hs = [gathered[r, : int(all_sizes[r, 0]) * HDR].view(-1, HDR) for r in range(world)]
-    ps = [gathered[r, max_n * HDR: max_n * HDR + int(all_sizes[r, 1])] for r in range(world)]
-    out_h, out_p = _merge_tables(hs, ps)
-    return out_h.to(header.device), out_p.to(payload.device)
+    n, pl = int(h.shape[0]), int(p.shape[0])
+    key = (backend, world)
+    cap = _caps.get(key)
+    stats["exchanges"] += 1
+    while True:
+        if cap is None:
+            sizes = torch.tensor([n, pl], dtype=torch.int64).to(comm_dev)
+            all_sizes = torch.zeros((world, 2), dtype=torch.int64, device=comm_dev)
+            dist.all_gather_into_tensor(all_sizes, sizes, group=group) if backend == "nccl" else \
+                dist.all_gather(list(all_sizes.unbind(0)), sizes, group=group)
+            all_sizes = all_sizes.cpu().numpy()
+            stats["size_exchanges"] += 1
+            stats["host_syncs"] += 1
+            cap = (int(all_sizes[:, 0].max()), int(all_sizes[:, 1].max()))
+        cn, cp = cap
+        nn, pp = min(n, cn), min(pl, cp)
+        buf = torch.zeros((2 + cn * HDR + cp,), dtype=torch.int32, device=comm_dev)
+        buf[:2] = torch.tensor([n, pl], dtype=torch.int32).to(comm_dev, non_blocking=True)
+        buf[2: 2 + nn * HDR] = h[:nn].reshape(-1)
+        buf[2 + cn * HDR: 2 + cn * HDR + pp] = p[:pp]
+        gathered = torch.empty((world, buf.numel()), dtype=torch.int32, device=comm_dev)
+        if backend == "nccl":
+            dist.all_gather_into_tensor(gathered, buf, group=group)      # one direct all-gather over the xGMI mesh
+        else:
+            dist.all_gather(list(gathered.unbind(0)), buf, group=group)
+        head = gathered[:, : 2 + cn * HDR].cpu().numpy()                 # THE host wait: every rank's sizes + header rows
+        stats["host_syncs"] += 1
+        sz = head[:, :2].astype(np.int64)
+        if bool((sz[:, 0] <= cn).all() and (sz[:, 1] <= cp).all()):
+            break
+        cap = None            # some rank's table outgrew the reservation: all ranks read the same words and redo it exactly
+    _caps[key] = (_grow(int(sz[:, 0].max()), 16), _grow(int(sz[:, 1].max()), 4096))
+    hs = [gathered[r, 2: 2 + int(sz[r, 0]) * HDR].view(-1, HDR) for r in range(world)]
+    ps = [gathered[r, 2 + cn * HDR: 2 + cn * HDR + int(sz[r, 1])] for r in range(world)]
+    host = [head[r, 2: 2 + int(sz[r, 0]) * HDR].reshape(-1, HDR) for r in range(world)]
+    out_h, out_p = _merge_tables(hs, ps, host)
+    hh = getattr(out_h, "_host", None)
+    out_h, out_p = out_h.to(header.device), out_p.to(payload.device)
+    if hh is not None:
+        out_h._host = hh
+    return out_h, out_p
 
 
-def _merge_tables(headers: List[torch.Tensor], payloads: List[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
+def reset_capacity() -> None:
+    """Forget the reserved capacities (tests; a new job whose tables have nothing to do with the last one's)."""
+    _caps.clear()
+
+
+def _merge_tables(headers: List[torch.Tensor], payloads: List[torch.Tensor], host: Optional[List[np.ndarray]] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """Concatenate rank tables and order instances by unit id (stable: rank, then local order within a unit).
     Round-robin / blocked unit assignment usually leaves the concatenation already ordered; otherwise the payload
-    segments are permuted with one index gather."""
+    segments are permuted with one index gather.  ``host``: the headers' host copies when the caller already has them
+    (no second device-to-host wait); the merged header carries its host copy as ``._host`` for the decoder."""
     hcat = torch.cat(headers, dim=0) if len(headers) > 1 else headers[0]
     pcat = torch.cat(payloads, dim=0) if len(payloads) > 1 else payloads[0]
-    hn = hcat.cpu().numpy()
+    hn = np.concatenate(host, axis=0) if host is not None else hcat.cpu().numpy()
     n = hn.shape[0]
     if n == 0:
         return hcat, pcat
     order = np.argsort(hn[:, 0], kind="stable")                   # concatenation order = (rank, local index): stable sort keeps it
     if np.array_equal(order, np.arange(n)):
+        hcat._host = hn
         return hcat, pcat
     lens = _payload_lengths(hn)
     offs = _offsets(lens)
     idx = np.concatenate([np.arange(offs[i], offs[i] + lens[i], dtype=np.int64) for i in order]) if int(lens.sum()) else np.zeros((0,), dtype=np.int64)
     ot = torch.from_numpy(order).to(hcat.device)
-    return hcat[ot].contiguous(), pcat[torch.from_numpy(idx).to(pcat.device)].contiguous()
+    out = hcat[ot].contiguous()
+    out._host = np.ascontiguousarray(hn[order])
+    return out, pcat[torch.from_numpy(idx).to(pcat.device)].contiguous()

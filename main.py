@@ -90,8 +90,20 @@ def main(argv=None) -> int:
         if dist is not None:
             dist.barrier()
 
+    def all_ranks_ok(ok: bool) -> bool:
+        """Rank 0's verdict on its host-side section, known to every rank: a failure there must end the whole job with a
+        non-zero code instead of leaving the other ranks in a barrier until the RCCL timeout."""
+        if dist is None:
+            return ok
+        import torch
+        on_dev = dist.get_backend() == "nccl"
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=f"cuda:{local_rank}" if on_dev else "cpu")
+        dist.broadcast(flag, src=0)
+        return bool(int(flag.item()))
+
     # Host side effects (download, clean-up, upload, removing the inputs) belong to rank 0 alone; the other ranks wait at a
     # barrier until the inputs are in place and again until rank 0 has written every output that is uploaded or removed.
+    prep_ok = True
     if rank != 0:
         pass
     elif online and args.download:
@@ -105,24 +117,43 @@ def main(argv=None) -> int:
             downloaded = True
         except (subprocess.CalledProcessError, OSError) as e:
             system_logger.error(f"GCS download failed: {e}")
-            raise
+            prep_ok = False
     else:
         system_logger.info("GCS disabled (no gsutil / DEEPEMIA_OFFLINE): using local dataset_info.json and DATASET/INFERENCE")
-    if rank == 0:
+    if rank == 0 and prep_ok:
         for pattern in ("*.png", "*.csv", "*.jpg"):     # reference main.py:462-468
             for f in glob.glob(pattern):
                 try:
                     os.remove(f)
                 except OSError:
                     pass
-    barrier()
+    if not all_ranks_ok(prep_ok):               # (a status broadcast, not a bare barrier: every rank leaves together)
+        if dist is not None:
+            dist.destroy_process_group()
+        return 1
     from deepemia_amd.functions.inference import run_inference
 
     t0 = time.perf_counter()
-    run_inference(args.dataset_name, str(split_dir), visualize=args.visualize, threshold=args.threshold, draw_id=args.draw_id,
-                  dataset_format=args.dataset_format, draw_scalebar=args.draw_scalebar)
-    system_logger.info(f"Inference task finished in {time.perf_counter() - t0:.2f}s; results in {split_dir}")
-    barrier()                                   # rank 0 has written the CSVs / overlays (it is the last to leave run_inference)
+    run_ok = True
+    try:
+        run_inference(args.dataset_name, str(split_dir), visualize=args.visualize, threshold=args.threshold, draw_id=args.draw_id,
+                      dataset_format=args.dataset_format, draw_scalebar=args.draw_scalebar)
+        system_logger.info(f"Inference task finished in {time.perf_counter() - t0:.2f}s; results in {split_dir}")
+    except Exception:
+        if dist is None:
+            raise
+        # an exception of one rank outside the collectives (rank 0's output writers): tell the others instead of leaving them
+        # at the barrier below.  (An exception INSIDE the sharded loop is per image and handled there on every rank alike.)
+        system_logger.error("run_inference failed", exc_info=True)
+        run_ok = False
+    if dist is not None:
+        import torch
+        on_dev = dist.get_backend() == "nccl"
+        flag = torch.tensor([1 if run_ok else 0], dtype=torch.int32, device=f"cuda:{local_rank}" if on_dev else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)      # also the barrier: rank 0 has written the CSVs / overlays
+        if not int(flag.item()):
+            dist.destroy_process_group()
+            return 1
     if rank == 0 and online and args.upload:
         try:
             stamp = time.strftime("%Y%m%d_%H%M%S")

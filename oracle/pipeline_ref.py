@@ -61,6 +61,12 @@ class RefPipeline:
         self.global_config = {"inference_settings": global_inf_settings}     # what get_confidence_threshold reads (inference.py:302, 352)
         self._cache = {}
         self.forward_calls = 0
+        # f4, the product's flagged NON-parity modes (checker twins; neither exists in the reference's live path)
+        self.merge_mode = str(inf_settings.get("merge_mode", "smart"))
+        snm = inf_settings.get("soft_nms", {}) or {}
+        self.soft_nms_sigma, self.soft_nms_thr = float(snm.get("sigma", 0.5)), float(snm.get("score_threshold", 0.001))
+        self.multiscale_enabled = bool((inf_settings.get("multiscale_settings", {}) or {}).get("enabled", False))
+        self.scales_visited: Dict[tuple, list] = {}
 
     def predict(self, mi: int, key, image: np.ndarray):
         ck = (mi, key)
@@ -94,11 +100,47 @@ class RefPipeline:
             return "EMPTY_NDARRAY", [], []
         return P.deduplicate_masks_smart(all_masks, all_scores, [target_class] * len(all_masks), iou_threshold)
 
+    # inference.py:1833-2064 as the product composes it (one class pass per scale instead of the iterative masking loop)
+    def multiscale_pass(self, model_ids, key, image, target_class, small_classes, conf, iou_threshold):
+        h, w = image.shape[:2]
+        is_small = target_class in small_classes
+        base_min = max(3, int(h * w * 0.000005)) if is_small else max(25, int(h * w * 0.0001))
+
+        def one(scale):
+            sh, sw = (h, w) if scale == 1.0 else (int(h * scale), int(w * scale))
+            im = image if scale == 1.0 else cv_resize_linear_u8(image, sh, sw)
+            m, s, _ = self.class_pass(model_ids, (key, "full") if scale == 1.0 else (key, "scale", scale), im, target_class,
+                                      small_classes, conf, iou_threshold)
+            if isinstance(m, str):
+                return [], []
+            keep = [i for i in range(len(m)) if int((np.asarray(m[i]) > 0).sum()) >= int(base_min * scale ** 2)]
+            return ([P.resize_nearest((np.asarray(m[i]) > 0).astype(np.uint8), h, w).astype(bool) if scale != 1.0 else np.asarray(m[i]) > 0
+                     for i in keep], [s[i] for i in keep])
+
+        per, order = {}, [0.7, 1.0, 1.5]
+        for sc in order:
+            per[sc] = one(sc)
+        base = len(per[1.0][1])
+        for unlocked, extra in ((len(per[1.5][1]) > base * 0.1, (2.0, 2.5)), (len(per[0.7][1]) > base * 0.1, (0.5, 0.6))):
+            if unlocked:
+                for sc in extra:
+                    r = one(sc)
+                    if len(r[1]) < base * 0.05:
+                        break
+                    per[sc] = r
+                    order.append(sc)
+        self.scales_visited[(key, target_class)] = list(order)
+        rm, rs = P.multiscale_merge(per, order)
+        return rm, rs, [target_class] * len(rs)
+
     # inference.py:2299-2485
     def tile_pipeline(self, model_ids, key, image, target_class, small_classes, conf, tile_size, overlap, upscale,
                       iou_threshold, edge_filter=True):
         h, w = image.shape[:2]
-        fm, fs, fc = self.class_pass(model_ids, (key, "full"), image, target_class, small_classes, conf, iou_threshold)
+        if self.multiscale_enabled and self.class_settings.get(f"class_{target_class}", {}).get("use_multiscale", False):
+            fm, fs, fc = self.multiscale_pass(model_ids, key, image, target_class, small_classes, conf, iou_threshold)
+        else:
+            fm, fs, fc = self.class_pass(model_ids, (key, "full"), image, target_class, small_classes, conf, iou_threshold)
         tiles = P.generate_tiles_with_overlap(image, tile_size, overlap)
         tm_all, ts_all, tc_all = [], [], []
         for ti, (tile, x_off, y_off) in enumerate(tiles):
@@ -123,7 +165,13 @@ class RefPipeline:
             if tm_all:
                 raise ValueError("operands could not be broadcast together")  # N4
             return [], [], []
-        return P.deduplicate_masks_smart(list(fm) + tm_all, list(fs) + ts_all, list(fc) + tc_all, 0.4)
+        masks, scores, classes = list(fm) + tm_all, list(fs) + ts_all, list(fc) + tc_all
+        if self.merge_mode == "soft_nms":
+            if not masks:
+                return [], [], []
+            order, rs = P.soft_nms_masks(masks, scores, classes, self.soft_nms_sigma, self.soft_nms_thr)
+            return [masks[i] for i in order], rs, [classes[i] for i in order]
+        return P.deduplicate_masks_smart(masks, scores, classes, 0.4)
 
     # inference.py:1626-1736
     def small_classes(self, sample: Sequence[Tuple[str, np.ndarray]]):

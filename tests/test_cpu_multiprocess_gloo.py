@@ -107,3 +107,62 @@ def test_single_process_roundtrip_and_sharding():
     np.testing.assert_array_equal(packed.numpy(), _pack(m).numpy() if len(m) else packed.numpy())
     assert gs == [float(v) for v in s] and gu == [5] * len(s)
     assert int(pay.numel()) * 4 < max(1, m.size // 8)           # cropped payload is smaller than the full frames
+
+
+def _worker_capacity(rank, world, port, h, w, out):
+    """Four exchanges in one job with tables of very different sizes: the agreed capacity is used when it fits (one
+    collective, one host wait), outgrown once (every rank redoes that exchange exactly), and the result is always exact."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from deepemia_amd import parallel as PL
+
+    PL.reset_capacity()
+    tables, log = [], []
+    for step, n_units in enumerate((6, 5, 40, 3)):          # 40 units: far more rows than 1.5 x the previous maximum
+        mine = PL.shard_indices(n_units, rank, world)
+        masks, scores, classes, units = [np.zeros((0, h, w), bool)], [], [], []
+        for u in mine:
+            m, s, c = _make_unit(100 * step + u, h, w)
+            masks.append(m)
+            scores += list(s)
+            classes += list(c)
+            units += [u] * len(s)
+        masks = np.concatenate(masks)
+        bb, area = _bbox_area(masks)
+        hdr, pay = PL.encode_instance_table(_pack(masks) if len(masks) else None, scores, classes, units, bb, area)
+        before = dict(PL.stats)
+        gh, gp = PL.all_gather_instance_tables(hdr, pay)
+        log.append((PL.stats["size_exchanges"] - before["size_exchanges"], PL.stats["host_syncs"] - before["host_syncs"]))
+        packed, gs, gc, gu = PL.decode_instance_table(gh, gp, h, w)
+        tables.append((packed.numpy(), gs, gc, gu))
+    out[rank] = (tables, log)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_agreed_capacity_exchange_is_exact_and_needs_one_host_wait_in_steady_state():
+    h, w, world = 48, 96, 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_capacity, args=(world, _free_port(), h, w, out), nprocs=world, join=True)
+    for step, n_units in enumerate((6, 5, 40, 3)):
+        em, es, ec, eu = [np.zeros((0, h, w), bool)], [], [], []
+        for u in range(n_units):
+            m, s, c = _make_unit(100 * step + u, h, w)
+            em.append(m)
+            es += [float(v) for v in s]
+            ec += [int(v) for v in c]
+            eu += [u] * len(s)
+        exp = _pack(np.concatenate(em)).numpy()
+        for r in range(world):
+            packed, gs, gc, gu = out[r][0][step]
+            assert gu == eu and gc == ec and gs == es
+            np.testing.assert_array_equal(packed, exp)
+    for r in range(world):
+        log = out[r][1]
+        assert log[0] == (1, 2)            # first exchange of a job: sizes first
+        assert log[1] == (0, 1)            # fits the agreed capacity: ONE collective, ONE host wait
+        assert log[2] == (1, 3)            # outgrown: detected from the gathered sizes, redone exactly by every rank
+        assert log[3] == (0, 1)
+    assert out[0][1] == out[1][1]

@@ -102,10 +102,73 @@ def test_bench_two_ranks_on_one_device_and_total_tiles_mode(gpu_device, tmp_path
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["steps"] == 2 and line["value"] > 0
     assert "all-gather of instance tables" in line["config"]["workload"]
     assert line["roofline"]["bound"] == "mfma" and 0 < line["roofline"]["frac"] < 1
-    # configs[4] shape on one rank: distinct tiles per step, parity checked against the CPU path on tile 0
-    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--total-tiles", "16", "--batch", "8", "--warmup", "1"], cwd=str(ROOT),
-                       capture_output=True, text=True, timeout=900)
+
+
+def test_config4_job_of_256_distinct_tiles_at_size(gpu_device):
+    """BASELINE configs[4] at its stated size on one GPU: a job of 256 DISTINCT 2048^2 tiles (16 steps of 16; step 0 holds
+    the numpy tiles, the rest are generated on the device), the whole per-tile path on every tile, the parity leg on tile 0
+    of the timed job (graph replay) against the CPU path, and the eager launch sequence against its replay."""
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--total-tiles", "256", "--batch", "16", "--warmup", "1", "--parity-only"],
+                       cwd=str(ROOT), capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stderr[-2000:] + r.stdout[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
-    assert line["steps"] == 2 and "configs[4]" in line["config"]["workload"] and line["parity"]["ok"] and line["value"] > 0
-    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["tiles_timed"] >= 3 and line["cpu_baseline"]["cpu_model"]
+    assert line["steps"] == 16 and "configs[4]" in line["config"]["workload"] and "256 distinct tiles" in line["config"]["workload"]
+    assert line["value"] > 0 and line["config"]["instances_last_step_rank0"] > 0
+    par = line["parity"]
+    assert par["ok"] and par["eager_equals_replay"] and par["mask_iou_min"] >= 0.999
+    assert par["csv_max_rel_err"] <= 1e-4 and par["csv_max_rel_err_own_mask"] <= 1e-4
+    assert "hipGraph replay" in par["checked"]
+    assert line["h2d"]["value_with_upload"] > 0 and line["h2d"]["h2d_ms_per_step"] > 0
+    assert 0 < line["roofline"]["share_of_step_time"] <= 1.0
+
+
+_RCCL_SCRIPT = r"""
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["DEEPEMIA_ROOT"])
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+from deepemia_amd import parallel as PL
+from deepemia_amd.maskset import MaskOps
+ops = MaskOps("cuda:0")
+h = w = 512
+ops.set_frame_width(w)
+g = np.random.default_rng(5)
+for step, n in enumerate((37, 30, 90)):
+    masks = np.zeros((n, h, w), dtype=bool)
+    for i in range(n):
+        y0, x0 = g.integers(0, h - 40, 2)
+        masks[i, y0:y0 + g.integers(4, 40), x0:x0 + g.integers(4, 40)] = True
+    masks[3] = False                                        # an empty mask travels as a header row without payload
+    packed = ops.from_dense(masks)
+    area, bbox = ops.area_bbox(packed)
+    scores = g.uniform(0.3, 1.0, n) * 0.6
+    classes = g.integers(0, 2, n)
+    units = np.sort(g.integers(0, 9, n))[::-1]              # descending: the merge has to permute the payload
+    hdr, pay = PL.encode_instance_table(packed, scores, classes, units, bbox.cpu().numpy(), area.cpu().numpy())
+    assert hdr.is_cuda and pay.is_cuda
+    before = dict(PL.stats)
+    gh, gp = PL.all_gather_instance_tables(hdr, pay)        # world 1, backend nccl: goes through RCCL on the device
+    assert gh.is_cuda and gp.is_cuda and PL.stats["exchanges"] == before["exchanges"] + 1
+    got, gs, gc, gu = PL.decode_instance_table(gh, gp, h, w, "cuda:0")
+    order = np.argsort(units, kind="stable")
+    assert gu == [int(u) for u in units[order]] and gc == [int(c) for c in classes[order]]
+    assert gs == [float(s) for s in scores[order]]
+    assert bool((ops.to_dense(got, w) == masks[order]).all())
+    if step == 1:
+        assert PL.stats["host_syncs"] - before["host_syncs"] == 1 and PL.stats["size_exchanges"] == before["size_exchanges"]
+torch.cuda.synchronize()
+dist.barrier()
+dist.destroy_process_group()
+print("RCCL_OK")
+"""
+
+
+def test_instance_tables_go_through_rccl_on_the_device(gpu_device):
+    """The exchange of the multi-GPU path on the backend it will use: `nccl` (= RCCL) with world size 1 on the one GPU of
+    this box -- device tensors through ``all_gather_into_tensor``, the agreed-capacity protocol, the device crop / unpack
+    kernels and the payload permutation.  (More than one GPU is not reachable from the build pool: no scaling number.)"""
+    env = dict(os.environ, DEEPEMIA_ROOT=str(ROOT), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, "-c", _RCCL_SCRIPT], cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stderr[-3000:] + r.stdout[-1000:]

@@ -412,6 +412,89 @@ def test_paste_on_oracle_inputs(env):
     assert not packed[0, n:].any()
 
 
+def test_paste_of_boxes_clipped_to_a_sliver(env):
+    """Boxes that the clip to the image leaves a few 1e-4 px wide (valid: width > 0): the sampling coordinate of their
+    columns is tens of thousands of mask cells away, beyond what a 16-bit tap index holds -- widths chosen so that a
+    WRAPPED index would land on a valid tap.  Every pixel must equal the CPU path's paste (nothing sampled there)."""
+    from oracle import maskrcnn_ref as R
+
+    eng, dev = env["eng"], env["dev"]
+    size, D = 128, 100
+    ulp = 2.0 ** -17                                       # f32 spacing just below 128
+    widths = []
+    for k in range(1, 400):                                # width = k ulps at the right image edge
+        x0 = np.float32(size) - np.float32(k * ulp)
+        wd = np.float32(size) - x0
+        for X in (126, 127):
+            ix = (((np.float32(X) + np.float32(0.5) - x0) / wd * np.float32(2) - np.float32(1)) + np.float32(1)) * np.float32(28)
+            ix = (ix - np.float32(1)) / np.float32(2)
+            if abs(float(ix)) < 2 ** 31 and abs(float(ix)) > 40000:
+                wrapped = (int(np.floor(ix)) + 32768) % 65536 - 32768
+                if -1 <= wrapped <= 27 and k not in widths:
+                    widths.append(k)
+    assert len(widths) >= 3, widths
+    widths = widths[:12]
+    n = len(widths)
+    boxes = torch.zeros((1, D, 4))
+    for i, k in enumerate(widths):
+        boxes[0, i] = torch.tensor([float(np.float32(size) - np.float32(k * ulp)), 10.0 + i, 300.0, 60.0 + i])
+    classes = torch.zeros((1, D), dtype=torch.int32)
+    prob = torch.ones((D * 196 * 4, 1, 1, 4))
+    ob, valid, packed, hint = eng.paste(prob.to(dev), boxes.to(dev), classes.to(dev), torch.tensor([n], dtype=torch.int32, device=dev),
+                                        size, size, size, size)
+    assert bool(valid[0, :n].all())
+    got = eng.unpack(packed[0, :n].contiguous(), size, size).cpu()
+    want = R.paste_masks(torch.ones((n, 28, 28)), ob[0, :n].cpu(), size, size)
+    assert torch.equal(got, want), int((got != want).sum())
+
+
+def test_per_shape_caches_are_bounded_over_many_image_sizes(env):
+    """Arenas, meta pools and captured graphs are per input shape; a folder of differently sized micrographs must not keep
+    one of each per size.  Seven distinct sizes (graphed from their second occurrence, as the pipeline does) through ONE
+    engine with two cached shapes: device memory stays bounded by the two largest arenas, shapes are evicted least recently
+    used first, and an evicted shape that comes back gives the results a fresh engine gives."""
+    from deepemia_amd.engine import MaskRCNNEngine
+
+    sd, synth, dev = env["sd"], env["synth"], env["dev"]
+    eng = MaskRCNNEngine(sd, 50, K, THR, dev, "f16x2")
+    eng.max_cached_shapes = 2
+    sizes = [(256, 256), (320, 256), (384, 320), (448, 256), (512, 384), (256, 384), (300, 500)]
+    imgs = {hw: torch.from_numpy(np.ascontiguousarray(synth.em_tile(60 + i, 512)[: hw[0], : hw[1]])).to(dev)[None]
+            for i, hw in enumerate(sizes)}
+
+    def run(e, hw, graphed):
+        r = (e.forward_graphed if graphed else e.forward)(imgs[hw])
+        out = (r.scores.clone(), r.classes.clone(), r.count.clone(), r.packed.clone())
+        del r
+        return out
+
+    torch.cuda.synchronize()
+    base = torch.cuda.memory_allocated()
+    arena_bytes, after, first = [], [], {}
+    for hw in sizes:
+        first[hw] = run(eng, hw, False)
+        run(eng, hw, True)                              # second occurrence: captured + replayed
+        torch.cuda.synchronize()
+        key = (1,) + hw
+        assert key in eng._arena and key in eng._graphs and len(eng._arena) <= 2 and len(eng._graphs) <= 2 and len(eng._meta_pools) <= 2
+        arena_bytes.append(sum(t.numel() * t.element_size() for t in eng._arena[key]))
+        after.append(torch.cuda.memory_allocated() - base)
+    assert eng.evictions == len(sizes) - 2
+    results = sum(sum(t.numel() * t.element_size() for t in v) for v in first.values())
+    big2 = sum(sorted(arena_bytes)[-2:])
+    # two arenas + two graphs' private output pools + the kept results; never one arena per size (their sum is ~3.5x big2)
+    assert max(after) <= 1.6 * big2 + results + (256 << 20), (after, arena_bytes)
+    assert sum(arena_bytes) > 2.5 * big2 * 0.9
+    # an evicted shape comes back: same bits as the first time and as a fresh engine
+    fresh = MaskRCNNEngine(sd, 50, K, THR, dev, "f16x2")
+    for hw in (sizes[0], sizes[3]):
+        again, ref = run(eng, hw, False), run(fresh, hw, False)
+        for a, b, c in zip(again, first[hw], ref):
+            assert torch.equal(a, b) and torch.equal(a, c)
+    eng.release_cached_shapes()
+    assert not eng._arena and not eng._graphs and not eng._meta_pools
+
+
 def test_unpack_and_area_bbox_bit_exact(env):
     eng, dev = env["eng"], env["dev"]
     rng = np.random.default_rng(5)

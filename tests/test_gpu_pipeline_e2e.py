@@ -140,6 +140,15 @@ def _compare(split, images, ref_rows, ref_masks, contrast=False):
                 best = (d, int((mine | rm).sum()))
         d, union = best
         assert d <= 8 or 1.0 - d / max(union, 1) >= 0.999, (uid, d, union)
+        # ... and no CSV row goes unchecked: the product's rows of this instance against the oracle's measurements of
+        # the product's OWN mask (the measurement kernels are verified on exactly the mask they saw), same 1e-4 bar
+        from oracle import pipeline_ref as PR
+        own = PR.measurement_rows(name, [mine], [int(by_id_g[uid][0][1])], CLASSES, image=images[name],
+                                  measure_contrast_distribution=contrast)
+        for r in own:
+            r[0] = uid
+        assert len(own) == len(by_id_g[uid]), (uid, len(own), len(by_id_g[uid]))
+        assert all(same(g, r) for g, r in zip(by_id_g[uid], own)), (uid, by_id_g[uid], own)
     assert len(unresolved) <= max(2, len(by_id_r) // 50), (len(unresolved), len(by_id_r), unresolved[:5])
     assert (split / "class_color_legend.txt").exists()
     for name, img in images.items():                       # --visualize: one overlay per image, same size, not the input
@@ -152,7 +161,11 @@ def _compare(split, images, ref_rows, ref_masks, contrast=False):
 @pytest.mark.parametrize("case", ["single_r50_blobby_upscale2", "ensemble_r50_r101_upscale1",
                                   "single_r50_tile200_upscale1p5_f32x3",
                                   "single_r50_blobby_upscale2_f16x2", "ensemble_r50_r101_upscale1_f16x2",
-                                  "single_r50_tile200_upscale1p5_f16x2"])
+                                  "single_r50_tile200_upscale1p5_f16x2",
+                                  # BASELINE configs[3] as ONE run: R50 + R101 ensemble, multi-scale full-image pass, soft-NMS
+                                  # merge of full-image + tile results, containment rule (flagged non-parity modes, f4:
+                                  # checked against the composed oracle, not against the reference's live path)
+                                  "configs3_ensemble_multiscale_softnms_f16x2"])
 def test_cli_inference_matches_oracle_pipeline(case, tmp_path, monkeypatch, gpu_device):
     from oracle import pipeline_ref as PR
     from deepemia_amd.data import models as DM
@@ -175,6 +188,7 @@ def test_cli_inference_matches_oracle_pipeline(case, tmp_path, monkeypatch, gpu_
         depths, bias, gain, size = [50, 101], 0.5, 6.0, 512   # blobby masks: a solid box mask flips a whole edge row on a 1e-4 px box shift
         tile = {"tile_size": 512, "overlap_ratio": 0.0, "upscale_factor": 1.0, "edge_filter_enabled": True}
     iou0, iou1 = (0.6, 0.5) if case.startswith("single") else (0.65, 0.6)
+    configs3 = case.startswith("configs3")         # (one 512 tile per image, like the ensemble case: each CPU forward costs ~1.5 s)
     # one case runs the reference's DEFAULT confidence mode (auto: thresholds from the image quality score and the GLOBAL
     # config, inference.py:288-362) and fills the contrast columns (measure_contrast_distribution, measurements.py:195-215)
     auto = case == "single_r50_tile200_upscale1p5_f16x2"
@@ -182,6 +196,13 @@ def test_cli_inference_matches_oracle_pipeline(case, tmp_path, monkeypatch, gpu_
                                       "class_specific_settings": {"class_0": {"confidence_threshold": 0.3, "iou_threshold": iou0, "min_size": 25},
                                                                   "class_1": {"confidence_threshold": 0.35, "iou_threshold": iou1, "min_size": 5}},
                                       "tile_settings": tile, "spatial_constraints": spatial}}
+    if configs3:
+        io = ds_cfg["inference_overrides"]
+        io["multiscale_settings"] = {"enabled": True}
+        io["class_specific_settings"]["class_0"]["use_multiscale"] = True
+        io["class_specific_settings"]["class_1"]["use_multiscale"] = True
+        io["merge_mode"] = "soft_nms"
+        io["soft_nms"] = {"sigma": 0.5, "score_threshold": 0.05}
     cfgdir, split, sds, images = _write_tree(tmp_path, depths, bias, gain, 2, size, ds_cfg, contrast=auto)
     _run_cli(monkeypatch, cfgdir, tmp_path)
 
@@ -197,6 +218,8 @@ def test_cli_inference_matches_oracle_pipeline(case, tmp_path, monkeypatch, gpu_
         m, s, c = ref.run_image(n, images[n], small, "auto" if auto else "manual", spatial, ensemble_enabled=True, ensemble_small_only=False)
         ref_masks[n] = m
         ref_rows.extend(PR.measurement_rows(n, m, c, CLASSES, image=images[n], measure_contrast_distribution=auto))
+    if configs3:        # the adaptive phases really ran on every (image, class), on both models
+        assert len(ref.scales_visited) == 2 * len(names) and all(len(v) >= 3 for v in ref.scales_visited.values())
     _compare(split, images, ref_rows, ref_masks, contrast=auto)
 
 
