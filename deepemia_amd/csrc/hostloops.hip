@@ -1,0 +1,107 @@
+// Host-side decision loops of the post-processing, as native code behind the C ABI.
+//
+// The reference's duplicate filters are sequential greedy loops over a few dozen masks per call (inference.py:1451-1459,
+// 2640-2671): every decision depends on the ones before it, so they stay on the host -- but as ONE native call per batch of
+// tiles over the integer tables the device reduced (pixel counts, boxes, the pair-intersection matrix of
+// demia_mask_pair_matrix), not as interpreted loops per tile.  Same integer counts, same float64 division and comparison as
+// the reference's scalar code; nothing here touches the GPU.
+#include <algorithm>
+#include <cstdint>
+#include <numeric>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+inline double iou_of(int64_t inter, int64_t a, int64_t b) {
+    const int64_t uni = a + b - inter;
+    return uni > 0 ? (double)inter / (double)uni : 0.0;     // `inter / union if union > 0 else 0` (inference.py:422-435)
+}
+
+}  // namespace
+
+// inference.py:1451-1459 for S segments: mask p of a segment is kept unless IoU(p, q) > thr for a q kept before it.
+// inter [n, ld]: row i, column j - row_first[i] = |mask_i & mask_j| for j > i (demia_mask_pair_matrix); seg_first / seg_len:
+// the masks first .. first + len - 1 of segment s take part (len may be shorter than the segment the matrix was built for).
+extern "C" int demia_host_greedy_keep(const int32_t* inter, int ld, const int32_t* row_first, const int64_t* area,
+                                      const int32_t* seg_first, const int32_t* seg_len, int S, double thr, uint8_t* keep) {
+    DEMIA_REQUIRE(inter && row_first && area && seg_first && seg_len && keep && ld > 0 && S >= 0, "args");
+    std::vector<int> kept;
+    for (int s = 0; s < S; ++s) {
+        const int f = seg_first[s], n = seg_len[s];
+        kept.clear();
+        for (int p = f; p < f + n; ++p) {
+            bool dup = false;
+            for (int q : kept) {                                  // q < p
+                const int col = p - row_first[q];
+                const int64_t it = col < ld ? inter[(long)q * ld + col] : 0;
+                if (iou_of(it, area[p], area[q]) > thr) { dup = true; break; }
+            }
+            keep[p] = dup ? 0 : 1;
+            if (!dup) kept.push_back(p);
+        }
+    }
+    return DEMIA_OK;
+}
+
+// Step 2 of deduplicate_masks_smart (inference.py:2640-2671) for T tiles, bug for bug: descending stable score
+// order (`np.argsort(scores)[::-1]`: of equal scores the HIGHER index first), `others = sorted_indices[idx + 1:]` sliced by
+// the MASK INDEX, and the box pre-filter that stores (y_min, y_max, x_min, x_max) but reads (y_min, x_min, y_max, x_max).
+// items: global mask indices of all tiles, tile t = items[tile_off[t] .. tile_off[t + 1]); scores / classes per item;
+// bbox [n_all][4] = y0, x0, y1, x1 and area [n_all] per GLOBAL mask; inter / ld / row_first as above (both masks of a pair in
+// the same matrix segment).  keep_out: per tile the LOCAL positions kept, in the order they are kept; keep_cnt [T].
+extern "C" int demia_host_dedup_smart(const int32_t* inter, int ld, const int32_t* row_first, const int64_t* area,
+                                      const int64_t* bbox, const int32_t* items, const double* scores, const int32_t* classes,
+                                      const int32_t* tile_off, int T, double thr, int32_t* keep_out, int32_t* keep_cnt) {
+    DEMIA_REQUIRE(inter && row_first && area && bbox && items && scores && classes && tile_off && keep_out && keep_cnt && ld > 0, "args");
+    std::vector<int> order, pos_after;
+    std::vector<uint8_t> hit, removed;
+    for (int t = 0; t < T; ++t) {
+        const int o = tile_off[t], n = tile_off[t + 1] - o;
+        keep_cnt[t] = 0;
+        if (n <= 0) continue;
+        order.resize(n);
+        std::iota(order.begin(), order.end(), 0);
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return scores[o + a] < scores[o + b]; });
+        std::reverse(order.begin(), order.end());
+        hit.assign((size_t)n * n, 0);
+        for (int i = 0; i < n; ++i) {
+            const int gi = items[o + i];
+            const int64_t* bi = bbox + (long)gi * 4;            // stored as (y_min, y_max, x_min, x_max) = bi[0], bi[2], bi[1], bi[3]
+            const int64_t si[4] = {bi[0], bi[2], bi[1], bi[3]};
+            for (int j = 0; j < n; ++j) {
+                if (classes[o + i] != classes[o + j]) continue;
+                const int gj = items[o + j];
+                const int64_t* bj = bbox + (long)gj * 4;
+                const int64_t sj[4] = {bj[0], bj[2], bj[1], bj[3]};
+                // ... read as (y_min, x_min, y_max, x_max): the literal test of inference.py:2685-2694
+                if (si[3] < sj[1] || sj[3] < si[1] || si[2] < sj[0] || sj[2] < si[0]) continue;
+                int64_t it;
+                if (gi == gj) it = area[gi];
+                else {
+                    const int lo = gi < gj ? gi : gj, hi = gi < gj ? gj : gi;
+                    const int col = hi - row_first[lo];
+                    it = (col >= 0 && col < ld) ? inter[(long)lo * ld + col] : 0;
+                }
+                if (it > 0 && iou_of(it, area[gi], area[gj]) > thr) hit[(size_t)i * n + j] = 1;
+            }
+        }
+        // rank[m] = position of mask m in `order`; "after[p]" = the masks at positions > p
+        pos_after.assign(n, 0);
+        for (int p = 0; p < n; ++p) pos_after[order[p]] = p;
+        removed.assign(n, 0);
+        int32_t* out = keep_out + o;
+        int cnt = 0;
+        for (int p = 0; p < n; ++p) {
+            const int idx = order[p];
+            if (removed[idx]) continue;
+            out[cnt++] = idx;
+            // `others = sorted_indices[idx + 1:]`: idx (a mask index) used as a POSITION
+            for (int j = 0; j < n; ++j)
+                if (hit[(size_t)idx * n + j] && pos_after[j] > idx) removed[j] = 1;
+        }
+        keep_cnt[t] = cnt;
+    }
+    return DEMIA_OK;
+}

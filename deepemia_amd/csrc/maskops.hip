@@ -250,6 +250,39 @@ __global__ __launch_bounds__(256) void pair_intersections_kernel(const uint32_t*
     if (threadIdx.x == 0) out[p] = acc;
 }
 
+// ---- |a_i & a_j| for EVERY pair of a segment (the masks of one tile / one call): block per mask i, one wave per
+// candidate j > i in turn; pairs whose boxes are disjoint (nearly all) cost four scalar loads.  Row i of `out`
+// ([M, ld], pre-zeroed) receives |a_i & a_j| at column j - first[i] -- the upper triangle; the host mirrors it.
+// `label` (optional): only pairs with equal labels are counted (same-class pairs of a cross-class set).
+__global__ __launch_bounds__(256) void pair_matrix_kernel(const uint32_t* __restrict__ a, const int* __restrict__ bbox,
+                                                          const int* __restrict__ first, const int* __restrict__ count,
+                                                          const int* __restrict__ label, int* __restrict__ out, int ld, int H, int W) {
+    const int i = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int f = first[i], end = f + count[i];
+    const int4 bi = reinterpret_cast<const int4*>(bbox)[i];          // y0, x0, y1, x1
+    if (bi.x < 0) return;
+    const int li = label ? label[i] : 0;
+    const int wpr = (W + 31) >> 5;
+    const uint32_t* ma = a + (long)i * H * wpr;
+    for (int j = i + 1 + wave; j < end; j += 4) {
+        if (j - f >= ld) break;
+        if (label && label[j] != li) continue;
+        const int4 bj = reinterpret_cast<const int4*>(bbox)[j];
+        const int y0 = max(bi.x, bj.x), y1 = min(bi.z, bj.z), x0 = max(bi.y, bj.y), x1 = min(bi.w, bj.w);
+        if (bj.x < 0 || y0 > y1 || x0 > x1) continue;
+        const int wx0 = x0 >> 5, rw = (x1 >> 5) - wx0 + 1, rh = y1 - y0 + 1;
+        const uint32_t* mb = a + (long)j * H * wpr;
+        int c = 0;
+        for (int t = lane; t < rh * rw; t += 64) {
+            const long o = (long)(y0 + t / rw) * wpr + wx0 + t % rw;
+            c += __popc(ma[o] & mb[o]);
+        }
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+        if (lane == 0) out[(long)i * ld + (j - f)] = c;
+    }
+}
+
 // ---- tile mask -> global frame (nearest resize + offset paste), with the edge-band test ----------
 // src [T, th, tw/32] (tile masks at network scale), dst [T, H, W/32]; tile t goes to (x_off[t], y_off[t]);
 // the mask is first resized to (tile_h, tile_w) with cv2's INTER_NEAREST rule.
@@ -427,6 +460,17 @@ extern "C" int demia_mask_pair_intersections(const uint32_t* a, const uint32_t* 
     hipLaunchKernelGGL(pair_intersections_kernel, dim3((int)P), dim3(256), 0, (hipStream_t)stream, a, b, pi, pj, bbox_a, bbox_b,
                        out, H, W);
     DEMIA_CHECK_LAUNCH("pair_intersections_kernel");
+    return DEMIA_OK;
+}
+
+extern "C" int demia_mask_pair_matrix(const uint32_t* masks, const int32_t* bbox, const int32_t* first, const int32_t* count,
+                                      const int32_t* label, int32_t* out, int64_t M, int ld, int H, int W, void* stream) {
+    DEMIA_REQUIRE(masks && bbox && first && count && out && W > 0 && ld > 0, "args");
+    if (M == 0) return DEMIA_OK;
+    DEMIA_REQUIRE(M <= 0x7fffffffL, "M");
+    hipLaunchKernelGGL(pair_matrix_kernel, dim3((int)M), dim3(256), 0, (hipStream_t)stream, masks, bbox, first, count, label, out, ld,
+                       H, W);
+    DEMIA_CHECK_LAUNCH("pair_matrix_kernel");
     return DEMIA_OK;
 }
 

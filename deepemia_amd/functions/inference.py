@@ -28,6 +28,7 @@ import torch
 
 from ..data.datasets import DatasetCatalog, MetadataCatalog, read_dataset_info, register_datasets
 from ..data.models import choose_and_use_model, get_trained_model_paths
+from .. import _lib as _L
 from .. import parallel
 from ..maskset import MaskOps
 from ..utils.config import get_config
@@ -241,6 +242,13 @@ class _Detections:
         self.base_idx: Optional[np.ndarray] = None
 
 
+class _PassTables:
+    """Pixel counts and tight boxes of a finished class pass (host copies): what the later stages read of it."""
+
+    def __init__(self, area: np.ndarray, bbox: np.ndarray):
+        self.area, self.bbox = area, bbox
+
+
 class EmptyEnsembleTypeError(ValueError):
     """Reference behaviour N4: ``np.array([]) + [masks...]`` raises and the image is skipped."""
 
@@ -284,6 +292,7 @@ class InferencePipeline:
         self._shape_seen: Dict[tuple, int] = {}
         self.last_batch_stats = None
         self.forward_calls = 0
+        self.d2h_waits = 0                       # device-to-host waits of the post-processing (finish_forward + process_tile_batch)
         import torch.distributed as dist
         self.rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
         self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
@@ -331,10 +340,15 @@ class InferencePipeline:
             for t in (raw.packed, raw.bbox, raw.scores, raw.classes, raw.valid, raw.count, raw.boxes):
                 if t is not None:
                     t.record_stream(cur)
-            counts = raw.count.cpu().numpy()
-            valid = raw.valid.cpu().numpy().astype(bool)
-            scores = raw.scores.cpu().numpy()
-            classes = raw.classes.cpu().numpy().astype(np.int64)
+            # ONE device-to-host copy for the forward's small tables (the wait for the forward itself)
+            nb, nd = int(raw.count.shape[0]), int(raw.scores.shape[1])
+            tab = torch.cat([raw.count.reshape(-1), raw.valid.reshape(-1).to(torch.int32), raw.scores.reshape(-1).view(torch.int32),
+                             raw.classes.reshape(-1)]).cpu().numpy()
+            self.d2h_waits += 1
+            counts = tab[:nb]
+            valid = tab[nb:nb + nb * nd].reshape(nb, nd).astype(bool)
+            scores = tab[nb + nb * nd:nb + 2 * nb * nd].view(np.float32).reshape(nb, nd)
+            classes = tab[nb + 2 * nb * nd:].reshape(nb, nd).astype(np.int64)
             # ONE view object per forward: detections of the same forward are recognised by `base is base`
             base = None if raw.bbox is None else raw.packed.view((-1,) + tuple(raw.packed.shape[2:]))
             base_bbox = None if raw.bbox is None else raw.bbox.view(-1, 4)
@@ -1013,6 +1027,191 @@ class InferencePipeline:
     def process_tile_batch(self, key: str, tiles: torch.Tensor, small_classes, class_thresholds: Dict[int, Tuple[float, float]],
                            spatial_cfg: Optional[dict] = None, um_pix: float = 1.0, model_ids: Sequence[int] = (0,),
                            dets: Optional[List[_Detections]] = None):
+        """The per-tile unit of work of the headline metric (see :meth:`process_tile_batch_hostloops` for the stages).
+        Single-model calls take the THREE-WAIT path: the class passes of all classes are enqueued back to back with every
+        data-dependent choice (the column-count truncation, the `> 2 masks` gate) made on the device, the pair counts come
+        from ``demia_mask_pair_matrix`` (pair list made on the device), and the host waits once for the tables of all class
+        passes, runs the greedy loops as ONE native call per class (``demia_host_greedy_keep``), enqueues the cross-class
+        stage (gather, contour trace, measurements of every candidate, pair matrix) and waits once more before the native
+        smart dedup (``demia_host_dedup_smart``).  With the forward's own result that is three device-to-host waits per
+        batch, whatever its size.  Same keep lists, masks and records as the host-loop version, which stays as its checker
+        (``tests/test_gpu_parity_maskops.py``)."""
+        if len(model_ids) > 1:
+            return self.process_tile_batch_hostloops(key, tiles, small_classes, class_thresholds, spatial_cfg, um_pix, model_ids, dets)
+        if dets is None:
+            dets = self._predict_batch(model_ids[0], key, tiles)
+        ops, dev, lib = self.ops, self.dev, self.ops.lib
+        ops.set_frame_width(int(tiles.shape[2]))
+        T = len(dets)
+        out = [(None, [], [], []) for _ in range(T)]
+        self.last_batch_stats = [(np.zeros((0,), dtype=np.int64), np.zeros((0, 4), dtype=np.int64)) for _ in range(T)]
+        # ---- class passes: enqueue all, wait once ---------------------------------------------------------------
+        handles = [self._single_class_pass_launch(dets, cls, small_classes, conf) for cls, (conf, _) in class_thresholds.items()]
+        live = [h for h in handles if h is not None]
+        if not live:
+            return out
+        host = torch.cat([t_ for h in live for t_ in (h["ncols"], h["area"], h["bbox"].reshape(-1), h["I"].reshape(-1))]).cpu().numpy()
+        self.d2h_waits += 1
+        passes, pos = [], 0
+        for (cls, (_, iou_thr)), h in zip(class_thresholds.items(), handles):
+            if h is None:
+                continue
+            n, ld = h["n"], h["ld"]
+            tabs = dict(ncols=host[pos:pos + T], area=host[pos + T:pos + T + n].astype(np.int64),
+                        bbox=host[pos + T + n:pos + T + 5 * n].reshape(n, 4).astype(np.int64),
+                        I=np.ascontiguousarray(host[pos + T + 5 * n:pos + T + 5 * n + n * ld]).reshape(n, ld))
+            pos += T + 5 * n + n * ld
+            big, res, calg = self._single_class_pass_finish(h, tabs, cls in small_classes, iou_thr)
+            if any(len(k) for k, _ in res):
+                passes.append((cls, big, res, calg))
+        total = sum(len(k) for _, _, res, _ in passes for k, _ in res)
+        if total == 0:
+            return out
+        # ---- what survives, gathered once per class into `allp` (class-major; a (class, tile) run is contiguous) -------
+        allp = torch.empty((total,) + tuple(passes[0][1].shape[1:]), dtype=passes[0][1].dtype, device=dev)
+        tile_items: List[List[int]] = [[] for _ in range(T)]
+        scores_all = np.zeros(total, dtype=np.float64)
+        classes_all = np.zeros(total, dtype=np.int32)
+        run_first = np.zeros(total, dtype=np.int32)
+        run_count = np.zeros(total, dtype=np.int32)
+        area_parts, bbox_parts = [], []
+        off = 0
+        for cls, big, res, calg in passes:
+            src = [i for kept, _ in res for i in kept]
+            p0 = off
+            for t, (kept, sc) in enumerate(res):
+                k = len(kept)
+                tile_items[t].extend(range(p0, p0 + k))
+                scores_all[p0:p0 + k] = sc
+                run_first[p0:p0 + k] = p0
+                run_count[p0:p0 + k] = k
+                p0 += k
+            classes_all[off:off + len(src)] = cls
+            ops.gather_regions(big, src, calg.bbox[src], out=allp[off:off + len(src)])   # tight boxes of the class pass
+            area_parts.append(calg.area[src])
+            bbox_parts.append(calg.bbox[src])
+            off += len(src)
+        area_all = np.concatenate(area_parts)
+        bbox_all = np.ascontiguousarray(np.concatenate(bbox_parts))
+        bbox_dev = ops.upload(bbox_all.astype(np.int32))
+        # ---- cross-class stage (a14 at 0.7): trace + measure every candidate + same-class pair counts, ONE wait -------
+        cset = ops.trace(allp, max_contours=256, bbox=bbox_dev, total_area=int(area_all.sum()))
+        cset.launch_measure(um_pix, slots=4)
+        ld2 = int(run_count.max())
+        I2 = ops.pair_matrix(allp, bbox_dev, run_first, run_count, None, ld2)
+        (I2h,) = cset.fetch(extra=[I2])
+        self.d2h_waits += 1
+        per0 = cset.first_contour_perimeter()
+        ok = (bbox_all[:, 0] >= 0) & ~((per0 > 0) & ((4 * np.pi * area_all) / np.where(per0 > 0, per0, 1.0) ** 2 < 0.15))
+        keep0_all = [[i for i in tile_items[t] if ok[i]] for t in range(T)]
+        items = np.asarray([i for k0 in keep0_all for i in k0], dtype=np.int32)
+        tile_off = np.concatenate(([0], np.cumsum([len(k0) for k0 in keep0_all]))).astype(np.int32)
+        keep_out = np.zeros(max(len(items), 1), dtype=np.int32)
+        keep_cnt = np.zeros(T, dtype=np.int32)
+        if len(items):
+            sc_items = np.ascontiguousarray(scores_all[items])
+            cl_items = np.ascontiguousarray(classes_all[items])
+            I2c = np.ascontiguousarray(I2h, dtype=np.int32)
+            _L.check(lib.demia_host_dedup_smart(I2c.ctypes.data, ld2, run_first.ctypes.data, area_all.ctypes.data, bbox_all.ctypes.data,
+                                                items.ctypes.data, sc_items.ctypes.data, cl_items.ctypes.data, tile_off.ctypes.data, T, 0.7,
+                                                keep_out.ctypes.data, keep_cnt.ctypes.data), "demia_host_dedup_smart")
+        final_idx: List[List[int]] = []
+        alg = None
+        for t in range(T):
+            k0 = keep0_all[t]
+            keep = keep_out[tile_off[t]:tile_off[t] + keep_cnt[t]].tolist()
+            gl = [k0[i] for i in keep]
+            sc, cl = [scores_all[i] for i in gl], [int(classes_all[i]) for i in gl]
+            sc = [self._score_type(v) for v in sc]
+            if gl and spatial_cfg is not None and spatial_cfg.get("enabled", False):
+                if alg is None:                 # the containment / overlap rules ask for arbitrary pairs: the general algebra
+                    alg = DeviceMaskAlgebra(ops, allp, area=area_all, bbox=bbox_all, blocks=tile_items)
+                kk = apply_spatial_constraints_indices(alg.view(gl), sc, cl, spatial_cfg)
+                gl, sc, cl = [gl[i] for i in kk], [sc[i] for i in kk], [cl[i] for i in kk]
+            final_idx.append(gl)
+            out[t] = (None, sc, cl, [])
+        flat = [i for gl in final_idx for i in gl]
+        if not flat:
+            return out
+        finalp = ops.gather_regions(allp, flat, bbox_all[flat])
+        recs = cset.records(um_pix=um_pix, measure=True, select=flat)
+        pos = 0
+        self.last_batch_stats = [(area_all[final_idx[t]], bbox_all[final_idx[t]]) for t in range(T)]
+        for t in range(T):
+            n = len(final_idx[t])
+            if n:
+                out[t] = (finalp[pos:pos + n], out[t][1], out[t][2], recs[pos:pos + n])
+            pos += n
+        return out
+
+    @staticmethod
+    def _score_type(v):
+        return np.float32(v)          # single-model scores are the predictor's float32 values
+
+    # ---- single-model class pass over many tiles, in two halves: everything that can be enqueued without knowing a
+    # ---- device result (launch), then the host decisions over the fetched tables (finish)
+    def _single_class_pass_launch(self, dets: Sequence[_Detections], target_class: int, small_classes, conf):
+        T, ops = len(dets), self.ops
+        sels = []
+        for det in dets:
+            sel = np.nonzero(det.classes == target_class)[0]
+            sel = sel[det.scores[sel] >= conf]
+            if len(sel) and bool(det.scores[sel].all()) < 0.5:
+                sel = sel[:0]                                     # `ori_score.all() < score_threshold` (mask_utils.py:59): nothing kept
+            sels.append(sel)
+        lens = np.asarray([len(x) for x in sels], dtype=np.int32)
+        n = int(lens.sum())
+        if n == 0:
+            return None
+        packed, bbox = self._gather_selected(dets, sels)
+        is_small = target_class in small_classes
+        min_size = self.class_specific_settings.get(f"class_{target_class}", {}).get("min_size", 5 if is_small else 25)
+        starts = np.concatenate(([0], np.cumsum(lens))).astype(np.int32)
+        seg_np = np.repeat(np.arange(T, dtype=np.int32), lens)
+        first_np = starts[seg_np]
+        tab = ops.upload(np.stack([seg_np, np.arange(n, dtype=np.int32) - first_np, lens[seg_np]]))
+        seg, rank, nt = tab[0], tab[1], tab[2]
+        # the column-count truncation quirk (mask_utils.py:62-68) ON THE DEVICE: a call keeps its first min(n, columns) masks.
+        # The truncated tail stays in the batch as dead weight -- every later stage is per mask or only looks at EARLIER masks
+        # of the call (overlap removal), so the live masks come out exactly as if the tail had been cut -- and the host cuts
+        # it from its index lists once it has the counts.
+        ncols = (ops.column_counts(packed, seg, T, bbox=bbox) > min_size).sum(dim=1).to(torch.int32)
+        nc_m = ncols[seg.long()]
+        newlen_m = torch.where(nc_m >= nt, nt, nc_m)
+        _, bbox, _ = ops.program_(packed, ["fill", "dilate", "erode"], bbox)
+        ops.overlap_prefix_(packed, seg, bbox)
+        if self.parallel_mask_processing:
+            active = ((rank < newlen_m) & (newlen_m > 2)).to(torch.uint8)         # process_masks_parallel: calls with > 2 masks
+            area, bbox, _ = ops.program_(packed, ["drop_multi", "gate", "fill", "erode", "dilate"], bbox, active)
+        else:
+            area, bbox, _ = ops.program_(packed, ["drop_multi"], bbox)
+        ld = int(lens.max())
+        I = ops.pair_matrix(packed, bbox, first_np, lens[seg_np], None, ld)
+        return dict(packed=packed, area=area, bbox=bbox, ncols=ncols, I=I, sels=sels, lens=lens, starts=starts, first=first_np,
+                    n=n, ld=ld, T=T, dets=dets)
+
+    def _single_class_pass_finish(self, h: dict, tabs: dict, is_small: bool, iou_threshold: float):
+        T, lens, starts = h["T"], h["lens"], h["starts"]
+        ncols = tabs["ncols"]
+        new_lens = np.asarray([(int(lens[t]) if ncols[t] >= lens[t] else int(ncols[t])) if lens[t] else 0 for t in range(T)], dtype=np.int32)
+        thr = 0.5 if is_small else iou_threshold
+        keep = np.zeros(h["n"], dtype=np.uint8)
+        area = np.ascontiguousarray(tabs["area"], dtype=np.int64)
+        seg_first = np.ascontiguousarray(starts[:-1], dtype=np.int32)
+        _L.check(self.ops.lib.demia_host_greedy_keep(tabs["I"].ctypes.data, h["ld"], h["first"].ctypes.data, area.ctypes.data,
+                                                     seg_first.ctypes.data, new_lens.ctypes.data, T, float(thr), keep.ctypes.data),
+                 "demia_host_greedy_keep")
+        res = []
+        for t in range(T):
+            s0 = int(starts[t])
+            kept = (s0 + np.nonzero(keep[s0:s0 + int(new_lens[t])])[0]).tolist()
+            sc = h["dets"][t].scores[h["sels"][t]] if lens[t] else []
+            res.append((kept, [sc[i - s0] for i in kept]))
+        return h["packed"], res, _PassTables(area, np.ascontiguousarray(tabs["bbox"], dtype=np.int64))
+
+    def process_tile_batch_hostloops(self, key: str, tiles: torch.Tensor, small_classes, class_thresholds: Dict[int, Tuple[float, float]],
+                                     spatial_cfg: Optional[dict] = None, um_pix: float = 1.0, model_ids: Sequence[int] = (0,),
+                                     dets: Optional[List[_Detections]] = None):
         """The per-tile unit of work of the headline metric: one batched forward for B independent tiles, then per
         tile the class loop (a6, a9, a11, a12), the cross-class dedup (a14, 0.7), the spatial constraints (a15) and the
         contour measurements (a17, a18).  Every kernel is launched ONCE for all tiles (segment-aware where the

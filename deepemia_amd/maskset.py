@@ -39,6 +39,23 @@ class MaskOps:
     def _stream(self) -> int:
         return int(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def upload(self, arr: np.ndarray) -> torch.Tensor:
+        """Host table -> device WITHOUT queueing the host behind the current stream's backlog: a copy from pageable memory
+        returns only when it has run, and on the post-processing stream that means after every kernel already enqueued
+        there (each of which waits for a CU beside the resident convolution workgroups).  The copy goes through a side
+        stream that is always empty; the current stream waits for its event."""
+        t = torch.from_numpy(np.ascontiguousarray(arr))
+        cur = torch.cuda.current_stream(self.device)
+        if getattr(self, "_up_stream", None) is None:
+            self._up_stream = torch.cuda.Stream(device=self.device)
+        with torch.cuda.stream(self._up_stream):
+            d = t.to(self.device)
+            ev = torch.cuda.Event()
+            ev.record(self._up_stream)
+        cur.wait_event(ev)
+        d.record_stream(cur)
+        return d
+
     # -- construction -------------------------------------------------------------------------
     def from_dense(self, masks: np.ndarray) -> torch.Tensor:
         """(M, H, W) bool/uint8 host array -> packed device tensor (test / interop helper)."""
@@ -94,6 +111,26 @@ class MaskOps:
                                                           _lib.ptr(bbox_b), _lib.ptr(out), P, H, self._w(a), self._stream()),
                    "demia_mask_pair_intersections")
         return out.cpu().numpy().astype(np.int64)
+
+    def pair_matrix(self, packed: torch.Tensor, bbox: torch.Tensor, first: np.ndarray, count: np.ndarray,
+                    label: Optional[np.ndarray] = None, ld: Optional[int] = None) -> torch.Tensor:
+        """[M, ld] int32 ON THE DEVICE: row i, column j - first[i] = |mask_i & mask_j| for every j > i of mask i's segment
+        (``first[i]`` / ``count[i]``: start and length of that segment; ``label``: equal-label pairs only).  The pair
+        list is made on the device from the boxes -- no host round trip between the stage that reduces the boxes and the
+        counts (``demia_mask_pair_matrix``).  The caller fetches it together with whatever else it waits for."""
+        M, H, wpr = packed.shape
+        if ld is None:
+            ld = max(1, int(np.max(count)) if M else 1)
+        out = torch.zeros((M, ld), dtype=torch.int32, device=self.device)
+        if M == 0:
+            return out
+        tab = np.stack([np.asarray(first, dtype=np.int32), np.asarray(count, dtype=np.int32),
+                        np.asarray(label if label is not None else np.zeros(M), dtype=np.int32)])
+        tt = self.upload(tab)
+        _lib.check(self.lib.demia_mask_pair_matrix(_lib.ptr(packed), _lib.ptr(bbox), _lib.ptr(tt[0]), _lib.ptr(tt[1]),
+                                                   _lib.ptr(tt[2]) if label is not None else 0, _lib.ptr(out), M, ld, H, self._w(packed),
+                                                   self._stream()), "demia_mask_pair_matrix")
+        return out
 
     def gray_histogram(self, packed: torch.Tensor, image: torch.Tensor, bbox: Optional[torch.Tensor] = None) -> np.ndarray:
         """[M, 256] gray-level counts of ``image`` ([H, W, 3] BGR or [H, W] gray, uint8, on the device) under each mask:
@@ -165,9 +202,9 @@ class MaskOps:
         """``src[index]`` for masks that are zero outside ``bbox`` (a superset of their tight boxes; -1 = empty): reads the
         boxes only, writes each destination plane once.  ``index``: int sequence / array (or an i64 device tensor), ``bbox``
         [n, 4] numpy or i32 device tensor, row i belonging to ``index[i]``."""
-        idx = index if torch.is_tensor(index) else torch.as_tensor(np.asarray(index, dtype=np.int64), device=self.device)
+        idx = index if torch.is_tensor(index) else self.upload(np.asarray(index, dtype=np.int64))
         idx = idx.to(device=self.device, dtype=torch.int64).contiguous()
-        bb = bbox if torch.is_tensor(bbox) else torch.as_tensor(np.ascontiguousarray(bbox, dtype=np.int32), device=self.device)
+        bb = bbox if torch.is_tensor(bbox) else self.upload(np.ascontiguousarray(bbox, dtype=np.int32))
         bb = bb.to(device=self.device, dtype=torch.int32).contiguous()
         n = int(idx.shape[0])
         assert bb.shape == (n, 4) and src.is_contiguous() and src.dtype == torch.int32
@@ -249,6 +286,65 @@ class ContourSet:
                           int(cnt[0]))
         return self._host
 
+    def launch_measure(self, um_pix: float = 1.0, slots: int = 4) -> None:
+        """Enqueue the measurements of the first ``slots`` contours of EVERY mask right behind the trace, without waiting
+        for the contour counts: :meth:`fetch` then brings counts, contour tables and values to the host with ONE wait.
+        (Masks with more contours than ``slots`` -- rare -- are measured again by :meth:`measure` on demand.)"""
+        ops = self.ops
+        M, C, mp = self.M, self.C, self.max_points
+        self._mslots, self._m_um = int(slots), float(um_pix)
+        self._wi = torch.empty((int(ops.lib.demia_contour_work_ints(M, C, mp)),), dtype=torch.int32, device=ops.device)
+        self._wf = torch.empty((int(ops.lib.demia_contour_work_floats(M, C, mp)),), dtype=torch.float32, device=ops.device)
+        self._wd = torch.empty((int(ops.lib.demia_contour_work_doubles(M, C, mp)),), dtype=torch.float64, device=ops.device)
+        self._vals_dev = torch.zeros((M, self._mslots, 12), dtype=torch.float64, device=ops.device)
+        _lib.check(ops.lib.demia_contour_measure(0, _lib.ptr(self.count), _lib.ptr(self.info), _lib.ptr(self.red),
+                                                 _lib.ptr(self.points), M, C, mp, _lib.ptr(self._wi), _lib.ptr(self._wf), _lib.ptr(self._wd),
+                                                 float(um_pix), _lib.ptr(self._vals_dev), self._mslots, ops._stream()), "demia_contour_measure")
+
+    def fetch(self, extra: Optional[Sequence[torch.Tensor]] = None):
+        """ONE device-to-host wait for everything the host decides on: counters, contour counts, the first ``slots``
+        contour slots of every mask (info, area / perimeter, measurement values when :meth:`launch_measure` ran) and the
+        int32 device tensors in ``extra`` (returned as numpy arrays).  Falls back to the sliced copy of :meth:`host` when a
+        mask has more contours than the slots fetched."""
+        M = self.M
+        k = getattr(self, "_mslots", 4)
+        k = min(k, self.C)
+        parts = [self.counters, self.count, self.info[:, :k].reshape(-1)]
+        f64 = [self.red[:, :k].reshape(-1)]
+        if getattr(self, "_vals_dev", None) is not None:
+            f64.append(self._vals_dev.reshape(-1))
+        extra = list(extra or [])
+        parts += [e.reshape(-1) for e in extra]
+        if sum(int(t.numel()) for t in parts) % 2:            # keep the float64 block 8-byte aligned in the host copy
+            parts.append(torch.zeros((1,), dtype=torch.int32, device=self.ops.device))
+        ints = torch.cat(parts)
+        dbl = torch.cat(f64).view(torch.int32)
+        host = torch.cat([ints, dbl]).cpu().numpy()            # the wait
+        pos = 0
+        cnt = host[pos:pos + 4]; pos += 4
+        count = host[pos:pos + M]; pos += M
+        info = host[pos:pos + M * k * 4].reshape(M, k, 4); pos += M * k * 4
+        outs = []
+        for e in extra:
+            outs.append(host[pos:pos + e.numel()].reshape(tuple(e.shape)))
+            pos += e.numel()
+        d = host[int(ints.numel()):].view(np.float64)
+        red = d[:M * k * 2].reshape(M, k, 2)
+        if cnt[1] != 0:
+            raise _lib.HipKernelError(f"contour extraction overflow (flags {int(cnt[1])}): raise max_contours / max_points")
+        self.walker_stats = (int(cnt[3]), int(cnt[2]))
+        mc = max(1, int(count.max()) if M else 1)
+        if mc <= k:
+            self.max_count = mc
+            self._host = (count, info[:, :mc], red[:, :mc], int(cnt[0]))
+            if getattr(self, "_vals_dev", None) is not None:
+                self._vals_host = d[M * k * 2:].reshape(M, k, 12)[:, :mc]
+        else:                                                     # a mask with many contours: the general (two-wait) path
+            self._host = None
+            self._vals_host = None
+            self.host()
+        return outs
+
     def first_contour_perimeter(self) -> np.ndarray:
         """Perimeter of ``contours[0]`` (OpenCV order: the contour with the greatest (start y, start x)) per mask,
         -1 where a mask has no contour -- what ``deduplicate_masks_smart``'s compactness test reads."""
@@ -266,6 +362,9 @@ class ContourSet:
         """[M, max contours per mask, 12] measurement values (only for the selected masks when ``select`` is given)."""
         ops = self.ops
         self.host()
+        pre = getattr(self, "_vals_host", None)
+        if pre is not None and abs(getattr(self, "_m_um", um_pix) - um_pix) == 0.0:
+            return pre                                    # measured for every mask right behind the trace (launch_measure)
         M, C, mp, mc = self.M, self.C, self.max_points, self.max_count
         sel_t = None
         if select is not None:

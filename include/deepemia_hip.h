@@ -328,6 +328,23 @@ int demia_mask_column_counts(const uint32_t* masks, const int32_t* seg, const in
 int demia_mask_pair_intersections(const uint32_t* a, const uint32_t* b, const int32_t* pi, const int32_t* pj,
                                   const int32_t* bbox_a, const int32_t* bbox_b, int32_t* out, int64_t P,
                                   int H, int W, void* stream);
+/* pair_matrix: the intersection counts of EVERY pair inside a segment (the masks of one tile or one class pass) in one
+ * launch, with the pair list made on the device from the boxes -- what the greedy IoU loops (inference.py:1451-1459) and
+ * step 2 of deduplicate_masks_smart (inference.py:2640-2671) ask for, without a host round trip to build the list.
+ * first[i] / count[i]: first mask and length of mask i's segment; label (optional): only equal-label pairs are counted;
+ * out [M, ld] pre-zeroed, out[i][j - first[i]] = np.count_nonzero(mask_i & mask_j) for j > i (upper triangle). */
+int demia_mask_pair_matrix(const uint32_t* masks, const int32_t* bbox, const int32_t* first, const int32_t* count,
+                           const int32_t* label, int32_t* out, int64_t M, int ld, int H, int W, void* stream);
+/* Host-side decision loops (no GPU work): the reference's sequential greedy filters for a whole batch of tiles in one
+ * native call over the integer tables the device reduced.  inter [n, ld] / row_first: the matrix of demia_mask_pair_matrix
+ * (host copy).  greedy_keep: inference.py:1451-1459 per segment (keep[p] = 0 / 1).  dedup_smart: step 2 of
+ * deduplicate_masks_smart, inference.py:2640-2671, bug for bug; items / scores / classes per tile entry,
+ * bbox [n][4] = y0, x0, y1, x1 and area [n] per global mask; keep_out = kept LOCAL positions per tile in keeping order. */
+int demia_host_greedy_keep(const int32_t* inter, int ld, const int32_t* row_first, const int64_t* area, const int32_t* seg_first,
+                           const int32_t* seg_len, int S, double thr, uint8_t* keep);
+int demia_host_dedup_smart(const int32_t* inter, int ld, const int32_t* row_first, const int64_t* area, const int64_t* bbox,
+                           const int32_t* items, const double* scores, const int32_t* classes, const int32_t* tile_off, int T,
+                           double thr, int32_t* keep_out, int32_t* keep_cnt);
 int demia_mask_place_tiles(const uint32_t* src, uint32_t* dst, const int32_t* x_off, const int32_t* y_off, int64_t T,
                            int src_h, int src_w, int tile_h, int tile_w, int H, int W, void* stream);
 /* Instance tables (what the ranks exchange before the global duplicate / containment filters,

@@ -511,3 +511,103 @@ def test_scalebar_line_selection_merge_and_calibration(monkeypatch):
     assert I.detect_scale_bar(None) == ("500", 0.25) and not I.scale_bar_needs_image("x")
     monkeypatch.setattr(I, "_scale_bar_settings", lambda name: {})
     assert I.detect_scale_bar(img) == ("0", 1.0)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# native decision loops (deepemia_amd/csrc/hostloops.hip) against the Python loops they replace
+class _FakeAlgebra:
+    """What ``InferencePipeline._greedy_keep`` / ``_dedup_smart_order`` read of a DeviceMaskAlgebra, from plain arrays."""
+
+    def __init__(self, inter, area):
+        self.I = inter.astype(np.int64)
+        self.area = area.astype(np.int64)
+        self.known = np.ones(inter.shape, dtype=bool)
+        self.n = len(area)
+
+    def intersections(self, pi, pj):          # pragma: no cover - every pair is known
+        raise AssertionError("unexpected device call")
+
+
+def _random_segments(g, seg_lens, quantised=False):
+    """Areas, boxes and a consistent random pair-intersection table for masks in contiguous segments."""
+    n = int(sum(seg_lens))
+    area = g.integers(40, 4000, n).astype(np.int64)
+    if quantised:
+        area = (area // 200 + 1) * 200                       # many equal areas: IoUs that sit ON common thresholds
+    first = np.repeat(np.concatenate(([0], np.cumsum(seg_lens)[:-1])), seg_lens).astype(np.int32)
+    inter = np.zeros((n, n), dtype=np.int64)
+    for s0, ln in zip(np.concatenate(([0], np.cumsum(seg_lens)[:-1])), seg_lens):
+        for i in range(s0, s0 + ln):
+            for j in range(i + 1, s0 + ln):
+                if g.random() < 0.35:
+                    hi = min(area[i], area[j])
+                    v = int(g.integers(0, hi + 1)) if not quantised else int(g.choice([0, hi // 2, hi // 3, hi]))
+                    inter[i, j] = inter[j, i] = v
+    inter[np.arange(n), np.arange(n)] = area
+    y0 = g.integers(0, 200, n)
+    x0 = g.integers(0, 200, n)
+    bbox = np.stack([y0, x0, y0 + g.integers(1, 120, n), x0 + g.integers(1, 120, n)], axis=1).astype(np.int64)
+    return area, bbox, inter, first
+
+
+def test_native_greedy_keep_and_smart_dedup_equal_the_python_loops():
+    import ctypes as C
+    from deepemia_amd import _lib
+    from deepemia_amd.functions.inference import InferencePipeline as IP
+
+    lib = _lib.load()
+    g = np.random.default_rng(11)
+    for trial in range(12):
+        quant = trial % 2 == 1
+        seg_lens = [int(v) for v in g.integers(0, 40, int(g.integers(1, 9)))]
+        n = sum(seg_lens)
+        if n == 0:
+            continue
+        area, bbox, inter, first = _random_segments(g, seg_lens, quant)
+        ld = max(seg_lens)
+        mat = np.zeros((n, ld), dtype=np.int32)              # the device layout: row i, column j - first[i], j > i
+        for i in range(n):
+            for j in range(i + 1, n):
+                if first[j] == first[i]:
+                    mat[i, j - first[i]] = inter[i, j]
+        alg = _FakeAlgebra(inter, area)
+        starts = np.concatenate(([0], np.cumsum(seg_lens))).astype(np.int32)
+        # ---- greedy keep: every segment, also with a shortened (truncated) length
+        for cut in (0, 3):
+            lens = np.asarray([max(0, ln - cut) for ln in seg_lens], dtype=np.int32)
+            for thr in (0.5, 0.7, 1.0 / 3.0):
+                keep = np.zeros(n, dtype=np.uint8)
+                _lib.check(lib.demia_host_greedy_keep(mat.ctypes.data, ld, first.ctypes.data, area.ctypes.data, starts[:-1].copy().ctypes.data,
+                                                      lens.ctypes.data, len(seg_lens), float(thr), keep.ctypes.data), "greedy")
+                for s, (s0, ln) in enumerate(zip(starts[:-1], lens)):
+                    want = IP._greedy_keep(alg, range(int(s0), int(s0) + int(ln)), thr)
+                    got = (int(s0) + np.nonzero(keep[s0:s0 + ln])[0]).tolist()
+                    assert got == want, (trial, s, thr)
+        # ---- smart dedup: per segment a random subset in random class mix, scores with ties
+        items, scores, classes, tile_off = [], [], [], [0]
+        per_tile = []
+        for s0, ln in zip(starts[:-1], seg_lens):
+            k0 = [int(i) for i in range(s0, s0 + ln) if g.random() < 0.8]
+            sc = np.round(g.uniform(0.3, 1.0, len(k0)), 1 if quant else 6)            # 1 decimal: many ties
+            cl = g.integers(0, 2, len(k0)) if not quant else np.zeros(len(k0), dtype=np.int64)
+            per_tile.append((k0, sc, cl))
+            items += k0
+            scores += sc.tolist()
+            classes += cl.tolist()
+            tile_off.append(len(items))
+        if not items:
+            continue
+        items_a = np.asarray(items, dtype=np.int32)
+        sc_a, cl_a = np.asarray(scores, dtype=np.float64), np.asarray(classes, dtype=np.int32)
+        off_a = np.asarray(tile_off, dtype=np.int32)
+        for thr in (0.7, 0.4, 0.5):
+            keep_out = np.zeros(len(items), dtype=np.int32)
+            keep_cnt = np.zeros(len(seg_lens), dtype=np.int32)
+            _lib.check(lib.demia_host_dedup_smart(mat.ctypes.data, ld, first.ctypes.data, area.ctypes.data, bbox.ctypes.data, items_a.ctypes.data,
+                                                  sc_a.ctypes.data, cl_a.ctypes.data, off_a.ctypes.data, len(seg_lens), float(thr),
+                                                  keep_out.ctypes.data, keep_cnt.ctypes.data), "dedup")
+            for t, (k0, sc, cl) in enumerate(per_tile):
+                bb = [(int(bbox[i, 0]), int(bbox[i, 2]), int(bbox[i, 1]), int(bbox[i, 3])) for i in k0]
+                want = IP._dedup_smart_order(alg, k0, sc.tolist(), cl.tolist(), bb, thr) if k0 else []
+                got = keep_out[off_a[t]:off_a[t] + keep_cnt[t]].tolist()
+                assert got == want, (trial, t, thr)

@@ -564,3 +564,99 @@ def test_predictions_overlay_matches_the_reference_drawing_order(gpu_device, tmp
     assert (got[~text] == want[~text]).all()
     assert (got[text] == 255).all(axis=-1).any()                                           # something white was written there
     assert (got != img).any() and (got[masks.any(0) == 0] == img[masks.any(0) == 0])[~text[masks.any(0) == 0]].all()
+
+
+def test_three_wait_tile_batch_equals_the_host_loop_version_on_adversarial_detections(gpu_device):
+    """``process_tile_batch`` (class-pass choices made on the device, pair counts from ``demia_mask_pair_matrix``, greedy
+    loops in ``demia_host_greedy_keep`` / ``demia_host_dedup_smart``, three device-to-host waits) against
+    ``process_tile_batch_hostloops`` (the Python loops over host-built pair lists) on detections made to hit every branch:
+    the column-count truncation (mask_utils.py:62-68), the zero-score quirk (:59), calls with <= 2 masks (no
+    process_masks_parallel), heavy duplicates, score ties, an empty tile, both classes.  Identical keep lists, masks,
+    scores, classes and contour records; the pair matrix is also checked entry by entry against the explicit pair kernel."""
+    import types
+    from deepemia_amd.functions.inference import InferencePipeline, _Detections
+    from deepemia_amd.utils.mask_algebra import DeviceMaskAlgebra
+
+    dev = torch.device(gpu_device)
+    pipe = InferencePipeline([types.SimpleNamespace(engine=types.SimpleNamespace(device=dev))], "t", {}, {})
+    ops = pipe.ops
+    size = 256
+    ops.set_frame_width(size)
+    g = np.random.default_rng(21)
+    yy, xx = np.mgrid[0:size, 0:size]
+
+    def blob(cx, cy, a, b, th):
+        u = (xx - cx) * np.cos(th) + (yy - cy) * np.sin(th)
+        v = -(xx - cx) * np.sin(th) + (yy - cy) * np.cos(th)
+        return (u / a) ** 2 + (v / b) ** 2 <= 1.0
+
+    tiles = []
+    # tile 0: 40 blobs in overlapping families, both classes, tied scores
+    m, centres = [], []
+    for i in range(40):
+        if i % 3 and centres:
+            cx, cy = centres[int(g.integers(0, len(centres)))] + g.uniform(-6, 6, 2)
+        else:
+            cx, cy = g.uniform(30, size - 30, 2)
+        centres.append(np.array([cx, cy]))
+        m.append(blob(cx, cy, g.uniform(8, 26), g.uniform(6, 20), g.uniform(0, np.pi)))
+    sc = np.round(g.uniform(0.31, 0.99, 40), 2).astype(np.float32)
+    tiles.append((np.stack(m), np.sort(sc)[::-1].copy(), g.integers(0, 2, 40)))
+    # tile 1: five 2-column strips on the same columns: 2 columns exceed min_size -> the call keeps its first 2 masks only
+    m = np.zeros((5, size, size), dtype=bool)
+    for i in range(5):
+        m[i, 20 + 8 * i: 120 + 8 * i, 100:102] = True
+    tiles.append((m, np.asarray([0.9, 0.8, 0.7, 0.6, 0.5], dtype=np.float32), np.zeros(5, dtype=np.int64)))
+    # tile 2: two masks of class 0 (a call with <= 2 masks skips process_masks_parallel), three of class 1 with a ZERO score
+    m = np.stack([blob(60, 60, 20, 14, 0.3), blob(66, 62, 18, 15, 0.5), blob(180, 180, 22, 12, 1.0), blob(185, 176, 20, 14, 1.1),
+                  blob(100, 200, 15, 15, 0.0)])
+    tiles.append((m, np.asarray([0.95, 0.9, 0.8, 0.0, 0.7], dtype=np.float32), np.asarray([0, 0, 1, 1, 1])))
+    # tile 3: nothing; tile 4: a mask with a hole and a two-component mask (dropped) among plain ones
+    tiles.append((np.zeros((0, size, size), dtype=bool), np.zeros(0, dtype=np.float32), np.zeros(0, dtype=np.int64)))
+    ring = blob(128, 128, 40, 40, 0) & ~blob(128, 128, 22, 22, 0)
+    two = blob(40, 200, 10, 10, 0) | blob(90, 200, 10, 10, 0)
+    m = np.stack([ring, two, blob(128, 128, 12, 12, 0), blob(200, 60, 25, 18, 0.7)])
+    tiles.append((m, np.asarray([0.9, 0.85, 0.8, 0.6], dtype=np.float32), np.zeros(4, dtype=np.int64)))
+
+    def dets():
+        return [_Detections(ops.from_dense(m) if len(m) else torch.zeros((0, size, size // 32), dtype=torch.int32, device=dev), s, np.asarray(c, dtype=np.int64),
+                            (size, size)) for m, s, c in tiles]
+
+    x = torch.zeros((len(tiles), size, size, 3), dtype=torch.uint8, device=dev)
+    for thr in ({0: (0.3, 0.7), 1: (0.0, 0.5)}, {0: (0.3, 0.3), 1: (0.3, 0.4)}):
+        w0 = pipe.d2h_waits
+        a = pipe.process_tile_batch("k", x, {1}, thr, um_pix=0.5, dets=dets())
+        assert pipe.d2h_waits - w0 == 2                  # class-pass tables, cross-class tables (+ the forward's own = three)
+        b = pipe.process_tile_batch_hostloops("k", x, {1}, thr, um_pix=0.5, dets=dets())
+        n_tot = 0
+        for t, ((pa, sa, ca, ra), (pb, sb, cb, rb)) in enumerate(zip(a, b)):
+            assert (pa is None) == (pb is None), t
+            assert [float(v) for v in sa] == [float(v) for v in sb] and list(ca) == list(cb), t
+            if pa is None:
+                continue
+            assert torch.equal(pa, pb), t
+            n_tot += int(pa.shape[0])
+            for ia, ib in zip(ra, rb):
+                assert len(ia) == len(ib)
+                for u, v in zip(ia, ib):
+                    assert np.array_equal(u["points"], v["points"]) and u["area"] == v["area"] and np.array_equal(u["values"], v["values"])
+        assert n_tot > 15
+        assert a[3][0] is None and len(a[1][1]) <= 2       # the empty tile; the truncated call
+    # the pair matrix against the explicit pair kernel, all pairs of two segments
+    m = tiles[0][0]
+    packed = ops.from_dense(m)
+    area, bbox = ops.area_bbox(packed)
+    first = np.asarray([0] * 25 + [25] * 15, dtype=np.int32)
+    count = np.asarray([25] * 25 + [15] * 15, dtype=np.int32)
+    mat = ops.pair_matrix(packed, bbox, first, count, None, 25).cpu().numpy()
+    alg = DeviceMaskAlgebra(ops, packed)
+    for i in range(40):
+        for j in range(i + 1, 40):
+            if first[i] == first[j]:
+                assert mat[i, j - first[i]] == int((m[i] & m[j]).sum()) == alg.inter(i, j)
+    lab = np.asarray(tiles[0][2], dtype=np.int32)
+    mat2 = ops.pair_matrix(packed, bbox, first, count, lab, 25).cpu().numpy()
+    for i in range(40):
+        for j in range(i + 1, 40):
+            if first[i] == first[j]:
+                assert mat2[i, j - first[i]] == (int((m[i] & m[j]).sum()) if lab[i] == lab[j] else 0)
