@@ -90,7 +90,7 @@ class PasteDesc(C.Structure):
         ("mask_prob", C.c_void_p), ("ld", C.c_int32), ("det_boxes", C.c_void_p), ("det_classes", C.c_void_p),
         ("det_count", C.c_void_p), ("N", C.c_int32), ("D", C.c_int32), ("img_h", C.c_int32), ("img_w", C.c_int32),
         ("out_h", C.c_int32), ("out_w", C.c_int32), ("out_boxes", C.c_void_p), ("valid", C.c_void_p),
-        ("packed", C.c_void_p), ("out_bbox", C.c_void_p),
+        ("packed", C.c_void_p), ("out_bbox", C.c_void_p), ("prev_bbox", C.c_void_p),
     ]
 
 

@@ -30,12 +30,17 @@
 // Reference call sites replaced: every Conv2d / Linear / ConvTranspose2d executed by Detectron2 0.6
 // `GeneralizedRCNN.inference` under `predictor(image)` (reference src/functions/inference.py:1395,1398,1507,1669;
 // src/data/models.py:107).
+#include <utility>
 #include "common.h"
 #ifndef P32_ABLATE
 #define P32_ABLATE 0      // timing-only dev builds: 1 = no A DMA after the first two steps, 2 = no B DMA, 4 = no MFMAs,
                           // 32 = no residual loads, 64 = no global stores in the epilogue, 128 = one K-step only,
                           // 256 = sigmoid / nearest-2x paths compiled out (instruction counting), 512 = no epilogue passes,
                           // 1024 = no fragment reads (scripts/build_variant.sh, scripts/gpu_ablate.sh)
+#endif
+
+#ifndef P32_FRAG_PIPE
+#define P32_FRAG_PIPE 0   // 1: A fragments double-buffered in registers, reads of tile-row i + 1 pinned in front of the MFMAs of row i
 #endif
 
 namespace {
@@ -67,6 +72,23 @@ struct ConvQ {
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
+
+// two 16-byte LDS reads at a compile-time offset (inline asm: issued where they stand, invisible to hipcc's waitcnt pass);
+// WAIT >= 0: followed IN THE SAME asm block by s_waitcnt lgkmcnt(WAIT)
+template <int OFF, int WAIT>
+__device__ __forceinline__ void ds_read2_b128(f16x8& a, f16x8& b, unsigned addr_a, unsigned addr_b) {
+    if constexpr (WAIT >= 0)
+        asm volatile("ds_read_b128 %0, %2 offset:%4\n\tds_read_b128 %1, %3 offset:%4\n\ts_waitcnt lgkmcnt(%5)"
+                     : "=&v"(a), "=&v"(b) : "v"(addr_a), "v"(addr_b), "n"(OFF), "n"(WAIT) : "memory");
+    else
+        asm volatile("ds_read_b128 %0, %2 offset:%4\n\tds_read_b128 %1, %3 offset:%4"
+                     : "=&v"(a), "=&v"(b) : "v"(addr_a), "v"(addr_b), "n"(OFF) : "memory");
+}
+
+template <int... Is, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f)); }
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 // One LDS-DMA piece: 64 lanes x 16 B from `rsrc` at byte offset voff (per lane) + soff (scalar) to LDS bytes
@@ -665,6 +687,10 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 2 : 1) void conv_p32_k
         fb16[pl] = BM * 128 + (wn * TN * 32 + (lane & 15)) * 128 + ch;
     }
 
+    // (P32_FRAG_PIPE == 2, two stages: compute() also ends the K-step -- `s_waitcnt vmcnt(0); s_barrier` sits in FRONT of
+    // the last tile-row's MFMAs, whose operands are in registers by then, so the wait for the slowest wave and for this
+    // wave's DMA pieces runs under matrix work instead of after it)
+    constexpr bool BARRIER_IN_COMPUTE = (P32_FRAG_PIPE == 2) && M16 && NST == 2;
     auto compute = [&](int st) {
         const char* sb = smem + st * STAGE;
         if constexpr (M16) {
@@ -672,11 +698,98 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 2 : 1) void conv_p32_k
             f16x8 fake;                                  // timing-only builds (P32_ABLATE & 1024): no fragment reads
 #pragma unroll
             for (int q = 0; q < 8; ++q) fake[q] = (_Float16)(float)(lane + q);
+#if P32_FRAG_PIPE != 2
 #pragma unroll
             for (int j = 0; j < 2 * TN; ++j) {
                 bh[j] = (P32_ABLATE & 1024) ? fake : *reinterpret_cast<const f16x8*>(sb + fb16[0] + j * 2048);
                 bl[j] = (P32_ABLATE & 1024) ? fake : *reinterpret_cast<const f16x8*>(sb + fb16[1] + j * 2048);
             }
+#endif
+#if P32_FRAG_PIPE == 2
+            // Hand-placed fragment reads.  Left to itself hipcc keeps ONE register set for the A fragments, so every pair of
+            // tile-rows opens with `ds_read x 4; s_waitcnt` in front of its MFMAs and the matrix pipe idles for an LDS round
+            // trip four times per K-step (both waves of a SIMD at once: they run in lockstep between barriers).  Here the reads
+            // are inline asm in program order: the K-step opens with A row 0 and all B fragments; then, per tile-row i, ONE asm
+            // block requests the A fragments of row i + 1 into the OTHER register set and waits until only those two reads are
+            // outstanding (LDS reads return in order: everything older -- row i, the B fragments -- has landed), and the row's
+            // MFMAs follow behind a scheduling fence (hipcc moves register-only MFMAs across an inline `s_waitcnt` otherwise).
+            // Request and wait sit in the same asm block, so nothing the compiler emits can come between them.
+            const unsigned la0 = (unsigned)(__SIZE_TYPE__)((lds_void*)(smem)) + st * STAGE + fa16[0];
+            const unsigned la1 = la0 - fa16[0] + fa16[1];
+            const unsigned lb0 = la0 - fa16[0] + fb16[0], lb1 = la0 - fa16[0] + fb16[1];
+            f16x8 ahp[2], alp[2];
+            ds_read2_b128<0, -1>(ahp[0], alp[0], la0, la1);
+            static_for<2 * TN>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                ds_read2_b128<j * 2048, -1>(bh[j], bl[j], lb0, lb1);
+            });
+            static_for<2 * TM>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                const f16x8 ah = ahp[i & 1], al = alp[i & 1];
+                if constexpr (i == 0) {
+                    // the K-step's first row starts as soon as ITS B fragments are there: in front of column block j only the
+                    // 2 (2 TN - 1 - j) younger B reads and the two reads of A row 1 may still be outstanding
+                    ds_read2_b128<2048, -1>(ahp[1], alp[1], la0, la1);
+                    static_for<2 * TN>([&](auto jc) {
+                        constexpr int j = decltype(jc)::value;
+                        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (2 * TN - 1 - j) + 2) : "memory");
+                        __builtin_amdgcn_sched_barrier(0);
+                        f32x4 c = acc16[0][j];
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[j], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[j], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[j], c, 0, 0, 0);
+                        acc16[0][j] = c;
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                } else {
+                    if constexpr (i + 1 < 2 * TM) {
+                        ds_read2_b128<(i + 1) * 2048, 2>(ahp[(i + 1) & 1], alp[(i + 1) & 1], la0, la1);
+                    } else if constexpr (BARRIER_IN_COMPUTE) {
+                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    } else {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < 2 * TN; ++j) {
+                        f32x4 c = acc16[i][j];
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[j], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[j], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[j], c, 0, 0, 0);
+                        acc16[i][j] = c;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+            return;
+#elif P32_FRAG_PIPE
+            // A fragments of tile-row i + 1 are requested BEFORE the MFMAs of tile-row i issue (two register sets): the
+            // matrix pipe never waits for an LDS round trip inside a K-step except at its first tile-row.  The issue order
+            // is pinned with sched_group_barrier (2 LDS reads, then the row's MFMAs): left to itself hipcc reuses ONE register
+            // set, so every pair of tile-rows starts with `ds_read x 4; s_waitcnt` in front of its MFMAs.
+            f16x8 ahp[2], alp[2];
+            ahp[0] = *reinterpret_cast<const f16x8*>(sb + fa16[0]);
+            alp[0] = *reinterpret_cast<const f16x8*>(sb + fa16[1]);
+#pragma unroll
+            for (int i = 0; i < 2 * TM; ++i) {
+                if (i + 1 < 2 * TM) {
+                    ahp[(i + 1) & 1] = *reinterpret_cast<const f16x8*>(sb + fa16[0] + (i + 1) * 2048);
+                    alp[(i + 1) & 1] = *reinterpret_cast<const f16x8*>(sb + fa16[1] + (i + 1) * 2048);
+                }
+                const f16x8 ah = ahp[i & 1], al = alp[i & 1];
+#pragma unroll
+                for (int j = 0; j < 2 * TN; ++j) {
+                    f32x4 c = acc16[i][j];
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[j], c, 0, 0, 0);
+                    acc16[i][j] = c;
+                }
+                if (i + 1 < 2 * TM) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 6 * TN, 0);
+            }
+            return;
+#else
 #pragma unroll
             for (int i = 0; i < 2 * TM; ++i) {
                 const f16x8 ah = (P32_ABLATE & 1024) ? fake : *reinterpret_cast<const f16x8*>(sb + fa16[0] + i * 2048);
@@ -695,6 +808,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 2 : 1) void conv_p32_k
                 }
             }
             return;
+#endif
         }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -763,7 +877,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 2 : 1) void conv_p32_k
         if (NST == 3 && more) {
             wait_all_but_last_issue();
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        } else {
+        } else if (!BARRIER_IN_COMPUTE) {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
         st = NST == 2 ? (st ^ 1) : (st == 2 ? 0 : st + 1);

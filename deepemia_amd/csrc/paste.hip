@@ -24,6 +24,7 @@ struct PasteP {
     uint8_t* valid;
     uint32_t* packed;
     int* out_bbox;
+    const int* prev_bbox;
 };
 
 constexpr int PASTE_ROWS = 16;   // rows per block: 4 KiB of packed output at 2048 px (most blocks only write zeros)
@@ -37,9 +38,6 @@ __global__ __launch_bounds__(256) void paste_kernel(const PasteP p) {
     const int n = inst / p.D, i = inst - n * p.D;
     const int tid = threadIdx.x;
     const int wpr = (p.out_w + 31) >> 5;  // words per row
-    const int row0 = blockIdx.x * PASTE_ROWS;
-    uint32_t* dst = p.packed + ((long)inst * p.out_h + row0) * wpr;
-    const int nrows = min(PASTE_ROWS, p.out_h - row0);
     if (tid == 0) {
         int ok = i < p.det_count[n];
         float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -69,30 +67,22 @@ __global__ __launch_bounds__(256) void paste_kernel(const PasteP p) {
         }
     }
     __syncthreads();
+    const bool ok = sflag != 0;
     const float x0 = sbox[0], y0 = sbox[1], x1 = sbox[2], y1 = sbox[3];
     const int x0i = max((int)floorf(x0) - 1, 0), y0i = max((int)floorf(y0) - 1, 0);
     const int x1i = min((int)ceilf(x1) + 1, p.out_w), y1i = min((int)ceilf(y1) + 1, p.out_h);
-    const bool live = sflag && (row0 < y1i) && (row0 + nrows > y0i);
-    if (!live) {
-        const int nw = nrows * wpr;
-        if ((wpr & 3) == 0) {            // rows are 16-byte multiples (and the plane base is): 16-byte stores
-            uint4* d4 = reinterpret_cast<uint4*>(dst);
-            for (int w = tid; w < (nw >> 2); w += 256) d4[w] = make_uint4(0u, 0u, 0u, 0u);
-        } else {
-            for (int w = tid; w < nw; w += 256) dst[w] = 0u;
-        }
-        return;
+    // Rows and word columns of this instance's plane that have to be written.  Whole plane (prev_bbox == NULL): all of
+    // them, the plane's previous content is unknown.  INCREMENTAL (prev_bbox given): the plane is known to be zero outside
+    // the box the PREVIOUS paste into this buffer could set, so only the union of that box and the new one is written --
+    // a 2048 x 2048 plane is 512 KiB, a detection's box a few KiB: the whole-plane paste of a batch is mostly a memset.
+    int ry0 = 0, ry1 = p.out_h, wlo = 0, whi = wpr - 1;
+    if (p.prev_bbox) {
+        const int4 pb = reinterpret_cast<const int4*>(p.prev_bbox)[inst];
+        ry0 = 1 << 30; ry1 = -1; wlo = 1 << 30; whi = -1;
+        if (pb.x >= 0) { ry0 = pb.x; ry1 = pb.z + 1; wlo = pb.y >> 5; whi = pb.w >> 5; }
+        if (ok) { ry0 = min(ry0, y0i); ry1 = max(ry1, y1i); wlo = min(wlo, x0i >> 5); whi = max(whi, (x1i - 1) >> 5); }
+        if (ry1 <= ry0) return;                      // nothing was pasted here and nothing is now (block-uniform)
     }
-    {
-        const int cls = p.det_classes[inst];
-        const float* mp = p.mask_prob + (long)inst * 196 * 4 * p.ld + cls;
-        for (int e = tid; e < 784; e += 256) {
-            const int yy = e / 28, xx = e - yy * 28;
-            const int cell = (yy >> 1) * 14 + (xx >> 1), sub = (yy & 1) * 2 + (xx & 1);
-            sm[e] = mp[(long)(cell * 4 + sub) * p.ld];
-        }
-    }
-    __syncthreads();
     const float invw = x1 - x0, invh = y1 - y0;
     // The column part of the sampling (grid coordinate, west / east taps and weights) is the same for every row of the
     // mask: worked out once per workgroup for the box's columns -- same operations in the same order as per pixel, so the
@@ -101,60 +91,82 @@ __global__ __launch_bounds__(256) void paste_kernel(const PasteP p) {
     __shared__ short s_xi[PASTE_COLS];
     const int ncol = x1i - x0i;
     const bool col_table = ncol <= PASTE_COLS;
-    if (col_table) {
-        for (int cix = tid; cix < ncol; cix += 256) {
-            const int X = x0i + cix;
-            float gx = ((float)X + 0.5f - x0) / invw * 2.0f - 1.0f;
-            const float ix = ((gx + 1.0f) * 28.0f - 1.0f) / 2.0f;
-            const float xw = floorf(ix);
-            s_we[cix] = ix - xw;
-            // clamped before narrowing: for a box clipped to a sliver |ix| can exceed what a short holds, and a wrapped
-            // value could land on a valid tap; anything <= -2 or >= 29 has both taps outside the 28-wide mask either way
-            s_xi[cix] = (short)(int)fminf(fmaxf(xw, -2.0f), 29.0f);
+    if (ok) {                                        // (block-uniform)
+        const int cls = p.det_classes[inst];
+        const float* mp = p.mask_prob + (long)inst * 196 * 4 * p.ld + cls;
+        for (int e = tid; e < 784; e += 256) {
+            const int yy = e / 28, xx = e - yy * 28;
+            const int cell = (yy >> 1) * 14 + (xx >> 1), sub = (yy & 1) * 2 + (xx & 1);
+            sm[e] = mp[(long)(cell * 4 + sub) * p.ld];
+        }
+        if (col_table) {
+            for (int cix = tid; cix < ncol; cix += 256) {
+                const int X = x0i + cix;
+                float gx = ((float)X + 0.5f - x0) / invw * 2.0f - 1.0f;
+                const float ix = ((gx + 1.0f) * 28.0f - 1.0f) / 2.0f;
+                const float xw = floorf(ix);
+                s_we[cix] = ix - xw;
+                // clamped before narrowing: for a box clipped to a sliver |ix| can exceed what a short holds, and a wrapped
+                // value could land on a valid tap; anything <= -2 or >= 29 has both taps outside the 28-wide mask either way
+                s_xi[cix] = (short)(int)fminf(fmaxf(xw, -2.0f), 29.0f);
+            }
         }
         __syncthreads();
     }
-    for (int w = tid; w < nrows * wpr; w += 256) {
-        const int ry = w / wpr, wx = w - ry * wpr;
-        const int Y = row0 + ry;
-        uint32_t bits = 0u;
-        const int xa = wx << 5;
-        if (Y >= y0i && Y < y1i && xa < x1i && xa + 32 > x0i) {
-            float gy = ((float)Y + 0.5f - y0) / invh * 2.0f - 1.0f;
-            const float iy = ((gy + 1.0f) * 28.0f - 1.0f) / 2.0f;
-            const float yn = floorf(iy);
-            const float ns = iy - yn, ss = 1.0f - ns;  // weights: n (south part), s
-            const int yi0 = (int)yn, yi1 = yi0 + 1;
-            const bool vy0 = (unsigned)yi0 < 28u, vy1 = (unsigned)yi1 < 28u;
-            const float* r0 = sm + (vy0 ? yi0 : 0) * 28;
-            const float* r1 = sm + (vy1 ? yi1 : 0) * 28;
-            for (int bx = 0; bx < 32; ++bx) {
-                const int X = xa + bx;
-                if (X < x0i || X >= x1i) continue;
-                float we;
-                int xi0;
-                if (col_table) {
-                    we = s_we[X - x0i];
-                    xi0 = s_xi[X - x0i];
-                } else {
-                    float gx = ((float)X + 0.5f - x0) / invw * 2.0f - 1.0f;
-                    const float ix = ((gx + 1.0f) * 28.0f - 1.0f) / 2.0f;
-                    const float xw = floorf(ix);
-                    we = ix - xw;
-                    xi0 = (int)xw;
-                }
-                const float ww = 1.0f - we;
-                const int xi1 = xi0 + 1;
-                const bool vx0 = (unsigned)xi0 < 28u, vx1 = (unsigned)xi1 < 28u;
-                const float nw = (vy0 && vx0) ? r0[xi0] : 0.f;
-                const float ne = (vy0 && vx1) ? r0[xi1] : 0.f;
-                const float sw = (vy1 && vx0) ? r1[xi0] : 0.f;
-                const float se = (vy1 && vx1) ? r1[xi1] : 0.f;
-                const float v = nw * (ss * ww) + ne * (ss * we) + sw * (ns * ww) + se * (ns * we);
-                if (v >= 0.5f) bits |= 1u << bx;
-            }
+    const int c0 = ry0 / PASTE_ROWS, c1 = (ry1 - 1) / PASTE_ROWS;
+    const int nw = whi - wlo + 1;
+    for (int chunk = c0 + blockIdx.x; chunk <= c1; chunk += gridDim.x) {
+        const int row0 = chunk * PASTE_ROWS;
+        const int nrows = min(PASTE_ROWS, p.out_h - row0);
+        uint32_t* dst = p.packed + ((long)inst * p.out_h + row0) * wpr;
+        const bool live = ok && (row0 < y1i) && (row0 + nrows > y0i);
+        if (!live && nw == wpr && (wpr & 3) == 0) {   // whole rows of zeros, 16-byte stores (rows and the plane base are 16-byte multiples)
+            uint4* d4 = reinterpret_cast<uint4*>(dst);
+            for (int w = tid; w < ((nrows * wpr) >> 2); w += 256) d4[w] = make_uint4(0u, 0u, 0u, 0u);
+            continue;
         }
-        dst[w] = bits;
+        for (int t = tid; t < nrows * nw; t += 256) {
+            const int ry = t / nw, wx = wlo + (t - ry * nw);
+            const int Y = row0 + ry;
+            uint32_t bits = 0u;
+            const int xa = wx << 5;
+            if (live && Y >= y0i && Y < y1i && xa < x1i && xa + 32 > x0i) {
+                float gy = ((float)Y + 0.5f - y0) / invh * 2.0f - 1.0f;
+                const float iy = ((gy + 1.0f) * 28.0f - 1.0f) / 2.0f;
+                const float yn = floorf(iy);
+                const float ns = iy - yn, ss = 1.0f - ns;  // weights: n (south part), s
+                const int yi0 = (int)yn, yi1 = yi0 + 1;
+                const bool vy0 = (unsigned)yi0 < 28u, vy1 = (unsigned)yi1 < 28u;
+                const float* r0 = sm + (vy0 ? yi0 : 0) * 28;
+                const float* r1 = sm + (vy1 ? yi1 : 0) * 28;
+                for (int bx = 0; bx < 32; ++bx) {
+                    const int X = xa + bx;
+                    if (X < x0i || X >= x1i) continue;
+                    float we;
+                    int xi0;
+                    if (col_table) {
+                        we = s_we[X - x0i];
+                        xi0 = s_xi[X - x0i];
+                    } else {
+                        float gx = ((float)X + 0.5f - x0) / invw * 2.0f - 1.0f;
+                        const float ix = ((gx + 1.0f) * 28.0f - 1.0f) / 2.0f;
+                        const float xw = floorf(ix);
+                        we = ix - xw;
+                        xi0 = (int)xw;
+                    }
+                    const float ww = 1.0f - we;
+                    const int xi1 = xi0 + 1;
+                    const bool vx0 = (unsigned)xi0 < 28u, vx1 = (unsigned)xi1 < 28u;
+                    const float nw_ = (vy0 && vx0) ? r0[xi0] : 0.f;
+                    const float ne = (vy0 && vx1) ? r0[xi1] : 0.f;
+                    const float sw = (vy1 && vx0) ? r1[xi0] : 0.f;
+                    const float se = (vy1 && vx1) ? r1[xi1] : 0.f;
+                    const float v = nw_ * (ss * ww) + ne * (ss * we) + sw * (ns * ww) + se * (ns * we);
+                    if (v >= 0.5f) bits |= 1u << bx;
+                }
+            }
+            dst[ry * wpr + wx] = bits;
+        }
     }
 }
 
@@ -245,8 +257,12 @@ extern "C" int demia_paste_masks(const demia_paste_desc* d, void* stream) {
     p.det_count = d->det_count; p.N = d->N; p.D = d->D; p.img_h = d->img_h; p.img_w = d->img_w;
     p.out_h = d->out_h; p.out_w = d->out_w; p.out_boxes = d->out_boxes; p.valid = d->valid; p.packed = d->packed;
     p.out_bbox = d->out_bbox;
+    p.prev_bbox = d->prev_bbox;
+    DEMIA_REQUIRE(!d->prev_bbox || (d->out_bbox && d->prev_bbox != d->out_bbox), "incremental paste: out_bbox set and distinct from prev_bbox");
     if (d->N * d->D == 0) return DEMIA_OK;
-    hipLaunchKernelGGL(paste_kernel, dim3(cdiv(d->out_h, PASTE_ROWS), d->N * d->D), dim3(256), 0, (hipStream_t)stream, p);
+    // whole planes: one block per 16-row chunk; incremental: eight blocks share the chunks of an instance's two boxes
+    const int gx = d->prev_bbox ? 8 : cdiv(d->out_h, PASTE_ROWS);
+    hipLaunchKernelGGL(paste_kernel, dim3(gx, d->N * d->D), dim3(256), 0, (hipStream_t)stream, p);
     DEMIA_CHECK_LAUNCH("paste_kernel");
     return DEMIA_OK;
 }

@@ -244,6 +244,7 @@ class MaskRCNNEngine:
         self._arena: Dict[tuple, list] = {}               # intermediate buffers per input shape, reused by later forwards
         self._arena_key: Optional[tuple] = None
         self._arena_i = 0
+        self._paste_static = None                         # (planes, previous boxes) while a forward is being captured
         # arenas, meta pools and captured graphs are per input shape and GBs each (16 x 2048^2 R101: 8.6 GiB): at most this
         # many shapes stay resident, least recently used first out -- a folder of differently sized micrographs must not
         # accumulate one arena per size (the reference handles arbitrary sizes, inference.py:2299-2485)
@@ -776,12 +777,22 @@ class MaskRCNNEngine:
         b, D = det_boxes.shape[:2]
         out_boxes = torch.empty((b, D, 4), dtype=torch.float32, device=self.device)
         valid = torch.empty((b, D), dtype=torch.uint8, device=self.device)
-        packed = torch.empty((b, D, out_h, (out_w + 31) // 32), dtype=torch.int32, device=self.device)
         bbox = torch.empty((b, D, 4), dtype=torch.int32, device=self.device)
+        static = self._paste_static
+        if static is not None:
+            # a captured forward pastes into ITS OWN planes every replay: they were zeroed once, `prev` holds the boxes the
+            # last replay could set, so only the union of old and new boxes is written (incremental paste) -- the whole-plane
+            # paste of a 48-tile batch is a 2.5 GB memset with ~1 % payload
+            packed, prev = static
+            assert tuple(packed.shape) == (b, D, out_h, (out_w + 31) // 32)
+        else:
+            packed, prev = torch.empty((b, D, out_h, (out_w + 31) // 32), dtype=torch.int32, device=self.device), None
         d = _lib.PasteDesc(_lib.ptr(mask_prob), mask_prob.shape[-1], _lib.ptr(det_boxes), _lib.ptr(det_classes),
                            _lib.ptr(det_count), b, D, newh, neww, out_h, out_w, _lib.ptr(out_boxes), _lib.ptr(valid),
-                           _lib.ptr(packed), _lib.ptr(bbox))
+                           _lib.ptr(packed), _lib.ptr(bbox), _lib.ptr(prev))
         _lib.check(self.lib.demia_paste_masks(C.byref(d), self._stream()), "demia_paste_masks")
+        if prev is not None:
+            prev.copy_(bbox)
         return out_boxes, valid, packed, bbox
 
     # ------------------------------------------------------------------ whole forward
@@ -831,13 +842,20 @@ class MaskRCNNEngine:
             with torch.cuda.stream(side):
                 for _ in range(slots):
                     static_in = torch.empty_like(images)
+                    b, h, w = key
+                    planes = torch.zeros((b, DETS_PER_IMAGE, h, (w + 31) // 32), dtype=torch.int32, device=self.device)
+                    prev = torch.full((b, DETS_PER_IMAGE, 4), -1, dtype=torch.int32, device=self.device)
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, stream=side):
-                        out = self.forward(static_in)
-                    st["graphs"].append((g, static_in, out))
+                    self._paste_static = (planes, prev)
+                    try:
+                        with torch.cuda.graph(g, stream=side):
+                            out = self.forward(static_in)
+                    finally:
+                        self._paste_static = None
+                    st["graphs"].append((g, static_in, out, planes, prev))
             cur.wait_stream(side)
             self._graphs[key] = st
-        g, static_in, out = st["graphs"][st["next"]]
+        g, static_in, out = st["graphs"][st["next"]][:3]
         st["next"] = (st["next"] + 1) % len(st["graphs"])
         static_in.copy_(images, non_blocking=True)
         g.replay()

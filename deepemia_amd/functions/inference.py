@@ -290,6 +290,7 @@ class InferencePipeline:
         self.use_graphs = os.environ.get("DEEPEMIA_GRAPHS", "1") == "1"     # hipGraph replay of repeated forward shapes
         self.graph_after = 2                                                   # ... from their second occurrence on
         self._shape_seen: Dict[tuple, int] = {}
+        self.graph_slots, self.clone_graph_outputs = 1, True                  # (see forward_async)
         self.last_batch_stats = None
         self.forward_calls = 0
         self.d2h_waits = 0                       # device-to-host waits of the post-processing (finish_forward + process_tile_batch)
@@ -315,12 +316,15 @@ class InferencePipeline:
             # one-off shape runs eagerly.  Same kernels in the same order either way: identical results.
             graphed = self.use_graphs and self._shape_seen[key] >= self.graph_after
             if graphed:
-                # a replay writes into the graph's own output buffers, which the next replay of this shape overwrites:
+                # a replay writes into the graph's own output buffers, which a later replay of this shape overwrites:
                 # the pipeline keeps detections for a whole image (and the first images' for the small-class statistics),
-                # so it takes its own copy (one device-to-device copy of the packed masks, ~0.3 ms per 16 tiles)
-                r = pred.engine.forward_graphed(chunk, slots=1)
-                r = type(r)(r.boxes.clone(), r.scores.clone(), r.classes.clone(), r.valid.clone(), r.count.clone(), r.packed.clone(),
-                            r.height, r.width, None if r.bbox is None else r.bbox.clone())
+                # so it takes its own copy (one device-to-device copy of the packed masks, ~0.3 ms per 16 tiles).  A caller
+                # that consumes a batch's detections before the forward after next (the tile-batch loop of bench.py:
+                # `graph_slots = 2`, `clone_graph_outputs = False`) reads the graph's buffers in place.
+                r = pred.engine.forward_graphed(chunk, slots=self.graph_slots)
+                if self.clone_graph_outputs:
+                    r = type(r)(r.boxes.clone(), r.scores.clone(), r.classes.clone(), r.valid.clone(), r.count.clone(), r.packed.clone(),
+                                r.height, r.width, None if r.bbox is None else r.bbox.clone())
                 raws.append(r)
             else:
                 raws.append(pred.engine.forward(chunk))

@@ -281,6 +281,10 @@ typedef struct demia_paste_desc {
     uint32_t* packed;
     int32_t* out_bbox;        /* optional [N, D, 4] i32: y0, x0, y1, x1 (inclusive) of the pixels the paste can set,
                                  -1 for invalid instances -- the bbox hint of the packed-mask entry points */
+    const int32_t* prev_bbox; /* optional [N, D, 4] i32 (incremental paste): `packed` is known to be ZERO outside these boxes
+                                 (the out_bbox of the previous paste into the same buffer; all -1 after a memset) -- only the
+                                 union of each instance's old and new box is written instead of whole 512-KiB planes.
+                                 Must not alias out_bbox; needs out_bbox. */
 } demia_paste_desc;
 int demia_paste_masks(const demia_paste_desc* d, void* stream);
 /* packed bits -> Detectron2's (M, H, W) bool bytes (pred_masks drop-in layout) */

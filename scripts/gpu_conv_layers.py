@@ -9,7 +9,9 @@ if os.environ.get('AB_LIB'):
 prec = sys.argv[1]; B = int(sys.argv[2])
 sd = synth.random_d2_state_dict(101, 2, 0)
 eng = E.MaskRCNNEngine(sd, 101, 2, 0.3, 'cuda:0', prec)
-x = torch.from_numpy(np.stack([synth.em_tile(i, 2048) for i in range(B)])).cuda()
+x = torch.from_numpy(np.stack([synth.em_tile(i, 2048) for i in range(min(B, 4))])).cuda()
+if B > 4:
+    x = torch.cat([x, synth.em_tiles_device(range(50004, 50000 + B), 2048, 'cuda:0')])
 log = []
 orig = eng.conv_p32 if eng.p32 else eng.conv
 def conv(xx, L, *a, **kw):

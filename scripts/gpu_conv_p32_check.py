@@ -170,6 +170,20 @@ R101_B16 = [
 ]
 
 
+def r101_layers(B):
+    """The R101 layer shapes at B tiles per forward (R101_B16 scaled in its batch dimension)."""
+    out = []
+    for cnt, (n, h, w), cin, cout, k, s, rs in R101_B16:
+        if n == 16:
+            n = B
+        elif n == 1600:
+            n = 100 * B
+        elif n == 1:
+            w = w // 16 * B
+        out.append((cnt, (n, h, w), cin, cout, k, s, rs))
+    return out
+
+
 def timeit(fn, reps=5):
     fn()
     torch.cuda.synchronize()
@@ -182,9 +196,9 @@ def timeit(fn, reps=5):
     return e0.elapsed_time(e1) / reps
 
 
-def time_layers(sweep=True, old=True):
+def time_layers(sweep=True, old=True, B=16):
     tot_new = tot_old = tot_fl = tot_auto = 0.0
-    for cnt, (n, h, w), cin, cout, k, s, rs in R101_B16:
+    for cnt, (n, h, w), cin, cout, k, s, rs in r101_layers(B):
         L = Layer(cout, cin, k, k, seed=1)
         x = torch.randn(n, h, w, cin, device=dev)
         xp = p32.from_f32(x)
@@ -245,3 +259,7 @@ if __name__ == '__main__':
         check()
     if mode in ('time', 'all'):
         time_layers()
+    if mode == 'auto':          # auto tile only, at B tiles: gpu_conv_p32_check.py auto <B>
+        time_layers(sweep=False, old=False, B=int(sys.argv[2]) if len(sys.argv) > 2 else 48)
+    if mode == 'sweep':         # every tile at B tiles
+        time_layers(sweep=True, old=False, B=int(sys.argv[2]) if len(sys.argv) > 2 else 48)

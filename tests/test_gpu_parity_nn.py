@@ -322,6 +322,49 @@ def test_roi_align_on_oracle_inputs(env):
     assert not out[0, 3:].any()
 
 
+@pytest.mark.parametrize("groups", [1, 2])
+def test_roi_align_on_p32_pyramids_equals_the_f32_kernel_on_the_same_values(env, groups):
+    """The P32 variant (full 128-byte lines per memory instruction: each lane sums ONE plane, partner lanes exchange
+    their plane sums) against the f32 kernel on the dequantised pyramids: boxes of every level, slivers, boxes hanging
+    over the image edge, bins with 1 .. 12 samples per side (table path and per-sample fallback), rows beyond `count`;
+    one scale per tensor and one scale group per image with very different magnitudes."""
+    from deepemia_amd import p32
+
+    eng, eng2, dev = env["f32"], env["f16x2"], env["dev"]
+    g = torch.Generator().manual_seed(3)
+    n = 2
+    dims = {"p2": (64, 80), "p3": (32, 40), "p4": (16, 20), "p5": (8, 10)}
+    f32, pl = {}, {}
+    for k, (h, w) in dims.items():
+        x = torch.randn(n, h, w, 256, generator=g) * 3.0
+        x[1] *= 37.0                                           # image 1 lives on another scale
+        x[..., :5] *= 1e-3
+        q = p32.from_f32(x.to(dev), groups=groups)
+        pl[k] = q
+        f32[k] = p32.to_f32(q).contiguous()
+    boxes = torch.zeros(n, 40, 4)
+    for i in range(n):
+        for r in range(40):
+            size = [6, 20, 60, 140, 250, 320][r % 6] * float(torch.empty(1).uniform_(0.6, 1.4, generator=g))
+            asp = float(torch.empty(1).uniform_(0.3, 3.0, generator=g))
+            cx, cy = float(torch.empty(1).uniform_(-10, 330, generator=g)), float(torch.empty(1).uniform_(-10, 266, generator=g))
+            bw, bh = size * asp ** 0.5, size / asp ** 0.5
+            boxes[i, r] = torch.tensor([cx - bw / 2, cy - bh / 2, cx + bw / 2, cy + bh / 2])
+    boxes[0, 0] = torch.tensor([10.0, 10.0, 10.4, 200.0])        # a sliver
+    cnt = torch.tensor([40, 33], dtype=torch.int32, device=dev)
+    for P in (7, 14):
+        want = eng.roi_align(f32, boxes.to(dev), cnt, P)
+        got = eng2.roi_align(pl, boxes.to(dev), cnt, P)
+        gv = p32.to_f32(got)
+        assert got.groups == groups
+        for i in range(n):                                       # per image: its own magnitude
+            err = float((gv[i] - want[i]).abs().max() / want[i].abs().max())
+            assert err < 2e-6, (P, i, err)
+        assert not gv[1, 33:].any()
+        # the output's scale covers its values: |x s| < 2^15 in both planes' sum
+        assert float((gv.reshape(groups, -1).abs().amax(1) * got.meta[:, 1]).max()) < 32768.0
+
+
 def test_box_detections_on_oracle_inputs(env):
     eng, d, ref = env["eng"], env["ref"]["dbg"], env["ref"]
     dev = env["dev"]
@@ -446,6 +489,38 @@ def test_paste_of_boxes_clipped_to_a_sliver(env):
     got = eng.unpack(packed[0, :n].contiguous(), size, size).cpu()
     want = R.paste_masks(torch.ones((n, 28, 28)), ob[0, :n].cpu(), size, size)
     assert torch.equal(got, want), int((got != want).sum())
+
+
+def test_incremental_paste_into_reused_planes_equals_the_whole_plane_paste(env):
+    """A captured forward pastes into its own planes on every replay and writes only the union of each instance's previous
+    and new box (``demia_paste_desc.prev_bbox``).  Three pastes in a row into the same planes -- boxes that move, shrink,
+    grow, vanish (fewer detections) and reappear, a non-multiple-of-32 width -- must each leave exactly what the whole-plane
+    paste of the same inputs writes, zeros everywhere else."""
+    eng, dev = env["eng"], env["dev"]
+    g = torch.Generator().manual_seed(9)
+    b, D, H, W, size = 2, 100, 300, 333, 320
+    planes = torch.zeros((b, D, H, (W + 31) // 32), dtype=torch.int32, device=dev)
+    prev = torch.full((b, D, 4), -1, dtype=torch.int32, device=dev)
+    for rnd, counts in enumerate(([60, 100], [100, 7], [0, 55])):
+        boxes = torch.zeros((b, D, 4))
+        cxy = torch.rand((b, D, 2), generator=g) * size
+        wh = torch.rand((b, D, 2), generator=g) * (120 if rnd != 1 else 30) + 2
+        boxes[..., 0:2] = cxy - wh / 2
+        boxes[..., 2:4] = cxy + wh / 2
+        prob = torch.rand((b * D * 196 * 4, 1, 1, 4), generator=g)
+        classes = torch.randint(0, 2, (b, D), generator=g, dtype=torch.int32)
+        cnt = torch.tensor(counts, dtype=torch.int32, device=dev)
+        args = (prob.to(dev), boxes.to(dev), classes.to(dev), cnt, size, size, H, W)
+        ob0, v0, want, bb0 = eng.paste(*args)
+        eng._paste_static = (planes, prev)
+        try:
+            ob1, v1, got, bb1 = eng.paste(*args)
+        finally:
+            eng._paste_static = None
+        assert got.data_ptr() == planes.data_ptr()
+        assert torch.equal(got, want) and torch.equal(bb1, bb0) and torch.equal(v1, v0) and torch.equal(ob1, ob0), rnd
+        assert torch.equal(prev, bb1)
+        assert int(want.ne(0).sum()) > 0 or rnd == 2
 
 
 def test_per_shape_caches_are_bounded_over_many_image_sizes(env):
