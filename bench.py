@@ -28,7 +28,8 @@ import torch
 # dense MFMA peaks, MI355X_MICROARCH.md.  f16x2 (default) computes the f32 product with three fp16 MFMAs per tile (two
 # scaled fp16 planes per operand): its roof in f32-equivalent FLOP/s is the fp16 peak / 3; f32x3 = six bf16 MFMAs per
 # tile (three bf16 planes): bf16 peak / 6.
-PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f32x3": 2500.0 / 6, "bf16x2": 2500.0 / 3, "f16x2": 2500.0 / 3, "f16x2r": 2500.0 / 3}
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f32x3": 2500.0 / 6, "bf16x2": 2500.0 / 3, "f16x2": 2500.0 / 3, "f16x2r": 2500.0 / 3,
+               "f16": 2500.0}        # flagged single-plane mode: one fp16 MFMA per product, the native fp16 peak
 
 
 CLASS_THRESHOLDS = {0: (0.3, 0.7), 1: (0.3, 0.5)}   # class -> (confidence, IoU) as in config.yaml class_0 / class_1
@@ -93,7 +94,8 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=48, help="tiles per GPU per step (48: the res3-res5 layers fill the 256 CUs for "
                     "several rounds per launch; 26 GiB of activations)")
-    ap.add_argument("--precision", choices=["f32", "f32x3", "f16x2", "f16x2r", "bf16x2", "bf16"], default="f16x2")
+    ap.add_argument("--precision", choices=["f32", "f32x3", "f16x2", "f16", "f16x2r", "bf16x2", "bf16"], default="f16x2",
+                    help="f16x2 (default, parity); f16 = flagged NON-parity single-plane fp16 operands (the reference's autocast arithmetic)")
     ap.add_argument("--depth", type=int, default=101)
     ap.add_argument("--size", type=int, default=2048)
     ap.add_argument("--threshold", type=float, default=0.3)
@@ -149,7 +151,7 @@ def main() -> None:
     sd = synth.random_d2_state_dict(args.depth, 2, seed=0)
     eng = MaskRCNNEngine(sd, args.depth, 2, args.threshold, dev, args.precision, args.min_size_test, args.max_size_test)
     pipe = InferencePipeline([Predictor(eng)], "bench", {}, {})
-    args.graph = not args.eager and args.precision == "f16x2"
+    args.graph = not args.eager and args.precision in ("f16x2", "f16")
     pipe.use_graphs = bool(args.graph)
     pipe.graph_after = 1
     pipe.forward_batch = args.batch             # ONE forward per step over the whole batch (the CLI default chunks at 16)
@@ -341,7 +343,7 @@ def main() -> None:
         # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this workload; FETCH_SIZE doubled per the gfx950 note)
         # a STORED value, not measured in this run: it is only reported when the stored pass was taken on this kernel
         traffic, traffic_source = None, None
-        kernel_name = "conv_p32_kernel" if args.precision == "f16x2" else ("conv_igemm_split_kernel" if args.precision in ("f16x2r", "f32x3", "bf16x2") else "conv_igemm_kernel")
+        kernel_name = "conv_p32_kernel" if args.precision in ("f16x2", "f16") else ("conv_igemm_split_kernel" if args.precision in ("f16x2r", "f32x3", "bf16x2") else "conv_igemm_kernel")
         cands = sorted((ROOT / "profiles").glob(f"r*_conv_{args.precision}_b{args.batch}_pmc_traffic.json"))
         tf = cands[-1] if cands else ROOT / "profiles" / "none.json"          # the newest round's stored pass
         native = (args.min_size_test, args.max_size_test) != (800, 1333)
@@ -357,7 +359,8 @@ def main() -> None:
             "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": ("NON-PARITY native-resolution mode, not configs[1]: " if native else
+            "config": {"workload": ("NON-PARITY single-plane fp16 arithmetic (flagged mode, parity bar not met -- see parity): " if args.precision == "f16" else "") +
+                                   ("NON-PARITY native-resolution mode, not configs[1]: " if native else
                                     (f"configs[4] (a job of {args.total_tiles} distinct tiles per GPU, {args.steps} steps): " if args.total_tiles else "configs[1]: ")) +
                                    f"R{args.depth}-FPN, {args.size}x{args.size} synthetic EM tiles, "
                                    f"{args.batch} tiles per GPU per step; per tile: resize {args.min_size_test} -> backbone/FPN/RPN/ROI heads -> mask paste to "
@@ -373,6 +376,8 @@ def main() -> None:
                                                      "per product; peak = bf16 dense peak / 6)" if args.precision == "f32x3" else
                                                      "conv_p32_kernel (implicit-GEMM conv, both operands as 2 pre-scaled fp16 planes moved by LDS-DMA, "
                                                      "3 fp16 MFMAs per product; peak = fp16 dense peak / 3)" if args.precision == "f16x2" else
+                                                     "conv_p32_kernel in its flagged single-plane mode (fp16 operands, ONE fp16 MFMA per product, zero low "
+                                                     "planes still moved: bytes as f16x2; peak = fp16 dense peak)" if args.precision == "f16" else
                                                      "conv_igemm_split_kernel (implicit-GEMM conv, f32 activations split into 2 scaled fp16 planes in "
                                                      "the K loop, 3 fp16 MFMAs per product; peak = fp16 dense peak / 3)" if args.precision == "f16x2r" else
                                                      "conv_igemm_kernel (implicit-GEMM conv)") + ", all tile configs",

@@ -39,6 +39,10 @@
                           // 1024 = no fragment reads (scripts/build_variant.sh, scripts/gpu_ablate.sh)
 #endif
 
+#ifndef P32_DEV_TILES
+#define P32_DEV_TILES 0   // 1: also instantiate the experimental tiles / schedules reachable through tile hints only (ping-pong
+                          // kernel, three LDS stages, 32x32x16 MFMAs, alternative wave grids): dev builds for same-box A/B
+#endif
 #ifndef P32_FRAG_PIPE
 #define P32_FRAG_PIPE 0   // 1: A fragments double-buffered in registers, reads of tile-row i + 1 pinned in front of the MFMAs of row i
 #endif
@@ -67,6 +71,7 @@ struct ConvQ {
     int head_n, head_ld, head_act;
     int groups, group_rows, row0;   // scale groups (images): in_meta / res_meta / out_meta are [groups][2]; output row m of this
                                     // call belongs to group (m + row0) / group_rows
+    int single;             // demia_p32_single_plane(): operands are ONE fp16 plane (low planes are zero): one MFMA per product, zero low plane out
     int stagger_ticks;      // > 0: the second half of the first resident set of workgroups starts this many 10-ns ticks late
     int resident;           // workgroups resident at once (256 CUs x workgroups per CU) -- for the stagger
 };
@@ -341,7 +346,7 @@ __device__ __forceinline__ void p32_epilogue(const ConvQ& p, const GroupScales& 
                         vm = fmaxf(vm, fabsf(v[q]));
                         const float y = v[q] * s_out;
                         h[q] = (_Float16)y;
-                        l[q] = (_Float16)(y - (float)h[q]);
+                        l[q] = p.single ? (_Float16)0.f : (_Float16)(y - (float)h[q]);
                     }
                     vmax3[0] = fmaxf(vmax3[0], gd == 0 ? vm : 0.f);
                     vmax3[1] = fmaxf(vmax3[1], gd == 1 ? vm : 0.f);
@@ -425,6 +430,7 @@ __device__ __forceinline__ void p32_epilogue_planes(const ConvQ& p, const GroupS
     const bool sigmoid_on = p.act == DEMIA_ACT_SIGMOID;
     const float act_lo = p.act == DEMIA_ACT_RELU ? 0.f : -INFINITY;
     const bool res_on = p.res_mode != DEMIA_RES_NONE;
+    const bool single = p.single != 0;
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.out_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(res_on ? p.res : p.out), 0, res_on ? (int)p.res_bytes : 0, 0x00020000);
     const unsigned cbytes = (unsigned)p.Cout * 4u;                                     // bytes per P32 pixel
@@ -523,6 +529,7 @@ __device__ __forceinline__ void p32_epilogue_planes(const ConvQ& p, const GroupS
                 l[q] = (_Float16)fmaf(-(float)h[q], 1.0f, y.x);
                 l[q + 1] = (_Float16)fmaf(-(float)h[q + 1], 1.0f, y.y);
             }
+            if (single) l = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
             vm = m < p.M ? vm : 0.f;                                            // rows beyond M hold bias only: not part of the tensor
             vmax0 = fmaxf(vmax0, gd == 0 ? vm : 0.f);
             vmax1 = fmaxf(vmax1, gd == 1 ? vm : 0.f);
@@ -691,7 +698,37 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 2 : 1) void conv_p32_k
     // the last tile-row's MFMAs, whose operands are in registers by then, so the wait for the slowest wave and for this
     // wave's DMA pieces runs under matrix work instead of after it)
     constexpr bool BARRIER_IN_COMPUTE = (P32_FRAG_PIPE == 2) && M16 && NST == 2;
+    // single-plane operands (flagged --precision f16): the high-plane fragments only, ONE MFMA per product
+    auto compute1 = [&](int st) {
+        const char* sb = smem + st * STAGE;
+        if constexpr (M16) {
+            f16x8 bh[2 * TN];
+#pragma unroll
+            for (int j = 0; j < 2 * TN; ++j) bh[j] = *reinterpret_cast<const f16x8*>(sb + fb16[0] + j * 2048);
+#pragma unroll
+            for (int i = 0; i < 2 * TM; ++i) {
+                const f16x8 ah = *reinterpret_cast<const f16x8*>(sb + fa16[0] + i * 2048);
+#pragma unroll
+                for (int j = 0; j < 2 * TN; ++j) acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[j], acc16[i][j], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                f16x8 bh[TN];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bh[j] = *reinterpret_cast<const f16x8*>(sb + fb[kk] + j * 4096);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const f16x8 ah = *reinterpret_cast<const f16x8*>(sb + fa[kk] + i * 4096);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[j], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+        if (BARRIER_IN_COMPUTE) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
     auto compute = [&](int st) {
+        if (p.single) { compute1(st); return; }
         const char* sb = smem + st * STAGE;
         if constexpr (M16) {
             f16x8 bh[2 * TN], bl[2 * TN];
@@ -897,6 +934,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 2 : 1) void conv_p32_k
     }
 }
 
+#if P32_DEV_TILES   // experiments that did not pay, kept for same-box A/B through tile hints (scripts/build_variant.sh -DP32_DEV_TILES=1)
 // ---------------------------------------------------------------------------------------------------------------------
 // The same tile as a PING-PONG of two wave groups (waves 0-3 = the upper half of the rows, waves 4-7 = the lower half;
 // wave w and wave w + 4 share a SIMD).  The plain kernel above runs all eight waves in lockstep -- fragment reads, MFMAs
@@ -1114,6 +1152,8 @@ int launch_pp(ConvQ p, hipStream_t st) {
     return DEMIA_OK;
 }
 
+#endif  // P32_DEV_TILES
+
 template <int WM, int WN, int TM, int TN, bool M16 = true, int EPI = EPI_PLANES, int NST = 2>
 int launch_q(ConvQ p, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -1199,6 +1239,7 @@ extern "C" int demia_conv2d_p32(const demia_conv_p32_desc* d, void* stream) {
     p.in_bytes = (unsigned)in_bytes; p.w_bytes = (unsigned)w_bytes;
     p.ntn = p.nwg = 0;
     p.resident = 256;
+    p.single = g_demia_single_plane;
     p.groups = d->groups > 1 ? d->groups : 1;
     p.group_rows = p.groups > 1 ? d->group_rows : (1 << 29);
     p.row0 = p.groups > 1 ? d->row0 : 0;
@@ -1249,24 +1290,25 @@ extern "C" int demia_conv2d_p32(const demia_conv_p32_desc* d, void* stream) {
     switch (tile) {
         case 1: DEMIA_REQUIRE(n256, "tile needs CoutPad % 256 == 0"); return launch_q<2, 4, 4, 2>(p, st);   // 256 x 256
         case 2: DEMIA_REQUIRE(n256, "tile needs CoutPad % 256 == 0"); return launch_q<2, 4, 2, 2>(p, st);   // 128 x 256
-        case 3: DEMIA_REQUIRE(n256, "tile needs CoutPad % 256 == 0"); return launch_q<1, 8, 8, 1>(p, st);   // 256 x 256, waves along N
         case 4: DEMIA_REQUIRE(n256, "tile needs CoutPad % 256 == 0"); return launch_q<1, 8, 6, 1>(p, st);   // 192 x 256
-        case 5: DEMIA_REQUIRE(n256, "tile needs CoutPad % 256 == 0"); return launch_q<1, 8, 4, 1>(p, st);   // 128 x 256, waves along N
         case 6: DEMIA_REQUIRE(n128, "tile needs CoutPad % 128 == 0"); return launch_q<4, 2, 2, 2>(p, st);   // 256 x 128
         case 7: DEMIA_REQUIRE(n128, "tile needs CoutPad % 128 == 0"); return launch_q<4, 2, 1, 2>(p, st);   // 128 x 128
-        case 8: DEMIA_REQUIRE(n128, "tile needs CoutPad % 128 == 0"); return launch_q<2, 4, 2, 1>(p, st);   // 128 x 128, waves along N
         case 9: return launch_q<8, 1, 1, 2>(p, st);                                                           // 256 x 64
-        case 10: return launch_q<4, 2, 2, 1>(p, st);                                                          // 256 x 64, two waves along N
         case 11: return launch_q<4, 2, 1, 1>(p, st);                                                          // 128 x 64
         case 12: DEMIA_REQUIRE(n256, "tile needs CoutPad % 256 == 0"); return launch_q<1, 8, 5, 1>(p, st);   // 160 x 256
         case 13: DEMIA_REQUIRE(n256, "tile needs CoutPad % 256 == 0"); return launch_q<1, 8, 7, 1>(p, st);   // 224 x 256
-        case 14: DEMIA_REQUIRE(n256, "tile needs CoutPad % 256 == 0"); return launch_q<2, 4, 3, 2>(p, st);   // 192 x 256, 2 x 4 waves
         // (four waves of 128 x 128 / 64 x 128 -- `launch_q<2, 2, 4, 4>`, `<2, 2, 2, 4>`, the kernel supports WM * WN == 4 -- were
         //  measured 14-20 % SLOWER than the eight-wave tiles: with one wave per SIMD nothing hides the fragment-read latency
         //  unless the reads are interleaved with the MFMAs by hand; not instantiated)
         // three LDS stages (request two K-steps ahead): measured within +-3 % of the two-stage tiles on every R101 layer --
         // the K loop of the short-K layers is bound by LDS bandwidth (every wave of a 1 x 8 wave grid reads ALL A rows), not
         // by how far ahead the operands are requested; kept as tile hints for A/B only
+#if P32_DEV_TILES
+        case 3: DEMIA_REQUIRE(n256, "tile needs CoutPad % 256 == 0"); return launch_q<1, 8, 8, 1>(p, st);   // 256 x 256, waves along N
+        case 5: DEMIA_REQUIRE(n256, "tile needs CoutPad % 256 == 0"); return launch_q<1, 8, 4, 1>(p, st);   // 128 x 256, waves along N
+        case 8: DEMIA_REQUIRE(n128, "tile needs CoutPad % 128 == 0"); return launch_q<2, 4, 2, 1>(p, st);   // 128 x 128, waves along N
+        case 10: return launch_q<4, 2, 2, 1>(p, st);                                                          // 256 x 64, two waves along N
+        case 14: DEMIA_REQUIRE(n256, "tile needs CoutPad % 256 == 0"); return launch_q<2, 4, 3, 2>(p, st);   // 192 x 256, 2 x 4 waves
         case 42: DEMIA_REQUIRE(n256, "tile needs CoutPad % 256 == 0"); return launch_q<2, 4, 2, 2, true, EPI_PLANES, 3>(p, st);   // 128 x 256
         case 52: DEMIA_REQUIRE(n256, "tile needs CoutPad % 256 == 0"); return launch_q<1, 8, 5, 1, true, EPI_PLANES, 3>(p, st);   // 160 x 256
         case 49: return launch_q<8, 1, 1, 2, true, EPI_PLANES, 3>(p, st);                                                           // 256 x 64
@@ -1275,6 +1317,7 @@ extern "C" int demia_conv2d_p32(const demia_conv_p32_desc* d, void* stream) {
         case 21: DEMIA_REQUIRE(n256, "tile needs CoutPad % 256 == 0"); return launch_pp<4, 2>(p, st);        // 256 x 256, ping-pong
         case 22: DEMIA_REQUIRE(n256, "tile needs CoutPad % 256 == 0"); return launch_pp<2, 2>(p, st);        // 128 x 256, ping-pong
         case 26: DEMIA_REQUIRE(n128, "tile needs CoutPad % 128 == 0"); return launch_pp<4, 1>(p, st);        // 256 x 128, ping-pong
+#endif
         default: DEMIA_REQUIRE(false, "tile_hint");
     }
     return DEMIA_EINVAL;

@@ -228,7 +228,7 @@ __global__ void maxpool3x3s2_kernel(const T* __restrict__ in, T* __restrict__ ou
 // maxpool 3x3 s2 p1 from f32 into P32 planes (conv_p32.hip): 8 channels per thread, 16-byte stores per plane.
 // blockIdx.y = image; meta is [groups][2] with groups = 1 or one group per image.
 __global__ void maxpool3x3s2_p32_kernel(const float* __restrict__ in, char* __restrict__ out, float* __restrict__ meta, float s,
-                                        long per_image, int H, int W, int C, int Ho, int Wo, int groups) {
+                                        long per_image, int H, int W, int C, int Ho, int Wo, int groups, int single) {
     const int C8 = C / 8;
     const long n = blockIdx.y;
     float vmax = 0.f;
@@ -260,7 +260,7 @@ __global__ void maxpool3x3s2_p32_kernel(const float* __restrict__ in, char* __re
             vmax = fmaxf(vmax, fabsf(m[q]));
             const float y = m[q] * s;
             h[q] = (_Float16)y;
-            l[q] = (_Float16)(y - (float)h[q]);
+            l[q] = single ? (_Float16)0.f : (_Float16)(y - (float)h[q]);
         }
         char* o = out + 128 + ((n * Ho + ho) * (long)Wo + wo) * (C * 4L) + (c8 >> 2) * 128 + (c8 & 3) * 16;
         *reinterpret_cast<f16x8*>(o) = h;
@@ -369,7 +369,7 @@ extern "C" int demia_maxpool3x3s2_p32(const float* in, void* out, float* out_met
     if (per_image * N == 0) return DEMIA_OK;
     const int gx = (int)((grid_for(per_image * N, 256) + N - 1) / N);
     hipLaunchKernelGGL(maxpool3x3s2_p32_kernel, dim3(gx, N), dim3(256), 0, (hipStream_t)stream, in, (char*)out, out_meta, s,
-                       per_image, H, W, C, Ho, Wo, groups);
+                       per_image, H, W, C, Ho, Wo, groups, g_demia_single_plane);
     DEMIA_CHECK_LAUNCH("maxpool3x3s2_p32_kernel");
     return DEMIA_OK;
 }

@@ -21,6 +21,7 @@ struct RoiP {
     const float* meta[4];   // P32 only: {amax, s} of each level, [groups][2]
     float* out_meta;        // P32 only, [groups][2]
     int groups;             // P32 only: 1, or N (one scale group per image)
+    int single;             // P32 only: write a zero low plane (demia_p32_single_plane)
 };
 
 // Element access policies: bytes per pixel, a lane's byte offset inside a pixel, NV values per lane (f32 / bf16: four
@@ -93,6 +94,9 @@ template <> struct Acc<P32Tag> {
         *reinterpret_cast<f16x8*>(p) = o;
     }
 };
+__device__ __forceinline__ void zero_low_plane(char* p, int lane) {          // single-plane mode: the low-plane lanes store zeros
+    if (lane & 4) *reinterpret_cast<uint4*>(p) = make_uint4(0u, 0u, 0u, 0u);
+}
 
 // One workgroup per ROI: the box -> level / scale / bin geometry is worked out once, then the four waves walk the
 // P x P bins (wave w takes bins w, w + 4, ...).  Lanes span the channel axis, four channels per lane, so every
@@ -212,6 +216,7 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiP p) {
 #pragma unroll
             for (int c = 0; c < NV; ++c) o[c] = (acc[c] * fin) / cnt;
             A::store(out0 + (long)bin * pixb, s_out, o, lane);
+            if (P32 && p.single) zero_low_plane(out0 + (long)bin * pixb, lane);
         }
         return;
     }
@@ -255,6 +260,7 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiP p) {
 #pragma unroll
         for (int c = 0; c < NV; ++c) o[c] = (acc[c] * fin) / cnt;
         A::store(out0 + (long)bin * pixb, s_out, o, lane);
+        if (P32 && p.single) zero_low_plane(out0 + (long)bin * pixb, lane);
     }
 }
 
@@ -273,6 +279,7 @@ extern "C" int demia_roi_align(const demia_roialign_desc* d, void* stream) {
     for (int l = 0; l < 4; ++l) p.meta[l] = d->meta[l];
     p.out_meta = d->out_meta;
     p.groups = d->groups > 1 ? d->groups : 1;
+    p.single = g_demia_single_plane;
     DEMIA_REQUIRE(p.groups == 1 || p.groups == d->N, "scale groups: one per image");
     if (d->dtype == DEMIA_P32) {
         DEMIA_REQUIRE(d->C % 32 == 0 && d->out_meta && d->meta[0] && d->meta[1] && d->meta[2] && d->meta[3], "P32 needs C % 32 == 0 and the meta pointers");

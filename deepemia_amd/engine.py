@@ -228,12 +228,15 @@ class MaskRCNNEngine:
         self.min_size_test, self.max_size_test = int(min_size_test), int(max_size_test)
         if self.min_size_test < 32 or self.max_size_test < self.min_size_test:
             raise ValueError(f"min_size_test / max_size_test = {min_size_test} / {max_size_test}")
-        if precision not in ("f32", "f32x3", "f16x2", "f16x2r", "bf16x2", "bf16"):
+        if precision not in ("f32", "f32x3", "f16x2", "f16", "f16x2r", "bf16x2", "bf16"):
             raise ValueError("precision must be 'f16x2' (default: f32-sized error on the fp16 pipe, activations kept as two "
                              "pre-scaled fp16 planes in HBM, LDS-DMA fed kernel), 'f16x2r' (the same arithmetic with f32 "
                              "activations split in the K loop: round 1's kernel), 'f32' (exact-f32 MFMA), 'f32x3' (f32 on the "
-                             "bf16 pipe, 3-way split), 'bf16x2' (16-bit operands on the bf16 pipe) or 'bf16'")
-        self.p32 = precision == "f16x2"                   # activations travel as P32 planes (deepemia_amd/p32.py)
+                             "bf16 pipe, 3-way split), 'bf16x2' (16-bit operands on the bf16 pipe), 'bf16', or 'f16' (flagged NON-parity: "
+                             "the f16x2 path with single-plane fp16 operands, one MFMA per product -- the reference's autocast "
+                             "arithmetic, inference.py:1390-1395)")
+        self.p32 = precision in ("f16x2", "f16")          # activations travel as P32 planes (deepemia_amd/p32.py)
+        self.single_plane = precision == "f16"            # ... with a zero low plane (demia_p32_single_plane)
         self._amax_buf: Optional[torch.Tensor] = None     # f16x2r: per-forward pool of |activation| bounds
         self._amax_i = 0
         self._meta_pool: Optional[torch.Tensor] = None    # f16x2: {max |x|, s} per activation tensor and image, zeroed once per forward
@@ -290,6 +293,8 @@ class MaskRCNNEngine:
             if cin % 32:
                 raise ValueError(f"{prefix or 'layer'}: Cin = {cin} is not a multiple of 32")
             planes, sw = split2_f16_scaled(wp.to(dev))
+            if self.single_plane:
+                planes[1].zero_()                             # weights rounded to ONE fp16 plane
             base = torch.ones(cout, dtype=torch.float32) if scale is None else scale
             l1 = w.abs().flatten(1).sum(1)
             return ConvLayer(None, None if scale is None else scale.to(dev).contiguous(), None if b is None else b.to(dev).contiguous(),
@@ -523,7 +528,7 @@ class MaskRCNNEngine:
             # every operand once (planes are 4 bytes per element, like f32): the algorithmic traffic
             nbytes = (n * h * w * cin * 4 + L.cout_pad * L.kh * L.kw * cin * 4 + n * ho * wo * L.cout * 4 +
                       (0 if residual is None else residual.pixels * residual.channels * 4))
-            ev.append((e0, e1, 2.0 * n * ho * wo * L.cout * L.kh * L.kw * cin, "f16x2", nbytes))
+            ev.append((e0, e1, 2.0 * n * ho * wo * L.cout * L.kh * L.kw * cin, self.precision, nbytes))
         return out
 
     def conv(self, x, L: ConvLayer, act=ACT_NONE, residual=None, res_mode=RES_NONE,
@@ -802,6 +807,8 @@ class MaskRCNNEngine:
         assert images.dtype == torch.uint8 and images.dim() == 4 and images.shape[3] == 3
         images = images.contiguous()
         b, h, w, _ = images.shape
+        if self.p32:
+            self.lib.demia_p32_single_plane(1 if self.single_plane else 0)     # read by the launchers of this forward
         self._amax_buf = None            # f16x2r: a fresh (zeroed) pool of |activation| bounds per forward
         xin, newh, neww, ph, pw = self.preprocess(images)
         feats = self.backbone(xin, ph, pw)

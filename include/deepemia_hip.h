@@ -52,6 +52,11 @@ extern "C" {
 int demia_abi_version(void);
 const char* demia_last_error(void);
 const char* demia_build_arch(void);   /* "gfx950" */
+/* Flagged NON-parity switch behind `--precision f16` (process-wide; read by the launchers, so a captured graph keeps the
+ * setting it was captured with): on != 0 -> every P32 producer (conv epilogue, max pool, ROIAlign) writes a ZERO low plane and
+ * the conv kernel issues one MFMA per product instead of three -- fp16 operands, f32 accumulation: the arithmetic of the
+ * reference's autocast predictor (inference.py:1390-1395).  on < 0 only queries.  Returns the previous setting. */
+int demia_p32_single_plane(int on);
 
 /* a3: convolution as implicit GEMM on MFMA -------------------------------------------
  * Replaces every Conv2d(+FrozenBatchNorm)(+ReLU)(+residual add) / Linear /
