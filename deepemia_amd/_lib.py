@@ -103,6 +103,7 @@ EXPORTS = {
     "demia_p32_single_plane": (C.c_int, [C.c_int]),
     "demia_conv2d_nhwc": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "demia_conv2d_p32": (C.c_int, [C.POINTER(ConvP32Desc), C.c_void_p]),
+    "demia_conv2d_p32_single": (C.c_int, [C.POINTER(ConvP32Desc), C.c_void_p]),
     "demia_resize_h_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "demia_resize_v_norm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

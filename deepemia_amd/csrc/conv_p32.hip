@@ -39,6 +39,10 @@
                           // 1024 = no fragment reads (scripts/build_variant.sh, scripts/gpu_ablate.sh)
 #endif
 
+#ifndef P32_SINGLE
+#define P32_SINGLE 0      // 1: the flagged single-plane build of this file (Makefile: conv_p32_single.o, entry point
+                          // demia_conv2d_p32_single): fp16 operands in the high plane, ONE MFMA per product, zero low plane out
+#endif
 #ifndef P32_DEV_TILES
 #define P32_DEV_TILES 0   // 1: also instantiate the experimental tiles / schedules reachable through tile hints only (ping-pong
                           // kernel, three LDS stages, 32x32x16 MFMAs, alternative wave grids): dev builds for same-box A/B
@@ -71,7 +75,6 @@ struct ConvQ {
     int head_n, head_ld, head_act;
     int groups, group_rows, row0;   // scale groups (images): in_meta / res_meta / out_meta are [groups][2]; output row m of this
                                     // call belongs to group (m + row0) / group_rows
-    int single;             // demia_p32_single_plane(): operands are ONE fp16 plane (low planes are zero): one MFMA per product, zero low plane out
     int stagger_ticks;      // > 0: the second half of the first resident set of workgroups starts this many 10-ns ticks late
     int resident;           // workgroups resident at once (256 CUs x workgroups per CU) -- for the stagger
 };
@@ -346,7 +349,7 @@ __device__ __forceinline__ void p32_epilogue(const ConvQ& p, const GroupScales& 
                         vm = fmaxf(vm, fabsf(v[q]));
                         const float y = v[q] * s_out;
                         h[q] = (_Float16)y;
-                        l[q] = p.single ? (_Float16)0.f : (_Float16)(y - (float)h[q]);
+                        l[q] = P32_SINGLE ? (_Float16)0.f : (_Float16)(y - (float)h[q]);
                     }
                     vmax3[0] = fmaxf(vmax3[0], gd == 0 ? vm : 0.f);
                     vmax3[1] = fmaxf(vmax3[1], gd == 1 ? vm : 0.f);
@@ -430,7 +433,7 @@ __device__ __forceinline__ void p32_epilogue_planes(const ConvQ& p, const GroupS
     const bool sigmoid_on = p.act == DEMIA_ACT_SIGMOID;
     const float act_lo = p.act == DEMIA_ACT_RELU ? 0.f : -INFINITY;
     const bool res_on = p.res_mode != DEMIA_RES_NONE;
-    const bool single = p.single != 0;
+    constexpr bool single = P32_SINGLE != 0;
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.out_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(res_on ? p.res : p.out), 0, res_on ? (int)p.res_bytes : 0, 0x00020000);
     const unsigned cbytes = (unsigned)p.Cout * 4u;                                     // bytes per P32 pixel
@@ -728,7 +731,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 2 : 1) void conv_p32_k
         if (BARRIER_IN_COMPUTE) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
     auto compute = [&](int st) {
-        if (p.single) { compute1(st); return; }
+        if constexpr (P32_SINGLE != 0) { compute1(st); return; }
         const char* sb = smem + st * STAGE;
         if constexpr (M16) {
             f16x8 bh[2 * TN], bl[2 * TN];
@@ -1208,7 +1211,13 @@ inline int choose_tile(long M, int cout_pad, int ksteps, bool residual, bool nee
 
 }  // namespace
 
+#if P32_SINGLE
+extern "C" int demia_conv2d_p32_single(const demia_conv_p32_desc* d, void* stream) {
+#else
+extern "C" int demia_conv2d_p32_single(const demia_conv_p32_desc* d, void* stream);      // conv_p32_single.o: this file with -DP32_SINGLE=1
 extern "C" int demia_conv2d_p32(const demia_conv_p32_desc* d, void* stream) {
+    if (g_demia_single_plane) return demia_conv2d_p32_single(d, stream);              // flagged mode (demia_p32_single_plane)
+#endif
     DEMIA_REQUIRE(d && d->in && d->in_meta && d->w && (d->out || d->head_n > 0), "null pointer");
     DEMIA_REQUIRE(d->out_f32 || d->out_meta || d->head_n > 0, "P32 output needs out_meta");
     DEMIA_REQUIRE(d->Cin > 0 && d->Cin % 32 == 0, "Cin must be a multiple of 32");
@@ -1239,7 +1248,6 @@ extern "C" int demia_conv2d_p32(const demia_conv_p32_desc* d, void* stream) {
     p.in_bytes = (unsigned)in_bytes; p.w_bytes = (unsigned)w_bytes;
     p.ntn = p.nwg = 0;
     p.resident = 256;
-    p.single = g_demia_single_plane;
     p.groups = d->groups > 1 ? d->groups : 1;
     p.group_rows = p.groups > 1 ? d->group_rows : (1 << 29);
     p.row0 = p.groups > 1 ? d->row0 : 0;

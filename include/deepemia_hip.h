@@ -57,6 +57,9 @@ const char* demia_build_arch(void);   /* "gfx950" */
  * the conv kernel issues one MFMA per product instead of three -- fp16 operands, f32 accumulation: the arithmetic of the
  * reference's autocast predictor (inference.py:1390-1395).  on < 0 only queries.  Returns the previous setting. */
 int demia_p32_single_plane(int on);
+/* (the conv entry point of that mode: demia_conv2d_p32 forwards to it while the switch is on; same descriptor) */
+struct demia_conv_p32_desc;
+int demia_conv2d_p32_single(const struct demia_conv_p32_desc* d, void* stream);
 
 /* a3: convolution as implicit GEMM on MFMA -------------------------------------------
  * Replaces every Conv2d(+FrozenBatchNorm)(+ReLU)(+residual add) / Linear /

@@ -3,14 +3,14 @@
 #   1. --kernel-trace --stats of the default bench command            -> gpurun_out/r02/stats/
 #   2. separate --pmc passes of the predictor-only eager bench        -> gpurun_out/r02/pmc_{fetch,write,sq,sq2,tcc}/
 # Reduced on the build host by scripts/pmc_conv_summary.py into profiles/r02_*.  usage: gpu_collect_profiles.sh [tag]
-tag=${1:-r02}
+tag=${1:-r03}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$tag
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 set -o pipefail
 echo "[collect] kernel trace of the default bench command"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_under_rocprofv3.json 2> $O/stats.err || { tail -5 $O/stats.err; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-h2d-leg > $O/bench_under_rocprofv3.json 2> $O/stats.err || { tail -5 $O/stats.err; exit 1; }
 tail -c 600 $O/bench_under_rocprofv3.json; echo
 pmc() { # name, counters...
     n=$1; shift
@@ -22,7 +22,7 @@ pmc fetch FETCH_SIZE && pmc write WRITE_SIZE && pmc sq SQ_VALU_MFMA_BUSY_CYCLES 
     && pmc lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
 rc=$?
 echo "[collect] per-layer conv timings"
-( cd $R && timeout -k 10 200 python3 scripts/gpu_conv_layers.py f16x2 16 $O/conv_layers.csv > $O/conv_layers.err 2>&1 ) || tail -3 $O/conv_layers.err
+( cd $R && timeout -k 10 200 python3 scripts/gpu_conv_layers.py f16x2 48 $O/conv_layers.csv > $O/conv_layers.err 2>&1 ) || tail -3 $O/conv_layers.err
 # keep what travels back small: the per-dispatch counter tables and the stats tables only
 find $O -name "*.csv" -size +30M -delete
 find $O -type f ! -name "*.csv" ! -name "*.json" ! -name "*.err" -delete

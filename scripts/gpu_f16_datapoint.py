@@ -36,12 +36,13 @@ for prec in ('f16x2', 'f16'):
         m, rm = inst.pred_masks, r['pred_masks']
         if k:
             # each reference instance against the product instance at the same position (order agreement) ...
-            iou_pos = ((m[:k] & rm[:k]).sum((1, 2)).float() / (m[:k] | rm[:k]).sum((1, 2)).float().clamp(min=1)).numpy()
+            un_pos = (m[:k] | rm[:k]).sum((1, 2)).float()
+            iou_pos = torch.where(un_pos > 0, (m[:k] & rm[:k]).sum((1, 2)).float() / un_pos.clamp(min=1), torch.ones_like(un_pos)).numpy()   # empty vs empty = 1
             # ... and against its best match anywhere (are the same objects found at all)
             mf, rf = m.flatten(1).float(), rm.flatten(1).float()
             inter = rf @ mf.T
             union = rf.sum(1)[:, None] + mf.sum(1)[None, :] - inter
-            iou_best = (inter / union.clamp(min=1)).max(1).values.numpy()
+            iou_best = torch.where(union > 0, inter / union.clamp(min=1), torch.ones_like(union)).max(1).values.numpy()
         else:
             iou_pos = iou_best = np.zeros(0)
         rows.append(dict(instances=n, instances_ref=nr, same_count=same_n, classes_same_at_position=cls_same,
