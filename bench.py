@@ -104,6 +104,8 @@ def main() -> None:
     ap.add_argument("--max-size-test", type=int, default=1333)
     ap.add_argument("--total-tiles", type=int, default=0, help="BASELINE configs[4]: a job of this many DISTINCT tiles per GPU (e.g. 256), "
                     "walked in steps of --batch; overrides --steps")
+    ap.add_argument("--repeat-tiles", action="store_true", help="(profiling passes) fill a batch beyond the 16 numpy tiles with copies of "
+                    "them instead of device-generated tiles: no torch compute kernels before the forward (rocprofv3 --pmc crashed in one)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the timed CPU sample AND the parity leg")
     ap.add_argument("--parity-only", action="store_true", help="run the CPU path on tile 0 only: the parity check of the timed result "
                     "without the 3-tile cpu_baseline timing (the -m gpu configs[4] job)")
@@ -162,7 +164,9 @@ def main() -> None:
     n_np = min(args.batch, NUMPY_TILES)
     tiles = np.stack([synth.em_tile(rank * args.batch + i, args.size) for i in range(n_np)])
     x = torch.from_numpy(tiles).to(dev)
-    if args.batch > n_np:
+    if args.batch > n_np and args.repeat_tiles:
+        x = x.repeat((args.batch + n_np - 1) // n_np, 1, 1, 1)[:args.batch].contiguous()
+    elif args.batch > n_np:
         first = 50000 + rank * args.batch
         x = torch.cat([x, synth.em_tiles_device(range(first + n_np, first + args.batch), args.size, dev)])
     xs = [x]
@@ -393,6 +397,9 @@ def main() -> None:
                          "measured_over": ("two instrumented eager steps after the timed region (the timed steps replay hipGraphs)" if instrumented_s
                                            else "the timed region"),
                          "frac_of_native_peak": achieved * 3.0 / 2500.0 if args.precision in ("f16x2", "f16x2r", "bf16x2") else None,
+                         # the same achieved (algorithmic, f32-equivalent) rate against the NATIVE 16-bit dense peak, i.e. without
+                         # crediting the three MFMAs a product costs in this arithmetic
+                         "algorithmic_frac_of_native_16bit_peak": achieved / 2500.0,
                          "frac_of_per_launch_roof": attainable_ms / conv_ms if conv_ms > 0 else None,
                          "per_launch_roof": f"sum over launches of max(FLOP / {peak:.0f} TFLOP/s, algorithmic bytes / 8 TB/s) / measured time; "
                                             f"{hbm_bound} of {launches} launches are HBM-bound by that measure",

@@ -9,20 +9,22 @@ O=$R/gpurun_out/$tag
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 set -o pipefail
+if [ -z "$PMC_ONLY" ]; then
 echo "[collect] kernel trace of the default bench command"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-h2d-leg > $O/bench_under_rocprofv3.json 2> $O/stats.err || { tail -5 $O/stats.err; exit 1; }
 tail -c 600 $O/bench_under_rocprofv3.json; echo
+fi
 pmc() { # name, counters...
     n=$1; shift
     echo "[collect] pmc pass $n: $*"
-    timeout -k 10 240 rocprofv3 --pmc "$@" --output-format csv -d $O/pmc_$n -o p -- python3 $R/bench.py --forward-only --eager --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_$n.json 2> $O/pmc_$n.err || { tail -5 $O/pmc_$n.err; return 1; }
+    timeout -k 10 240 rocprofv3 --pmc "$@" --output-format csv -d $O/pmc_$n -o p -- python3 $R/bench.py --forward-only --eager --steps 2 --warmup 1 --no-cpu-baseline --repeat-tiles > $O/pmc_$n.json 2> $O/pmc_$n.err || { tail -5 $O/pmc_$n.err; return 1; }
 }
 pmc fetch FETCH_SIZE && pmc write WRITE_SIZE && pmc sq SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE \
     && pmc tcc TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE \
     && pmc lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
 rc=$?
 echo "[collect] per-layer conv timings"
-( cd $R && timeout -k 10 200 python3 scripts/gpu_conv_layers.py f16x2 48 $O/conv_layers.csv > $O/conv_layers.err 2>&1 ) || tail -3 $O/conv_layers.err
+[ -z "$PMC_ONLY" ] && ( cd $R && timeout -k 10 200 python3 scripts/gpu_conv_layers.py f16x2 48 $O/conv_layers.csv > $O/conv_layers.err 2>&1 ) || tail -3 $O/conv_layers.err
 # keep what travels back small: the per-dispatch counter tables and the stats tables only
 find $O -name "*.csv" -size +30M -delete
 find $O -type f ! -name "*.csv" ! -name "*.json" ! -name "*.err" -delete
