@@ -24,79 +24,63 @@ struct RoiP {
     int single;             // P32 only: write a zero low plane (demia_p32_single_plane)
 };
 
-// Element access policies: bytes per pixel, a lane's byte offset inside a pixel, NV values per lane (f32 / bf16: four
-// channels; P32: see Acc<P32Tag>), load / store of those values; the P32 buffer starts with a 128-byte zero header.
+// Element access policies: bytes per pixel, a lane's byte offset inside a pixel (four channels per lane), load / store
+// of those four channels.  P32 (conv_p32.hip): 4 high halves at p, 4 low halves 64 bytes on, value = (h + l) * inv_s; a
+// lane's channels 4 l .. 4 l + 3 sit in group l / 8 at (l % 8) * 8 bytes; the buffer starts with a 128-byte zero header.
 template <typename T> struct Acc;
 template <> struct Acc<float> {
-    static constexpr int HEADER = 0, NV = 4;
-    static __device__ __forceinline__ void finish(float*, int) {}
+    static constexpr int HEADER = 0;
     static __device__ __forceinline__ long pix_bytes(int C) { return (long)C * 4; }
     static __device__ __forceinline__ int lane_off(int lane) { return lane * 16; }
     static __device__ __forceinline__ void load(const char* p, float, float v[4]) {
         const float4 t = *reinterpret_cast<const float4*>(p);
         v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
     }
-    static __device__ __forceinline__ void store(char* p, float, const float v[4], int) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+    static __device__ __forceinline__ void store(char* p, float, const float v[4]) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
 };
 template <> struct Acc<bf16_t> {
-    static constexpr int HEADER = 0, NV = 4;
-    static __device__ __forceinline__ void finish(float*, int) {}
+    static constexpr int HEADER = 0;
     static __device__ __forceinline__ long pix_bytes(int C) { return (long)C * 2; }
     static __device__ __forceinline__ int lane_off(int lane) { return lane * 8; }
     static __device__ __forceinline__ void load(const char* p, float, float v[4]) {
         const bf16x4 t = *reinterpret_cast<const bf16x4*>(p);
         v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
     }
-    static __device__ __forceinline__ void store(char* p, float, const float v[4], int) {
+    static __device__ __forceinline__ void store(char* p, float, const float v[4]) {
         bf16x4 o;
         o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
         *reinterpret_cast<bf16x4*>(p) = o;
     }
 };
 struct P32Tag {};
-// P32, FULL 128-byte lines per memory instruction: a pixel of 256 channels is eight lines [h0 h1 h2 h3 | l0 l1 l2 l3] of
-// 16-byte chunks (8 channels each).  Lane 8 g + j moves bytes 16 j .. 16 j + 15 of line g: lanes j < 4 hold the HIGH halves
-// of channels 32 g + 8 j .. + 7, lanes j >= 4 the LOW halves of channels 32 g + 8 (j - 4) .. + 7, and each accumulates the
-// weighted sum of ITS plane (the sum over taps is linear in h and l, and the plane scale is an exact power of two applied
-// once at the end).  `finish` adds the partner lane's plane sum (lane ^ 4, two DPP row shifts), after which both lanes of a
-// pair hold the value of their 8 channels; lanes j < 4 then store its high half, lanes j >= 4 its low half -- again 16 bytes
-// per lane, whole lines per wave instruction.  (Round 2 moved 8 + 8 bytes per lane, half a line per eight lanes and
-// instruction: twice the L1 requests for the same bytes, on a kernel that is bound by them.)
 template <> struct Acc<P32Tag> {
-    static constexpr int HEADER = 128, NV = 8;
+    static constexpr int HEADER = 128;
     static __device__ __forceinline__ long pix_bytes(int C) { return (long)C * 4; }
-    static __device__ __forceinline__ int lane_off(int lane) { return lane * 16; }
-    static __device__ __forceinline__ void load(const char* p, float, float v[8]) {
-        const f16x8 t = *reinterpret_cast<const f16x8*>(p);
+    static __device__ __forceinline__ int lane_off(int lane) { return (lane >> 3) * 128 + (lane & 7) * 8; }
+    static __device__ __forceinline__ void load(const char* p, float inv_s, float v[4]) {
+        const f16x4 h = *reinterpret_cast<const f16x4*>(p);
+        const f16x4 l = *reinterpret_cast<const f16x4*>(p + 64);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) v[c] = (float)t[c];
+        for (int c = 0; c < 4; ++c) v[c] = ((float)h[c] + (float)l[c]) * inv_s;
     }
-    static __device__ __forceinline__ void finish(float acc[8], int lane) {
-        const bool low = (lane & 4) != 0;
+    static __device__ __forceinline__ void store(char* p, float s, const float v[4]) {
+        f16x4 h, l;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const int own = __float_as_int(acc[c]);
-            const int up = __builtin_amdgcn_update_dpp(own, own, 0x104, 0xf, 0xf, false);     // row_shl:4 -> the value of lane + 4
-            const int dn = __builtin_amdgcn_update_dpp(own, own, 0x114, 0xf, 0xf, false);     // row_shr:4 -> the value of lane - 4
-            const float partner = __int_as_float(low ? dn : up);
-            acc[c] = low ? partner + acc[c] : acc[c] + partner;                              // h-sum + l-sum in both lanes
-        }
-    }
-    static __device__ __forceinline__ void store(char* p, float s, const float v[8], int lane) {
-        f16x8 o;
-        const bool low = (lane & 4) != 0;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
+        for (int c = 0; c < 4; ++c) {
             const float y = v[c] * s;
-            const _Float16 h = (_Float16)y;
-            o[c] = low ? (_Float16)(y - (float)h) : h;
+            h[c] = (_Float16)y;
+            l[c] = (_Float16)(y - (float)h[c]);
         }
-        *reinterpret_cast<f16x8*>(p) = o;
+        *reinterpret_cast<f16x4*>(p) = h;
+        *reinterpret_cast<f16x4*>(p + 64) = l;
     }
 };
-__device__ __forceinline__ void zero_low_plane(char* p, int lane) {          // single-plane mode: the low-plane lanes store zeros
-    if (lane & 4) *reinterpret_cast<uint4*>(p) = make_uint4(0u, 0u, 0u, 0u);
-}
+// (Round 3 tried FULL 128-byte lines per memory instruction here, as in the conv epilogue: a lane takes 16 bytes = 8 channels
+//  of ONE plane, sums that plane, and partner lanes exchange their plane sums by DPP at the end of a bin.  Same box, the boxes
+//  of a real 48-tile forward: 7x7 2.43 ms against 2.19 ms for this version, 14x14 0.92 against 0.82 -- 11-13 % SLOWER.  The
+//  kernel moves ~37 GB through L1 / L2 per 7x7 call (every bin re-reads the pixels it shares with its neighbours): it is
+//  bound by bytes through the texture path, not by the number of requests, and the rewrite added a DPP exchange and a
+//  second plane split per lane.  Reverted.)
 
 // One workgroup per ROI: the box -> level / scale / bin geometry is worked out once, then the four waves walk the
 // P x P bins (wave w takes bins w, w + 4, ...).  Lanes span the channel axis, four channels per lane, so every
@@ -109,7 +93,6 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiP p) {
     const long roi = blockIdx.x;  // n*R + r
     const int PP = p.P * p.P;
     const int n = (int)(roi / p.R), r = (int)(roi % p.R);
-    constexpr int NV = A::NV;                       // values a lane accumulates (P32: 8 halves of ONE plane, see Acc<P32Tag>)
     const bool lane_on = lane * 4 < p.C;
     const long pixb = A::pix_bytes(p.C);
     float s_out = 1.f;
@@ -125,8 +108,8 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiP p) {
     }
     char* out0 = reinterpret_cast<char*>(p.out) + A::HEADER + roi * PP * pixb + A::lane_off(lane);
     if (r >= p.count[n]) {
-        const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (lane_on) for (int bin = wave; bin < PP; bin += 4) A::store(out0 + (long)bin * pixb, s_out, z, lane);
+        const float z[4] = {0.f, 0.f, 0.f, 0.f};
+        if (lane_on) for (int bin = wave; bin < PP; bin += 4) A::store(out0 + (long)bin * pixb, s_out, z);
         return;
     }
     const float4 b = reinterpret_cast<const float4*>(p.boxes)[roi];
@@ -139,7 +122,6 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiP p) {
     const float scale = 1.0f / (float)(4 << lv);
     const char* feat = reinterpret_cast<const char*>(p.feat[lv]) + A::HEADER + (long)n * H * W * pixb + A::lane_off(lane);
     const float inv_s = P32 ? 1.0f / p.meta[lv][(p.groups > 1 ? 2 * n : 0) + 1] : 1.f;
-    const float fin = P32 ? inv_s : 1.f;            // P32 planes are summed raw; the level's (power-of-two) scale comes off once
 
     const float rsw = b.x * scale - 0.5f, rsh = b.y * scale - 0.5f;
     const float rew = b.z * scale - 0.5f, reh = b.w * scale - 0.5f;
@@ -192,31 +174,26 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiP p) {
         for (int bin = wave; bin < PP; bin += 4) {
             const int ph = bin / p.P, pw = bin - ph * p.P;
             const int y0 = s_lo[0][ph], ny = s_n[0][ph], x0 = s_lo[1][pw], nx = s_n[1][pw];
-            float acc[NV];
-#pragma unroll
-            for (int c = 0; c < NV; ++c) acc[c] = 0.f;
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
             for (int yy = 0; yy < ny; ++yy) {
                 const float wy = s_w[0][ph * 8 + yy];
                 const char* rowp = feat + ((long)(y0 + yy) * W + x0) * pixb;
-                float t[NV];
-#pragma unroll
-                for (int c = 0; c < NV; ++c) t[c] = 0.f;
+                float t[4] = {0.f, 0.f, 0.f, 0.f};
                 for (int xx = 0; xx < nx; ++xx) {
                     const float wx = s_w[1][pw * 8 + xx];
-                    float v[NV];
+                    float v[4];
                     A::load(rowp + (long)xx * pixb, inv_s, v);
 #pragma unroll
-                    for (int c = 0; c < NV; ++c) t[c] += wx * v[c];
+                    for (int c = 0; c < 4; ++c) t[c] += wx * v[c];
                 }
 #pragma unroll
-                for (int c = 0; c < NV; ++c) acc[c] += wy * t[c];
+                for (int c = 0; c < 4; ++c) acc[c] += wy * t[c];
             }
-            A::finish(acc, lane);
-            float o[NV];
+            float o[4];
 #pragma unroll
-            for (int c = 0; c < NV; ++c) o[c] = (acc[c] * fin) / cnt;
-            A::store(out0 + (long)bin * pixb, s_out, o, lane);
-            if (P32 && p.single) zero_low_plane(out0 + (long)bin * pixb, lane);
+            for (int c = 0; c < 4; ++c) o[c] = acc[c] / cnt;
+            A::store(out0 + (long)bin * pixb, s_out, o);
+            if (P32 && p.single) *reinterpret_cast<uint2*>(out0 + (long)bin * pixb + 64) = make_uint2(0u, 0u);
         }
         return;
     }
@@ -224,9 +201,7 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiP p) {
 
     for (int bin = wave; bin < PP; bin += 4) {
         const int ph = bin / p.P, pw = bin - ph * p.P;
-        float acc[NV];
-#pragma unroll
-        for (int c = 0; c < NV; ++c) acc[c] = 0.f;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
         for (int iy = 0; iy < gh; ++iy) {
             float y = rsh + (float)ph * bin_h + ((float)iy + 0.5f) * bin_h / (float)gh;
             const bool oy = (y < -1.0f) || (y > (float)H);
@@ -243,24 +218,23 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiP p) {
                 if (xl >= W - 1) { xl = xh = W - 1; x = (float)xl; } else { xh = xl + 1; }
                 const float lx = x - (float)xl, hx = 1.0f - lx;
                 const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
-                float v1[NV], v2[NV], v3[NV], v4[NV];
+                float v1[4], v2[4], v3[4], v4[4];
                 A::load(feat + ((long)yl * W + xl) * pixb, inv_s, v1);
                 A::load(feat + ((long)yl * W + xh) * pixb, inv_s, v2);
                 A::load(feat + ((long)yh * W + xl) * pixb, inv_s, v3);
                 A::load(feat + ((long)yh * W + xh) * pixb, inv_s, v4);
 #pragma unroll
-                for (int c = 0; c < NV; ++c) {
+                for (int c = 0; c < 4; ++c) {
                     const float v = w1 * v1[c] + w2 * v2[c] + w3 * v3[c] + w4 * v4[c];
                     acc[c] += v;
                 }
             }
         }
-        A::finish(acc, lane);
-        float o[NV];
+        float o[4];
 #pragma unroll
-        for (int c = 0; c < NV; ++c) o[c] = (acc[c] * fin) / cnt;
-        A::store(out0 + (long)bin * pixb, s_out, o, lane);
-        if (P32 && p.single) zero_low_plane(out0 + (long)bin * pixb, lane);
+        for (int c = 0; c < 4; ++c) o[c] = acc[c] / cnt;
+        A::store(out0 + (long)bin * pixb, s_out, o);
+        if (P32 && p.single) *reinterpret_cast<uint2*>(out0 + (long)bin * pixb + 64) = make_uint2(0u, 0u);
     }
 }
 

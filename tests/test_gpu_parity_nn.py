@@ -324,10 +324,10 @@ def test_roi_align_on_oracle_inputs(env):
 
 @pytest.mark.parametrize("groups", [1, 2])
 def test_roi_align_on_p32_pyramids_equals_the_f32_kernel_on_the_same_values(env, groups):
-    """The P32 variant (full 128-byte lines per memory instruction: each lane sums ONE plane, partner lanes exchange
-    their plane sums) against the f32 kernel on the dequantised pyramids: boxes of every level, slivers, boxes hanging
-    over the image edge, bins with 1 .. 12 samples per side (table path and per-sample fallback), rows beyond `count`;
-    one scale per tensor and one scale group per image with very different magnitudes."""
+    """The P32 variant of the ROIAlign kernel (planes in, planes out, per-image scale groups) against the f32 kernel on the
+    dequantised pyramids: boxes of every level, slivers, boxes hanging over the image edge, bins with 1 .. 12 samples per
+    side (table path and per-sample fallback), rows beyond `count`; one scale per tensor and one scale group per image with
+    very different magnitudes."""
     from deepemia_amd import p32
 
     eng, eng2, dev = env["f32"], env["f16x2"], env["dev"]
