@@ -893,6 +893,25 @@ class InferencePipeline:
         return packed, out, alg
 
     def _single_class_pass_batched(self, dets: Sequence[_Detections], target_class: int, small_classes, conf, iou_threshold):
+        """a6 + a9 + a11 + a12 for ONE class over MANY tiles: everything enqueued at once (:meth:`_single_class_pass_launch`),
+        ONE device-to-host wait for its tables, the greedy loop as one native call (:meth:`_single_class_pass_finish`).
+        Returns (masks, per tile (indices into them, scores), tables with ``area`` / ``bbox``).  The host-loop version
+        below is its checker."""
+        h = self._single_class_pass_launch(dets, target_class, small_classes, conf)
+        T = len(dets)
+        if h is None:
+            return None, [([], []) for _ in range(T)], None
+        host = torch.cat([h["ncols"], h["area"], h["bbox"].reshape(-1), h["I"].reshape(-1)]).cpu().numpy()
+        self.d2h_waits += 1
+        n, ld = h["n"], h["ld"]
+        tabs = dict(ncols=host[:T], area=host[T:T + n].astype(np.int64), bbox=host[T + n:T + 5 * n].reshape(n, 4).astype(np.int64),
+                    I=np.ascontiguousarray(host[T + 5 * n:T + 5 * n + n * ld]).reshape(n, ld))
+        big, res, tables = self._single_class_pass_finish(h, tabs, target_class in small_classes, iou_threshold)
+        if not any(len(k) for k, _ in res):
+            return None, res, None
+        return big, res, tables
+
+    def _single_class_pass_batched_hostloops(self, dets: Sequence[_Detections], target_class: int, small_classes, conf, iou_threshold):
         """a6 + a9 + a11 + a12 for ONE class over MANY tiles with one launch per kernel: the masks of all tiles are
         concatenated and carry a segment id (tile index); overlap removal and column counts are segment-aware, every
         other kernel is per mask anyway.  Returns per tile (index tensor into the returned big tensor, scores)."""
@@ -1236,7 +1255,7 @@ class InferencePipeline:
             if ensemble:
                 big, res, calg = self._ensemble_class_pass_batched(dets_per_model, cls, small_classes, conf, iou_thr)
             else:
-                big, res, calg = self._single_class_pass_batched(dets, cls, small_classes, conf, iou_thr)
+                big, res, calg = self._single_class_pass_batched_hostloops(dets, cls, small_classes, conf, iou_thr)
             if big is not None and any(len(k) for k, _ in res):
                 passes.append((cls, big, res, calg))
         out = [(None, [], [], []) for _ in range(T)]

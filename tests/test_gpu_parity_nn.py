@@ -50,7 +50,7 @@ def test_library_is_the_hip_one(env):
     assert lib.demia_abi_version() == 4
 
 
-@pytest.mark.parametrize("hw", [(1024, 1024), (2048, 2048), (600, 600), (700, 1100), (1000, 2000)])
+@pytest.mark.parametrize("hw", [(1024, 1024), (2048, 2048), (600, 600), (700, 1100), (1000, 2000), (601, 1001), (333, 517)])
 def test_resize_normalise_bit_exact_vs_pillow(env, hw):
     eng, R = env["eng"], env["R"]
     h, w = hw
