@@ -323,7 +323,13 @@ class InferencePipeline:
                 # `graph_slots = 2`, `clone_graph_outputs = False`) reads the graph's buffers in place.
                 r = pred.engine.forward_graphed(chunk, slots=self.graph_slots)
                 if self.clone_graph_outputs:
-                    r = type(r)(r.boxes.clone(), r.scores.clone(), r.classes.clone(), r.valid.clone(), r.count.clone(), r.packed.clone(),
+                    if r.bbox is not None:       # the planes are zero outside the paste boxes: read the boxes, write each plane once
+                        flat = r.packed.view((-1,) + tuple(r.packed.shape[2:]))
+                        idx = torch.arange(flat.shape[0], dtype=torch.int64, device=self.dev)
+                        packed = self.ops.gather_regions(flat, idx, r.bbox.view(-1, 4)).view_as(r.packed)
+                    else:
+                        packed = r.packed.clone()
+                    r = type(r)(r.boxes.clone(), r.scores.clone(), r.classes.clone(), r.valid.clone(), r.count.clone(), packed,
                                 r.height, r.width, None if r.bbox is None else r.bbox.clone())
                 raws.append(r)
             else:
