@@ -13,6 +13,8 @@ units sharded over ranks (weak scaling).  See DESIGN.md "Measurement".
 from __future__ import annotations
 
 import argparse
+import csv
+import io
 import json
 import os
 import sys
@@ -111,6 +113,7 @@ def main() -> None:
                     "without the 3-tile cpu_baseline timing (the -m gpu configs[4] job)")
     ap.add_argument("--no-h2d-leg", action="store_true", help="skip the second timed leg that uploads every step's tiles from pinned "
                     "host memory on a copy stream (reported as `h2d`, never as `value`)")
+    ap.add_argument("--no-csv-text", action="store_true", help="leave the CSV text (a19) of every step out of the timed region")
     ap.add_argument("--no-overlap", action="store_true", help="do not overlap batch i+1's network with batch i's post-processing")
     ap.add_argument("--forward-only", action="store_true", help="time predictor(tile) only, without the per-tile post-processing")
     ap.add_argument("--post-priority", choices=["default", "high", "low"], default="default", help="(experiment) priority of the post-processing stream")
@@ -147,7 +150,7 @@ def main() -> None:
 
     from deepemia_amd import parallel, synth
     from deepemia_amd.engine import MaskRCNNEngine
-    from deepemia_amd.functions.inference import InferencePipeline
+    from deepemia_amd.functions.inference import InferencePipeline, measurement_rows
     from deepemia_amd.predictor import Predictor
 
     sd = synth.random_d2_state_dict(args.depth, 2, seed=0)
@@ -186,6 +189,7 @@ def main() -> None:
             dist.barrier()
             torch.cuda.synchronize()
 
+    MIN_AREA = max(5, args.size * args.size * 0.000005 * 0.05)      # inference.py:1175-1190
     net_stream = torch.cuda.Stream(device=dev)      # network of batch i+1 ...
     prio = {"default": 0, "high": -1, "low": 1}[args.post_priority]
     post_stream = torch.cuda.Stream(device=dev, priority=prio)     # ... runs under the post-processing of batch i
@@ -210,7 +214,18 @@ def main() -> None:
         if i >= 0 and i % len(xs) == 0 or not args.total_tiles:
             last["res"] = res          # the step whose tile 0 is synthetic tile 0 (the parity check's reference)
         n_inst = sum(0 if r[0] is None else int(r[0].shape[0]) for r in res)
-        n_rows = sum(len(c) for r in res for c in r[3])
+        if args.no_csv_text:
+            n_rows = sum(len(c) for r in res for c in r[3])
+        else:
+            # a19: the CSV text of the step's tiles (20 columns, csv.writer, area gate of inference.py:1175-1190) into memory
+            buf = io.StringIO()
+            wr = csv.writer(buf)
+            n_rows = 0
+            for t_, r in enumerate(res):
+                for row in measurement_rows(f"tile{rank * args.batch + t_}.tif", r[2], r[3], ("class_0", "class_1"), MIN_AREA):
+                    wr.writerow(row)
+                    n_rows += 1
+            last["csv_bytes"] = buf.tell()
         if dist is not None:
             # the one exchange of the path: instance tables of every rank's tiles (unit id = global tile index);
             # areas / boxes come from the reductions the path has already done, the crop is one launch
@@ -369,7 +384,8 @@ def main() -> None:
                                    f"R{args.depth}-FPN, {args.size}x{args.size} synthetic EM tiles, "
                                    f"{args.batch} tiles per GPU per step; per tile: resize {args.min_size_test} -> backbone/FPN/RPN/ROI heads -> mask paste to "
                                    f"bit-packed {args.size}^2 masks" + ("" if args.forward_only else " -> class loop (fill holes, closing, overlap "
-                                   "removal, component test, opening, greedy IoU dedup) -> cross-class dedup -> contour trace + 12 measurements") +
+                                   "removal, component test, opening, greedy IoU dedup) -> cross-class dedup -> contour trace + 12 measurements" +
+                                   ("" if args.no_csv_text else " -> measurement CSV text (csv.writer, in memory)")) +
                                    f"; random-init Detectron2-layout weights, K=2, threshold {args.threshold}"
                                    + ("; all-gather of instance tables over ranks" if world > 1 and not args.forward_only else ""),
                        "tiles_per_step_per_gpu": args.batch, "instances_last_step_rank0": det_total,

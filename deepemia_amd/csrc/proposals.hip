@@ -326,13 +326,13 @@ __global__ __launch_bounds__(1024) void box_detections_kernel(const DetP p) {
     float4* kbox = reinterpret_cast<float4*>(keys + DET_MAXC);                // [128] kept boxes
     int* kcls = reinterpret_cast<int*>(kbox + DET_MAXK);                      // [128]
     float* kscore = reinterpret_cast<float*>(kcls + DET_MAXK);                // [128]
-    __shared__ int nkept, ncand;
+    __shared__ int nkept, ncand, maxc_bits;
     const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int K = p.K;
     const int R = p.prop_count[n] < p.R ? p.prop_count[n] : p.R;
     const float iw = (float)p.img_w, ih = (float)p.img_h;
     for (int i = tid; i < DET_MAXC; i += blockDim.x) keys[i] = 0ull;
-    if (tid == 0) { nkept = 0; ncand = 0; }
+    if (tid == 0) { nkept = 0; ncand = 0; maxc_bits = 0; }
     __syncthreads();
     for (int r = tid; r < R; r += blockDim.x) {
         const float* lg = p.logits + ((long)n * p.R + r) * p.ld;
@@ -348,6 +348,11 @@ __global__ __launch_bounds__(1024) void box_detections_kernel(const DetP p) {
         for (int c = 0; c < K; ++c) {
             const float sc = expf(lg[c] - mx) / sum;
             if (sc > p.score_thresh) {
+                // `boxes.max()` over the candidates (torchvision's coordinate trick, below); clipped boxes are >= 0, so the
+                // float order is the order of the bit patterns
+                bool f2 = true;
+                const float4 cb = det_class_box(lg + K + 1 + 4 * c, pb, iw, ih, f2);
+                atomicMax(&maxc_bits, __float_as_int(fmaxf(fmaxf(cb.x, cb.y), fmaxf(cb.z, cb.w))));
                 const int slot = atomicAdd(&ncand, 1);
                 if (slot < DET_MAXC)
                     keys[slot] = ((unsigned long long)f2key(sc) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)(r * K + c));
@@ -357,6 +362,17 @@ __global__ __launch_bounds__(1024) void box_detections_kernel(const DetP p) {
     __syncthreads();
     bitonic_desc(keys, DET_MAXC);
     // ---- greedy per-class NMS with early stop at topk, wave 0 ---------------------------------------
+    // torchvision 0.11 batched_nms (what detectron2.layers.batched_nms calls): with at most 4000 box COORDINATES
+    // (boxes.numel() <= 4000, i.e. <= 1000 candidates) it shifts every box by class * (boxes.max() + 1) in fp32 and runs ONE
+    // nms over the shifted boxes; above that, one nms per class on the boxes as they are.  Classes never meet either way;
+    // the shift only changes the fp32 rounding of the IoU of a same-class pair -- reproduced here so that a pair sitting on
+    // the threshold decides as the reference's CPU path decides.
+    const bool trick = 4 * ncand <= 4000;
+    const float shift1 = trick ? __int_as_float(maxc_bits) + 1.0f : 0.f;
+    auto shifted = [&](const float4 b, int cls) {
+        const float o = (float)cls * shift1;
+        return make_float4(b.x + o, b.y + o, b.z + o, b.w + o);
+    };
     if (tid < 64) {
         int kept_n = 0;
         for (int base = 0; base < DET_MAXC && kept_n < p.topk; base += 64) {
@@ -368,16 +384,17 @@ __global__ __launch_bounds__(1024) void box_detections_kernel(const DetP p) {
             bool fin_unused = true;
             const float4 b = det_class_box(p.logits + ((long)n * p.R + prow) * p.ld + K + 1 + 4 * cls,
                                            reinterpret_cast<const float4*>(p.props)[(long)n * p.R + prow], iw, ih, fin_unused);
+            const float4 bs = shifted(b, cls);
             bool sup = !live;
             for (int j = 0; j < kept_n && !sup; ++j)
-                if (kcls[j] == cls && iou_gt(kbox[j], b, p.nms_thresh)) sup = true;
+                if (kcls[j] == cls && iou_gt(shifted(kbox[j], cls), bs, p.nms_thresh)) sup = true;
             // intra-chunk rows
             unsigned long long row = 0ull;
             for (int j = 0; j < 64; ++j) {
-                const float4 bj = make_float4(__shfl(b.x, j, 64), __shfl(b.y, j, 64), __shfl(b.z, j, 64), __shfl(b.w, j, 64));
+                const float4 bj = make_float4(__shfl(bs.x, j, 64), __shfl(bs.y, j, 64), __shfl(bs.z, j, 64), __shfl(bs.w, j, 64));
                 const int cj = __shfl(cls, j, 64);
                 const bool lj = __shfl((int)live, j, 64) != 0;
-                if (j > lane && live && lj && cj == cls && iou_gt(b, bj, p.nms_thresh)) row |= 1ull << j;
+                if (j > lane && live && lj && cj == cls && iou_gt(bs, bj, p.nms_thresh)) row |= 1ull << j;
             }
             unsigned long long rem = __ballot(sup);
             for (int bbit = 0; bbit < 64; ++bbit) {

@@ -1591,6 +1591,24 @@ def write_predictions_png(path: str, image_bgr: np.ndarray, crops, classes: Sequ
     return text_boxes
 
 
+def measurement_rows(image_name: str, classes: Sequence[int], recs, thing_classes, min_area: float, contrast=None, psum: str = "0") -> List[list]:
+    """The 20-column rows of ``measurements_results.csv`` for one image / tile (``inference.py:1148-1230``): one row per
+    external contour that passes the area gate, ``<image>_<instance>`` ids counted from 1, ``None`` -> empty field."""
+    rows = []
+    for instance_id, (cls, contours) in enumerate(zip(classes, recs), 1):
+        cls = int(cls)
+        d10, d50, d90 = contrast[instance_id - 1] if contrast is not None else (None, None, None)
+        cname = thing_classes[cls] if cls < len(thing_classes) else f"class_{cls}"
+        for c in contours:
+            if c["area"] < min_area:
+                continue
+            v = c["values"]
+            rows.append([f"{image_name}_{instance_id}", cls, cname, float(v[0]), float(v[1]), float(v[2]), float(v[3]),
+                         float(v[4]), float(v[5]), float(v[6]), float(v[7]), float(v[8]), float(v[9]), float(v[10]),
+                         float(v[11]), d10, d50, d90, psum, image_name])
+    return rows
+
+
 def write_measurements(ops: MaskOps, dedup_results: Dict[str, dict], test_img_path: str, output_dir: str, metadata,
                        dataset_name: str, draw_scalebar: bool = False, visualize: bool = False) -> str:
     """Measurement phase (``inference.py:983-1291``): one CSV row per external contour that passes
@@ -1638,19 +1656,7 @@ def write_measurements(ops: MaskOps, dedup_results: Dict[str, dict], test_img_pa
                 if im is not None:
                     write_predictions_png(os.path.join(output_dir, f"{test_img}_predictions.png"), im, mask_crops(ops, packed),
                                           classes, recs, metadata.thing_classes)
-            rows = []
-            for instance_id, (cls, contours) in enumerate(zip(classes, recs), 1):
-                cls = int(cls)
-                d10, d50, d90 = contrast[instance_id - 1]
-                cname = metadata.thing_classes[cls] if cls < len(metadata.thing_classes) else f"class_{cls}"
-                for c in contours:
-                    if c["area"] < min_area:
-                        continue
-                    v = c["values"]
-                    rows.append([f"{test_img}_{instance_id}", cls, cname, float(v[0]), float(v[1]), float(v[2]), float(v[3]),
-                                 float(v[4]), float(v[5]), float(v[6]), float(v[7]), float(v[8]), float(v[9]), float(v[10]),
-                                 float(v[11]), d10, d50, d90, psum, test_img])
-            for r in rows:
+            for r in measurement_rows(test_img, classes, recs, metadata.thing_classes, min_area, contrast, psum):
                 w.writerow(r)
             csvfile.flush()
     system_logger.info(f"Measurements complete. Results: {csv_filename}")

@@ -241,9 +241,20 @@ def nms(boxes: torch.Tensor, scores: torch.Tensor, thresh: float) -> torch.Tenso
     return order[torch.tensor(keep, dtype=torch.int64)]
 
 
-def batched_nms(boxes, scores, idxs, thresh) -> torch.Tensor:
-    """torchvision ``_batched_nms_vanilla``: independent NMS per key, result sorted by
+def batched_nms(boxes, scores, idxs, thresh, size_rule: bool = False) -> torch.Tensor:
+    """torchvision 0.11 ``batched_nms`` (detectron2.layers.nms.batched_nms forwards to it).  ``size_rule`` applies
+    torchvision's own choice: more than 4000 box COORDINATES (``boxes.numel() > 4000``) -> ``_batched_nms_vanilla``
+    (independent NMS per key), else ``_batched_nms_coordinate_trick``: every box is shifted by ``idx * (boxes.max() + 1)``
+    (fp32) and ONE nms runs over the shifted boxes -- the same result unless an IoU sits within fp32 rounding of the
+    threshold after the shift.  The ROI heads call it with <= 1000 x K candidates (both branches occur); the RPN call has
+    4768 boxes at MIN_SIZE_TEST = 800 and is always the vanilla branch (``size_rule=False`` there).  Result sorted by
     descending score (stable)."""
+    if size_rule and boxes.numel() <= 4000:
+        if boxes.numel() == 0:
+            return torch.zeros((0,), dtype=torch.int64)
+        max_coordinate = boxes.max()
+        offsets = idxs.to(boxes) * (max_coordinate + torch.tensor(1).to(boxes))
+        return nms(boxes + offsets[:, None], scores, thresh)
     keep_mask = torch.zeros_like(scores, dtype=torch.bool)
     for k in torch.unique(idxs):
         cur = torch.where(idxs == k)[0]
@@ -406,7 +417,7 @@ def fast_rcnn_inference(boxes, scores, image_size, score_thresh, nms_thresh=0.5,
     filter_inds = filter_mask.nonzero()
     b = b[filter_mask]
     s = scores[filter_mask]
-    keep = batched_nms(b, s, filter_inds[:, 1], nms_thresh)
+    keep = batched_nms(b, s, filter_inds[:, 1], nms_thresh, size_rule=True)
     if topk >= 0:
         keep = keep[:topk]
     return b[keep], s[keep], filter_inds[keep, 1], filter_inds[keep, 0]

@@ -383,6 +383,64 @@ def test_box_detections_on_oracle_inputs(env):
     assert float((db[0, :n].cpu() - d["det_boxes"]).abs().max()) < 2e-3
 
 
+@pytest.mark.parametrize("branch", ["coordinate_trick", "vanilla"])
+def test_box_detections_follow_torchvisions_batched_nms_branch_on_threshold_pairs(env, branch):
+    """torchvision 0.11 ``batched_nms`` shifts the boxes by class * (boxes.max() + 1) when there are at most 4000 box
+    coordinates and runs one NMS per class otherwise -- the same result unless a pair's IoU sits on the threshold, where
+    the fp32 rounding of the shifted coordinates decides.  Hundreds of same-class pairs built to have IoU = 0.5 exactly
+    (in exact arithmetic) at fractional positions, in both regimes: the kernel keeps exactly what the oracle's
+    ``fast_rcnn_inference`` keeps, and the two regimes really differ on such pairs."""
+    import torch.nn.functional as F2
+
+    eng, R, dev = env["eng"], env["R"], env["dev"]
+    k, newh, neww = 2, 800, 1100
+    g = torch.Generator().manual_seed(5)
+    pairs = 140 if branch == "coordinate_trick" else 520           # 280 / 2080 candidates: <= / > 1000
+    x = torch.rand(pairs, generator=g) * 900 + 20
+    y = torch.rand(pairs, generator=g) * 600 + 20
+    w = (torch.randint(4, 40, (pairs,), generator=g) * 3).float()  # dx = w / 3 -> IoU = (w - dx) / (w + dx) = 0.5
+    h = torch.rand(pairs, generator=g) * 60 + 10
+    a = torch.stack([x, y, x + w, y + h], dim=1)
+    b = a.clone()
+    b[:, 0] += w / 3
+    b[:, 2] += w / 3
+    props = torch.stack([a, b], dim=1).reshape(-1, 4)
+    r = props.shape[0]
+    cls_logits = torch.zeros((r, k + 1))
+    rank = torch.randperm(r, generator=g).float()                   # distinct scores, gaps far above an ulp of the softmax
+    if branch == "coordinate_trick":
+        cls_logits[:, 1] = 2.0 + rank * 2e-3                         # one candidate per proposal, all class 1: shifted boxes
+    else:
+        cls_logits[:, 0] = 0.2 + rank * 2e-5                         # both classes above 0.3: 2 r candidates -> vanilla
+        cls_logits[:, 1] = 0.2 + rank * 2e-5 + 1e-5
+    deltas = torch.zeros((r, 4 * k))
+    probs = F2.softmax(cls_logits, dim=-1)
+    pred = R.apply_deltas(deltas, props, (10.0, 10.0, 5.0, 5.0))
+    rb, rs, rc, _ = R.fast_rcnn_inference(pred, probs, (newh, neww), 0.3, topk=100000)
+    n_cand = int((probs[:, :k] > 0.3).sum())
+    assert (4 * n_cand <= 4000) == (branch == "coordinate_trick")
+    ld = 12
+    logits = torch.zeros((1, r, ld))
+    logits[0, :, :k + 1] = cls_logits
+    logits[0, :, k + 1:k + 1 + 4 * k] = deltas
+    db, ds, dc, dn = eng.detections(logits.to(dev), props[None].contiguous().to(dev), torch.tensor([r], dtype=torch.int32, device=dev),
+                                    newh, neww)
+    n = int(dn[0])
+    m = min(n, 100)
+    assert n == min(rb.shape[0], 100)
+    np.testing.assert_array_equal(dc[0, :m].cpu().numpy(), rc[:m].numpy())
+    assert float((ds[0, :m].cpu() - rs[:m]).abs().max()) < 1e-6 and float((db[0, :m].cpu() - rb[:m]).abs().max()) == 0.0
+    # the other regime decides differently on some of these pairs (what the test is sensitive to)
+    scores_f = probs[:, :k]
+    mask = scores_f > 0.3
+    bb = pred.view(-1, k, 4)[mask]
+    idx = mask.nonzero()[:, 1]
+    other = R.batched_nms(bb, scores_f[mask], idx, 0.5, size_rule=False) if branch == "coordinate_trick" else None
+    if other is not None:
+        mine = R.batched_nms(bb, scores_f[mask], idx, 0.5, size_rule=True)
+        assert len(other) != len(mine) or not torch.equal(other, mine)
+
+
 def test_box_detections_many_classes_and_a_non_finite_row(env):
     """demia_box_detections with K = 12 classes and 1000 proposals (12 000 (proposal, class) pairs; only those above
     the score threshold take a sort slot) and one proposal whose deltas overflow: same survivors, order and classes as
