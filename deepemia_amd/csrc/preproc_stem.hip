@@ -278,6 +278,126 @@ __global__ void maxpool3x3s2_kernel(const T* __restrict__ in, T* __restrict__ ou
     }
 }
 
+// ---- stem on the matrix pipe (the f16x2 path, round 3) ------------------------------------------------------------
+// The same 7x7 s2 p3 convolution + FrozenBN + ReLU in the arithmetic of conv_p32.hip: both operands as two fp16 planes of
+// x * s (s an exact power of two; 22 significand bits), a product = a_h b_l + a_l b_h + a_h b_h in the f32 accumulator of
+// v_mfma_f32_16x16x32_f16 -- 3 MFMAs of 16 cycles for 16 pixels x 16 channels x 32 k instead of ~1000 packed VALU FMAs.
+//   GEMM view: M = output pixels, N = 64 channels, K = 7 kernel rows x (8 pixels x 4 channels): one K-step of 32 is ONE
+//   kernel row, k = kw * 4 + c; kw = 7 and c = 3 carry zero weights.  The zero-bordered 4-channel f32 input is split into
+//   planes once per workgroup while it is staged in LDS ([row][40 px][4 ch] fp16 per plane); an A fragment (row = output
+//   pixel wo, k-chunk q = pixels 2 wo + 2 q, + 1) is then 16 contiguous bytes, and the 16 pixels of an output row read 16
+//   contiguous chunks: no gather, no conflicts.  Weights arrive as planes [2][7][64][32] fp16 of w * 2^e(co) (host:
+//   engine.py::stem_weight_planes), rows padded to 80 bytes in LDS (conflict-free 16-byte fragment reads).
+// block = 4 waves = 16 x 16 output pixels: wave w takes output rows 4 w .. 4 w + 3 (one 16-pixel M block each) x 64 channels.
+constexpr int SM_PW = 40;                        // staged input pixels per row (2 * 16 + 7 = 39, padded)
+constexpr int SM_ROWS = 37;                      // 2 * 16 + 5
+__global__ __launch_bounds__(256, 2) void stem_mfma_kernel(const float* __restrict__ in, const _Float16* __restrict__ wpl,
+                                                           const float* __restrict__ scale, const float* __restrict__ bias,
+                                                           float* __restrict__ out, int PH, int PW, float s_in) {
+    __shared__ __attribute__((aligned(16))) char sx[2 * SM_ROWS * SM_PW * 8];          // input planes h | l (23.7 KB: 4+ blocks per CU)
+    const int Ho = PH / 2, Wo = PW / 2, DW = PW + 8, DH = PH + 6;
+    const int n = blockIdx.z, ho0 = blockIdx.y * 16, wo0 = blockIdx.x * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wo = lane & 15, q = lane >> 4;
+    // B fragments straight from global memory (56 KB of weight planes, the same for every workgroup: L2 / L1 resident),
+    // one kernel row ahead in a second register set: lane (n = lane & 15, q) reads k = 8 q .. + 7 of row kh * 64 + nb * 16 + n
+    const f16x8* wh = reinterpret_cast<const f16x8*>(wpl) + (lane & 15) * 4 + q;        // + (kh * 64 + nb * 16) * 4
+    constexpr int WPLANE = 7 * 64 * 4;                                                 // f16x8 units per plane
+    f16x8 bh[2][4], bl[2][4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        bh[0][nb] = wh[(nb * 16) * 4];
+        bl[0][nb] = wh[WPLANE + (nb * 16) * 4];
+    }
+    // input patch: rows 2 ho0 .. + 36, pixels 2 wo0 .. + 39 of the bordered image, split into planes
+    const float4* in4 = reinterpret_cast<const float4*>(in) + (long)n * DH * DW;
+    for (int i = tid; i < SM_ROWS * SM_PW; i += 256) {
+        const int r = i / SM_PW, c = i - r * SM_PW;
+        const int gy = 2 * ho0 + r, gx = 2 * wo0 + c;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gy < DH && gx < DW) v = in4[(long)gy * DW + gx];
+        const float y[4] = {v.x * s_in, v.y * s_in, v.z * s_in, v.w * s_in};
+        f16x4 h, l;
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+            h[c4] = (_Float16)y[c4];
+            l[c4] = (_Float16)(y[c4] - (float)h[c4]);
+        }
+        *reinterpret_cast<f16x4*>(sx + i * 8) = h;
+        *reinterpret_cast<f16x4*>(sx + SM_ROWS * SM_PW * 8 + i * 8) = l;
+    }
+    __syncthreads();
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int a_off = (2 * wo + 2 * q) * 8;                    // + (input row) * SM_PW * 8
+    constexpr int XL = SM_ROWS * SM_PW * 8;
+#pragma unroll
+    for (int kh = 0; kh < 7; ++kh) {
+        const int cur = kh & 1, nxt = cur ^ 1;
+        if (kh + 1 < 7) {
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                bh[nxt][nb] = wh[((kh + 1) * 64 + nb * 16) * 4];
+                bl[nxt][nb] = wh[WPLANE + ((kh + 1) * 64 + nb * 16) * 4];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const char* xp = sx + (2 * (wave * 4 + i) + kh) * (SM_PW * 8) + a_off;
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(xp);
+            const f16x8 al = *reinterpret_cast<const f16x8*>(xp + XL);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                f32x4 c = acc[i][nb];
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[cur][nb], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[cur][nb], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[cur][nb], c, 0, 0, 0);
+                acc[i][nb] = c;
+            }
+        }
+    }
+    // Epilogue through LDS so that every store instruction writes whole pixels: the 16 pixels x 64 channels of an M block
+    // are 4 KiB CONTIGUOUS in the NHWC output.  C layout of 16x16: column (channel) = lane & 15, row (pixel) = 4 * (lane >> 4)
+    // + r; each wave passes one M block at a time through its own 16 x 68-word piece of the (now free) input buffer, then
+    // lane l stores 16 bytes of pixel 4 it + (l >> 4): four instructions of 1 KiB each.  (Straight from the accumulators a
+    // store instruction wrote four 64-byte pieces: 1.39 ms for 48 tiles against 1.97 ms for the VALU stem.)
+    __syncthreads();                                            // every wave is done reading the input planes
+    float* ep = reinterpret_cast<float*>(sx) + wave * (16 * 68);
+    float sc4[4], bs4[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        sc4[nb] = scale[nb * 16 + (lane & 15)];                 // scale already carries 1 / (s_in * 2^e(co))
+        bs4[nb] = bias[nb * 16 + (lane & 15)];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ho = ho0 + wave * 4 + i;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = acc[i][nb][r] * sc4[nb] + bs4[nb];
+                ep[(4 * (lane >> 4) + r) * 68 + nb * 16 + (lane & 15)] = v > 0.f ? v : 0.f;
+            }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (ho < Ho) {
+            float* orow = out + (((long)n * Ho + ho) * Wo + wo0) * 64;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int px = 4 * it + (lane >> 4);
+                const float4 v = *reinterpret_cast<const float4*>(ep + px * 68 + (lane & 15) * 4);
+                if (wo0 + px < Wo) *reinterpret_cast<float4*>(orow + px * 64 + (lane & 15) * 4) = v;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
 // maxpool 3x3 s2 p1 from f32 into P32 planes (conv_p32.hip): 8 channels per thread, 16-byte stores per plane.
 // blockIdx.y = image; meta is [groups][2] with groups = 1 or one group per image.
 __global__ void maxpool3x3s2_p32_kernel(const float* __restrict__ in, char* __restrict__ out, float* __restrict__ meta, float s,
@@ -401,6 +521,19 @@ extern "C" int demia_stem_conv(const void* in, const void* w, const float* scale
                            (float*)mid, PH, PW);
     }
     DEMIA_CHECK_LAUNCH("stem_conv_kernel");
+    return DEMIA_OK;
+}
+
+extern "C" int demia_stem_conv_mfma(const float* in, const void* w_planes, const float* scale, const float* bias, float* mid, int N,
+                                    int PH, int PW, float s_in, void* stream) {
+    DEMIA_REQUIRE(in && w_planes && scale && bias && mid && s_in > 0.f, "args");
+    DEMIA_REQUIRE(PH % 32 == 0 && PW % 32 == 0, "padded size");
+    DEMIA_REQUIRE(N <= 65535, "N");
+    const int Ho = PH / 2, Wo = PW / 2;
+    if ((long)N * Ho * Wo == 0) return DEMIA_OK;
+    hipLaunchKernelGGL(stem_mfma_kernel, dim3(cdiv(Wo, 16), cdiv(Ho, 16), N), dim3(256), 0, (hipStream_t)stream, in,
+                       reinterpret_cast<const _Float16*>(w_planes), scale, bias, mid, PH, PW, s_in);
+    DEMIA_CHECK_LAUNCH("stem_mfma_kernel");
     return DEMIA_OK;
 }
 

@@ -160,6 +160,19 @@ def split2_f16_scaled(w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     return torch.stack([h, l], dim=0), sw
 
 
+def stem_weight_planes(w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Stem weights [64, 3, 7, 7] for ``demia_stem_conv_mfma``: K ordered (kh, kw, c) with kw padded to 8 and c to 4 (zero
+    weights), one K-step of 32 per kernel row; per output channel an exact power of two brings max |w| into [2^14, 2^15), then
+    ``w * 2^e = h + l`` in fp16.  Returns (planes [2, 7, 64, 32] fp16, the per-channel factors [64] f32)."""
+    w = w.to(torch.float32)
+    cout = w.shape[0]
+    k = torch.zeros((cout, 7, 8, 4), dtype=torch.float32)
+    k[:, :, :7, :3] = w.permute(0, 2, 3, 1)                       # [co, kh, kw, c]
+    planes, sw = split2_f16_scaled(k.reshape(cout, 7 * 32))
+    planes = planes.reshape(2, cout, 7, 32).permute(0, 2, 1, 3).contiguous()      # [plane, kh, co, 32]
+    return planes, sw
+
+
 def cell_anchor_table() -> np.ndarray:
     out = np.zeros((5, 3, 4), dtype=np.float32)
     for l, size in enumerate(ANCHOR_SIZES):
@@ -248,6 +261,7 @@ class MaskRCNNEngine:
         self._arena_key: Optional[tuple] = None
         self._arena_i = 0
         self._paste_static = None                         # (planes, previous boxes) while a forward is being captured
+        self.stem_on_mfma = self.p32 and os.environ.get("DEEPEMIA_STEM", "mfma") == "mfma"   # f16x2 path: the stem on the matrix pipe
         # arenas, meta pools and captured graphs are per input shape and GBs each (16 x 2048^2 R101: 8.6 GiB): at most this
         # many shapes stay resident, least recently used first out -- a folder of differently sized micrographs must not
         # accumulate one arena per size (the reference handles arbitrary sizes, inference.py:2299-2485)
@@ -332,6 +346,16 @@ class MaskRCNNEngine:
         # |pixel - mean| <= 255 - min(mean): the a-priori bound of the stem's (pooled) output, from which the P32 scale of the
         # first activation tensor is derived on the host
         self.stem_bound = float(((255.0 - min(PIXEL_MEAN)) * sc.abs() * w.abs().flatten(1).sum(1) + (beta - rm * sc).abs()).max())
+        if self.p32:
+            # the stem on the matrix pipe (demia_stem_conv_mfma): weight planes, the input's plane scale (|pixel - mean| <=
+            # 255 - min(mean): a constant, so results do not depend on the image or the batch), FrozenBN scale with both powers
+            # of two divided out
+            planes, sw = stem_weight_planes(w)
+            if self.single_plane:
+                planes[1].zero_()
+            self.stem_planes = planes.to(self.device).contiguous()
+            self.stem_s_in = p32.plane_scale(255.0 - min(PIXEL_MEAN))
+            self.stem_scale_mfma = (sc / (sw * self.stem_s_in)).to(self.device).contiguous()
         self.blocks = []
         for stage, nblk in zip((2, 3, 4, 5), RES_BLOCKS[self.depth]):
             stage_blocks = []
@@ -652,8 +676,12 @@ class MaskRCNNEngine:
         st = self._stream()
         if self.p32:
             mid = self._scratch(b * (ph // 2) * (pw // 2) * 64, torch.float32)
-            _lib.check(self.lib.demia_stem_conv(_lib.ptr(xin), _lib.ptr(self.stem_w), _lib.ptr(self.stem_scale),
-                                                _lib.ptr(self.stem_bias), _lib.ptr(mid), b, ph, pw, F32, st), "demia_stem_conv")
+            if self.stem_on_mfma:
+                _lib.check(self.lib.demia_stem_conv_mfma(_lib.ptr(xin), _lib.ptr(self.stem_planes), _lib.ptr(self.stem_scale_mfma),
+                                                         _lib.ptr(self.stem_bias), _lib.ptr(mid), b, ph, pw, self.stem_s_in, st), "demia_stem_conv_mfma")
+            else:
+                _lib.check(self.lib.demia_stem_conv(_lib.ptr(xin), _lib.ptr(self.stem_w), _lib.ptr(self.stem_scale),
+                                                    _lib.ptr(self.stem_bias), _lib.ptr(mid), b, ph, pw, F32, st), "demia_stem_conv")
             x = self.new_p32((b, ph // 4, pw // 4, 64))
             _lib.check(self.lib.demia_maxpool3x3s2_p32(_lib.ptr(mid), _lib.ptr(x.buf), _lib.ptr(x.meta), p32.plane_scale(self.stem_bound),
                                                        b, ph // 2, pw // 2, 64, x.groups, st), "demia_maxpool3x3s2_p32")

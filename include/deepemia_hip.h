@@ -183,6 +183,12 @@ int demia_resize_linear_u8(const uint8_t* src, uint8_t* dst, int N, int H, int W
  *   mid  [N, PH/2, PW/2, 64]   out [N, PH/4, PW/4, 64]                              */
 int demia_stem_conv(const void* in, const void* w, const float* scale, const float* bias, void* mid,
                     int N, int PH, int PW, int dtype, void* stream);
+/* The same stem (7x7 s2 p3 + FrozenBN + ReLU, f32 NHWC out) on the matrix pipe in the f16x2 arithmetic: the input is split
+ * into two fp16 planes of x * s_in (s_in an exact power of two with |x| s_in < 2^15) while it is staged, w_planes
+ * [2][7][64][32] fp16 hold w * 2^e(co) with K ordered (kh, kw padded to 8, c padded to 4), and `scale` carries the FrozenBN
+ * scale divided by s_in * 2^e(co).  Replaces the same Detectron2 BasicStem.conv1 as demia_stem_conv. */
+int demia_stem_conv_mfma(const float* in, const void* w_planes, const float* scale, const float* bias, float* mid, int N,
+                         int PH, int PW, float s_in, void* stream);
 int demia_maxpool3x3s2(const void* in, void* out, int N, int H, int W, int C, int dtype, void* stream);
 /* the same pool from an f32 input into a P32 buffer scaled with the power of two `s` (the caller derives it from the
  * stem's a-priori bound); out_meta receives {max |out| (atomic max; zero it first), s} -- one pair (groups <= 1) or one

@@ -70,6 +70,37 @@ def test_resize_normalise_bit_exact_vs_pillow(env, hw):
     assert not got[mask].any()
 
 
+@pytest.mark.parametrize("hw", [(512, 512), (300, 500), (2048, 2048)])
+def test_stem_on_the_matrix_pipe_equals_the_f32_stem(env, hw):
+    """``demia_stem_conv_mfma`` (the stem of the f16x2 path: input and weights as two fp16 planes, three MFMAs per product)
+    against the exact-f32 VALU stem on the same zero-bordered input: f32-sized error, ReLU zeros in the same places up to
+    that error, and identical results for an image alone and inside a batch."""
+    import ctypes as C
+    from deepemia_amd import _lib
+
+    eng = env["f16x2"]
+    h, w = hw
+    rng = np.random.default_rng(h + w)
+    imgs = rng.integers(0, 256, size=(2, h, w, 3), dtype=np.uint8)
+    imgs[1] = (imgs[1] // 3)                                       # a darker image beside a bright one
+    x = torch.from_numpy(imgs).to(env["dev"])
+    xin, newh, neww, ph, pw = eng.preprocess(x)
+    st = int(torch.cuda.current_stream().cuda_stream)
+    a = torch.empty((2, ph // 2, pw // 2, 64), dtype=torch.float32, device=env["dev"])
+    b = torch.empty_like(a)
+    _lib.check(eng.lib.demia_stem_conv(_lib.ptr(xin), _lib.ptr(eng.stem_w), _lib.ptr(eng.stem_scale), _lib.ptr(eng.stem_bias), _lib.ptr(a),
+                                       2, ph, pw, _lib.F32, st), "stem")
+    _lib.check(eng.lib.demia_stem_conv_mfma(_lib.ptr(xin), _lib.ptr(eng.stem_planes), _lib.ptr(eng.stem_scale_mfma), _lib.ptr(eng.stem_bias),
+                                            _lib.ptr(b), 2, ph, pw, eng.stem_s_in, st), "stem mfma")
+    err = float((a - b).abs().max() / a.abs().max())
+    assert err < 2e-6, err
+    assert float(a.abs().max()) > 1.0
+    one = torch.empty((1, ph // 2, pw // 2, 64), dtype=torch.float32, device=env["dev"])
+    _lib.check(eng.lib.demia_stem_conv_mfma(_lib.ptr(xin[1:].contiguous()), _lib.ptr(eng.stem_planes), _lib.ptr(eng.stem_scale_mfma),
+                                            _lib.ptr(eng.stem_bias), _lib.ptr(one), 1, ph, pw, eng.stem_s_in, st), "stem mfma")
+    assert torch.equal(one[0], b[1])
+
+
 CONV_CASES = [
     # cin, cout, k, stride, pad, h, w, n, relu, res
     (64, 64, 1, 1, 0, 50, 50, 2, True, 0),
