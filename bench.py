@@ -189,6 +189,7 @@ def main() -> None:
             dist.barrier()
             torch.cuda.synchronize()
 
+    DIAG_POST = os.environ.get("DEEPEMIA_BENCH_POST", "")
     MIN_AREA = max(5, args.size * args.size * 0.000005 * 0.05)      # inference.py:1175-1190
     from concurrent.futures import ThreadPoolExecutor
     csv_pool, csv_jobs = ThreadPoolExecutor(max_workers=1), []
@@ -218,7 +219,17 @@ def main() -> None:
     last = {}
 
     def post(i, handle):
+        tp0 = time.perf_counter()
+        try:
+            return _post(i, handle)
+        finally:
+            last["post_s"] = last.get("post_s", 0.0) + time.perf_counter() - tp0
+
+    def _post(i, handle):
         dets = pipe.finish_forward(handle)
+        if DIAG_POST == "wait":          # (diagnostic: the forward's tables fetched, no post-processing kernels at all)
+            time.sleep(0.02)
+            return 0, 0
         res = pipe.process_tile_batch(f"step{i}", x, SMALL_CLASSES, CLASS_THRESHOLDS, dets=dets)
         if i >= 0 and i % len(xs) == 0 or not args.total_tiles:
             last["res"] = res          # the step whose tile 0 is synthetic tile 0 (the parity check's reference)
@@ -267,6 +278,7 @@ def main() -> None:
     sync_all()
     eng.conv_events = None if (args.no_conv_events or args.graph) else []
     waits0 = pipe.d2h_waits
+    last["post_s"] = 0.0
     t0 = time.perf_counter()
     if args.forward_only or args.no_overlap:
         for i in range(args.steps):
@@ -284,6 +296,7 @@ def main() -> None:
     sync_all()
     dt = time.perf_counter() - t0
     d2h_waits_per_step = (pipe.d2h_waits - waits0) / max(args.steps, 1)
+    post_wall_ms = last.get("post_s", 0.0) / max(args.steps, 1) * 1e3     # host wall time inside the post-processing of a step (incl. its waits)
     events, eng.conv_events = eng.conv_events or [], None
 
     def snapshot(res):
@@ -410,7 +423,8 @@ def main() -> None:
                        "tiles_per_step_per_gpu": args.batch, "instances_last_step_rank0": det_total,
                        "csv_rows_last_step_rank0": rows_total, "stage": "predictor only" if args.forward_only else "whole per-tile path",
                        "overlap": (not args.forward_only) and (not args.no_overlap), "hipgraph_forward": bool(args.graph),
-                       "post_d2h_waits_per_step": None if args.forward_only else d2h_waits_per_step},
+                       "post_d2h_waits_per_step": None if args.forward_only else d2h_waits_per_step,
+                       "post_wall_ms_per_step": None if args.forward_only else post_wall_ms},
             "roofline": {"bound": "mfma", "kernel": ("conv_igemm_split_kernel (implicit-GEMM conv, f32 operands as 3 bf16 planes, 6 bf16 MFMAs "
                                                      "per product; peak = bf16 dense peak / 6)" if args.precision == "f32x3" else
                                                      "conv_p32_kernel (implicit-GEMM conv, both operands as 2 pre-scaled fp16 planes moved by LDS-DMA, "

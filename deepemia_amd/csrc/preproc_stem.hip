@@ -398,6 +398,142 @@ __global__ __launch_bounds__(256, 2) void stem_mfma_kernel(const float* __restri
     }
 }
 
+// ---- stem + max pool in ONE kernel: 7x7 s2 conv + FrozenBN + ReLU + 3x3 s2 p1 max pool, P32 planes out ---------------
+// The f32 stem output (2 GB per 48 tiles) is never written: a workgroup computes a 16 x 16 tile of conv outputs that
+// starts ONE row / column before an even position (conv rows 2 pi0 - 1 .. 2 pi0 + 14), leaves them in LDS and pools the
+// 7 x 7 outputs whose windows lie inside the tile.  Tiles therefore overlap by two conv rows / columns (1.31 x the conv
+// work, which is the cheap part).  Conv positions outside the image count as 0: every real value is >= 0 after the ReLU,
+// so a 0 never changes the maximum over the valid ones (torch pads the pool with -inf).
+constexpr int SP_CROW = 16 * 68;                 // words per conv row in LDS: 16 pixels x (64 channels + 4 pad)
+__global__ __launch_bounds__(256, 2) void stem_pool_mfma_kernel(const float* __restrict__ in, const _Float16* __restrict__ wpl,
+                                                                const float* __restrict__ scale, const float* __restrict__ bias,
+                                                                char* __restrict__ out, float* __restrict__ meta, int PH, int PW,
+                                                                float s_in, float s_out, int groups, int single) {
+    __shared__ __attribute__((aligned(16))) char smem[16 * SP_CROW * 4];               // conv tile (69.6 KB); first the input planes
+    char* sx = smem;
+    const int Ho = PH / 2, Wo = PW / 2, Hp = (Ho + 2 - 3) / 2 + 1, Wp = (Wo + 2 - 3) / 2 + 1, DW = PW + 8, DH = PH + 6;
+    const int n = blockIdx.z, pi0 = blockIdx.y * 7, pj0 = blockIdx.x * 7;
+    const int hb = 2 * pi0 - 1, wb = 2 * pj0 - 1;                // conv position of tile element (0, 0)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wo = lane & 15, q = lane >> 4;
+    const f16x8* wh = reinterpret_cast<const f16x8*>(wpl) + (lane & 15) * 4 + q;
+    constexpr int WPLANE = 7 * 64 * 4;
+    f16x8 bh[2][4], bl[2][4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        bh[0][nb] = wh[(nb * 16) * 4];
+        bl[0][nb] = wh[WPLANE + (nb * 16) * 4];
+    }
+    // input patch: bordered rows 2 hb .. + 36, pixels 2 wb .. + 39 (negative at the top / left tiles: zeros)
+    const float4* in4 = reinterpret_cast<const float4*>(in) + (long)n * DH * DW;
+    for (int i = tid; i < SM_ROWS * SM_PW; i += 256) {
+        const int r = i / SM_PW, c = i - r * SM_PW;
+        const int gy = 2 * hb + r, gx = 2 * wb + c;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gy >= 0 && gx >= 0 && gy < DH && gx < DW) v = in4[(long)gy * DW + gx];
+        const float y[4] = {v.x * s_in, v.y * s_in, v.z * s_in, v.w * s_in};
+        f16x4 h, l;
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+            h[c4] = (_Float16)y[c4];
+            l[c4] = (_Float16)(y[c4] - (float)h[c4]);
+        }
+        *reinterpret_cast<f16x4*>(sx + i * 8) = h;
+        *reinterpret_cast<f16x4*>(sx + SM_ROWS * SM_PW * 8 + i * 8) = l;
+    }
+    __syncthreads();
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int a_off = (2 * wo + 2 * q) * 8;
+    constexpr int XL = SM_ROWS * SM_PW * 8;
+#pragma unroll
+    for (int kh = 0; kh < 7; ++kh) {
+        const int cur = kh & 1, nxt = cur ^ 1;
+        if (kh + 1 < 7) {
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                bh[nxt][nb] = wh[((kh + 1) * 64 + nb * 16) * 4];
+                bl[nxt][nb] = wh[WPLANE + ((kh + 1) * 64 + nb * 16) * 4];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const char* xp = sx + (2 * (wave * 4 + i) + kh) * (SM_PW * 8) + a_off;
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(xp);
+            const f16x8 al = *reinterpret_cast<const f16x8*>(xp + XL);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                f32x4 c = acc[i][nb];
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[cur][nb], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[cur][nb], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[cur][nb], c, 0, 0, 0);
+                acc[i][nb] = c;
+            }
+        }
+    }
+    __syncthreads();                                            // the input planes are dead: the conv tile takes their place
+    float* cv = reinterpret_cast<float*>(smem);
+    float sc4[4], bs4[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        sc4[nb] = scale[nb * 16 + (lane & 15)];
+        bs4[nb] = bias[nb * 16 + (lane & 15)];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int tr = wave * 4 + i, ho = hb + tr;
+        const bool row_ok = ho >= 0 && ho < Ho;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int px = 4 * (lane >> 4) + r, wx = wb + px;
+            const bool ok = row_ok && wx >= 0 && wx < Wo;
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                const float v = acc[i][nb][r] * sc4[nb] + bs4[nb];
+                cv[tr * SP_CROW + px * 68 + nb * 16 + (lane & 15)] = (ok && v > 0.f) ? v : 0.f;
+            }
+        }
+    }
+    __syncthreads();
+    float vmax = 0.f;
+    for (int it = tid; it < 49 * 8; it += 256) {
+        const int pp = it >> 3, cg = it & 7;
+        const int pi = pp / 7, pj = pp - pi * 7;
+        const int gi = pi0 + pi, gj = pj0 + pj;
+        if (gi >= Hp || gj >= Wp) continue;
+        float m[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const float* p = cv + (2 * pi + dy) * SP_CROW + (2 * pj + dx) * 68 + cg * 8;
+                const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+                m[0] = fmaxf(m[0], a.x); m[1] = fmaxf(m[1], a.y); m[2] = fmaxf(m[2], a.z); m[3] = fmaxf(m[3], a.w);
+                m[4] = fmaxf(m[4], b.x); m[5] = fmaxf(m[5], b.y); m[6] = fmaxf(m[6], b.z); m[7] = fmaxf(m[7], b.w);
+            }
+        f16x8 h, l;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            vmax = fmaxf(vmax, m[c]);
+            const float y = m[c] * s_out;
+            h[c] = (_Float16)y;
+            l[c] = single ? (_Float16)0.f : (_Float16)(y - (float)h[c]);
+        }
+        char* o = out + 128 + (((long)n * Hp + gi) * Wp + gj) * 256L + (cg >> 2) * 128 + (cg & 3) * 16;
+        *reinterpret_cast<f16x8*>(o) = h;
+        *reinterpret_cast<f16x8*>(o + 64) = l;
+    }
+    float* slot = meta + (groups > 1 ? 2 * n : 0);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+    if (lane == 0 && vmax > *reinterpret_cast<volatile const float*>(slot))
+        atomicMax(reinterpret_cast<unsigned int*>(slot), __float_as_uint(vmax));
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && (groups > 1 || n == 0)) slot[1] = s_out;
+}
+
 // maxpool 3x3 s2 p1 from f32 into P32 planes (conv_p32.hip): 8 channels per thread, 16-byte stores per plane.
 // blockIdx.y = image; meta is [groups][2] with groups = 1 or one group per image.
 __global__ void maxpool3x3s2_p32_kernel(const float* __restrict__ in, char* __restrict__ out, float* __restrict__ meta, float s,
@@ -534,6 +670,21 @@ extern "C" int demia_stem_conv_mfma(const float* in, const void* w_planes, const
     hipLaunchKernelGGL(stem_mfma_kernel, dim3(cdiv(Wo, 16), cdiv(Ho, 16), N), dim3(256), 0, (hipStream_t)stream, in,
                        reinterpret_cast<const _Float16*>(w_planes), scale, bias, mid, PH, PW, s_in);
     DEMIA_CHECK_LAUNCH("stem_mfma_kernel");
+    return DEMIA_OK;
+}
+
+extern "C" int demia_stem_pool_mfma(const float* in, const void* w_planes, const float* scale, const float* bias, void* out,
+                                    float* out_meta, int N, int PH, int PW, float s_in, float s_out, int groups, void* stream) {
+    DEMIA_REQUIRE(in && w_planes && scale && bias && out && out_meta && s_in > 0.f && s_out > 0.f, "args");
+    DEMIA_REQUIRE(PH % 32 == 0 && PW % 32 == 0, "padded size");
+    DEMIA_REQUIRE(groups <= 1 || groups == N, "scale groups: one per image");
+    DEMIA_REQUIRE(N <= 65535, "N");
+    const int Hp = PH / 4, Wp = PW / 4;
+    if ((long)N * Hp * Wp == 0) return DEMIA_OK;
+    hipLaunchKernelGGL(stem_pool_mfma_kernel, dim3(cdiv(Wp, 7), cdiv(Hp, 7), N), dim3(256), 0, (hipStream_t)stream, in,
+                       reinterpret_cast<const _Float16*>(w_planes), scale, bias, (char*)out, out_meta, PH, PW, s_in, s_out, groups,
+                       g_demia_single_plane);
+    DEMIA_CHECK_LAUNCH("stem_pool_mfma_kernel");
     return DEMIA_OK;
 }
 

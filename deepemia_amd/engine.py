@@ -261,7 +261,9 @@ class MaskRCNNEngine:
         self._arena_key: Optional[tuple] = None
         self._arena_i = 0
         self._paste_static = None                         # (planes, previous boxes) while a forward is being captured
-        self.stem_on_mfma = self.p32 and os.environ.get("DEEPEMIA_STEM", "mfma") == "mfma"   # f16x2 path: the stem on the matrix pipe
+        # f16x2 path: the stem on the matrix pipe, fused with the max pool (DEEPEMIA_STEM = fused | mfma | valu for A/B)
+        self.stem_mode = os.environ.get("DEEPEMIA_STEM", "fused") if self.p32 else "valu"
+        self.stem_on_mfma = self.stem_mode in ("fused", "mfma")
         # arenas, meta pools and captured graphs are per input shape and GBs each (16 x 2048^2 R101: 8.6 GiB): at most this
         # many shapes stay resident, least recently used first out -- a folder of differently sized micrographs must not
         # accumulate one arena per size (the reference handles arbitrary sizes, inference.py:2299-2485)
@@ -675,16 +677,27 @@ class MaskRCNNEngine:
         b = xin.shape[0]
         st = self._stream()
         if self.p32:
-            mid = self._scratch(b * (ph // 2) * (pw // 2) * 64, torch.float32)
-            if self.stem_on_mfma:
+            if self.stem_mode == "fused":
+                # stem + max pool in one launch, planes out: the 2 GB f32 stem output of a 48-tile batch is never written
+                x = self.new_p32((b, ph // 4, pw // 4, 64))
+                _lib.check(self.lib.demia_stem_pool_mfma(_lib.ptr(xin), _lib.ptr(self.stem_planes), _lib.ptr(self.stem_scale_mfma),
+                                                         _lib.ptr(self.stem_bias), _lib.ptr(x.buf), _lib.ptr(x.meta), b, ph, pw, self.stem_s_in,
+                                                         p32.plane_scale(self.stem_bound), x.groups, st), "demia_stem_pool_mfma")
+                mid = None
+            else:
+                mid = self._scratch(b * (ph // 2) * (pw // 2) * 64, torch.float32)
+            if mid is None:
+                pass
+            elif self.stem_on_mfma:
                 _lib.check(self.lib.demia_stem_conv_mfma(_lib.ptr(xin), _lib.ptr(self.stem_planes), _lib.ptr(self.stem_scale_mfma),
                                                          _lib.ptr(self.stem_bias), _lib.ptr(mid), b, ph, pw, self.stem_s_in, st), "demia_stem_conv_mfma")
             else:
                 _lib.check(self.lib.demia_stem_conv(_lib.ptr(xin), _lib.ptr(self.stem_w), _lib.ptr(self.stem_scale),
                                                     _lib.ptr(self.stem_bias), _lib.ptr(mid), b, ph, pw, F32, st), "demia_stem_conv")
-            x = self.new_p32((b, ph // 4, pw // 4, 64))
-            _lib.check(self.lib.demia_maxpool3x3s2_p32(_lib.ptr(mid), _lib.ptr(x.buf), _lib.ptr(x.meta), p32.plane_scale(self.stem_bound),
-                                                       b, ph // 2, pw // 2, 64, x.groups, st), "demia_maxpool3x3s2_p32")
+            if mid is not None:
+                x = self.new_p32((b, ph // 4, pw // 4, 64))
+                _lib.check(self.lib.demia_maxpool3x3s2_p32(_lib.ptr(mid), _lib.ptr(x.buf), _lib.ptr(x.meta), p32.plane_scale(self.stem_bound),
+                                                           b, ph // 2, pw // 2, 64, x.groups, st), "demia_maxpool3x3s2_p32")
         else:
             mid = torch.empty((b, ph // 2, pw // 2, 64), dtype=self.tdt, device=self.device)
             _lib.check(self.lib.demia_stem_conv(_lib.ptr(xin), _lib.ptr(self.stem_w), _lib.ptr(self.stem_scale),

@@ -189,6 +189,10 @@ int demia_stem_conv(const void* in, const void* w, const float* scale, const flo
  * scale divided by s_in * 2^e(co).  Replaces the same Detectron2 BasicStem.conv1 as demia_stem_conv. */
 int demia_stem_conv_mfma(const float* in, const void* w_planes, const float* scale, const float* bias, float* mid, int N,
                          int PH, int PW, float s_in, void* stream);
+/* ... and stem + max pool (3x3 s2 p1) in ONE kernel, P32 planes out: the f32 stem output is never written.  out / out_meta /
+ * s_out / groups as demia_maxpool3x3s2_p32 (s_out = the planes' power-of-two scale from the a-priori bound of the stem output). */
+int demia_stem_pool_mfma(const float* in, const void* w_planes, const float* scale, const float* bias, void* out, float* out_meta,
+                         int N, int PH, int PW, float s_in, float s_out, int groups, void* stream);
 int demia_maxpool3x3s2(const void* in, void* out, int N, int H, int W, int C, int dtype, void* stream);
 /* the same pool from an f32 input into a P32 buffer scaled with the power of two `s` (the caller derives it from the
  * stem's a-priori bound); out_meta receives {max |out| (atomic max; zero it first), s} -- one pair (groups <= 1) or one

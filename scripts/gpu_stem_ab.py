@@ -19,4 +19,10 @@ def t(fn, reps=10):
     return e0.elapsed_time(e1) / reps
 a = t(lambda: _lib.check(eng.lib.demia_stem_conv(_lib.ptr(xin), _lib.ptr(eng.stem_w), _lib.ptr(eng.stem_scale), _lib.ptr(eng.stem_bias), _lib.ptr(out), B, ph, pw, _lib.F32, st), 'a'))
 b = t(lambda: _lib.check(eng.lib.demia_stem_conv_mfma(_lib.ptr(xin), _lib.ptr(eng.stem_planes), _lib.ptr(eng.stem_scale_mfma), _lib.ptr(eng.stem_bias), _lib.ptr(out), B, ph, pw, eng.stem_s_in, st), 'b'))
+from deepemia_amd import p32
+xp = p32.alloc((B, ph // 4, pw // 4, 64), 'cuda:0', groups=B)
+s_out = p32.plane_scale(eng.stem_bound)
+c = t(lambda: _lib.check(eng.lib.demia_maxpool3x3s2_p32(_lib.ptr(out), _lib.ptr(xp.buf), _lib.ptr(xp.meta), s_out, B, ph // 2, pw // 2, 64, B, st), 'c'))
+d = t(lambda: _lib.check(eng.lib.demia_stem_pool_mfma(_lib.ptr(xin), _lib.ptr(eng.stem_planes), _lib.ptr(eng.stem_scale_mfma), _lib.ptr(eng.stem_bias), _lib.ptr(xp.buf), _lib.ptr(xp.meta), B, ph, pw, eng.stem_s_in, s_out, B, st), 'd'))
+print(f'max pool (f32 -> P32) {c*1e3:.0f} us; fused stem + pool {d*1e3:.0f} us')
 print(f'B={B}: VALU stem {a*1e3:.0f} us, MFMA stem {b*1e3:.0f} us ({out.numel()*4/1e9:.2f} GB written)')

@@ -99,6 +99,18 @@ def test_stem_on_the_matrix_pipe_equals_the_f32_stem(env, hw):
     _lib.check(eng.lib.demia_stem_conv_mfma(_lib.ptr(xin[1:].contiguous()), _lib.ptr(eng.stem_planes), _lib.ptr(eng.stem_scale_mfma),
                                             _lib.ptr(eng.stem_bias), _lib.ptr(one), 1, ph, pw, eng.stem_s_in, st), "stem mfma")
     assert torch.equal(one[0], b[1])
+    # stem + max pool in ONE kernel (planes out, the f32 stem output never written) = the two kernels, bit for bit: the same
+    # MFMA sequence per conv output, the same maxima, the same plane split and |x| maxima
+    from deepemia_amd import p32
+    for groups in (1, 2):
+        s_out = p32.plane_scale(eng.stem_bound)
+        two = p32.alloc((2, ph // 4, pw // 4, 64), env["dev"], groups=groups)
+        fused = p32.alloc((2, ph // 4, pw // 4, 64), env["dev"], groups=groups)
+        _lib.check(eng.lib.demia_maxpool3x3s2_p32(_lib.ptr(b), _lib.ptr(two.buf), _lib.ptr(two.meta), s_out, 2, ph // 2, pw // 2, 64, groups, st), "pool")
+        _lib.check(eng.lib.demia_stem_pool_mfma(_lib.ptr(xin), _lib.ptr(eng.stem_planes), _lib.ptr(eng.stem_scale_mfma), _lib.ptr(eng.stem_bias),
+                                                _lib.ptr(fused.buf), _lib.ptr(fused.meta), 2, ph, pw, eng.stem_s_in, s_out, groups, st), "fused")
+        assert torch.equal(fused.buf, two.buf) and torch.equal(fused.meta, two.meta), groups
+        assert float(fused.meta[:, 0].min()) > 0.0
 
 
 CONV_CASES = [
