@@ -105,3 +105,86 @@ extern "C" int demia_host_dedup_smart(const int32_t* inter, int ld, const int32_
     }
     return DEMIA_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The float columns of measurements_results.csv as text.  The reference writes its rows with Python's csv.writer, which
+// formats a float with repr(): the shortest digit string that round-trips (David Gay's mode 0 = what std::to_chars yields),
+// laid out by CPython's rule -- scientific notation iff the decimal point position `decpt` (value = 0.d1d2... x 10^decpt) is
+// <= -4 or > 16, exponent with sign and at least two digits, otherwise positional with a ".0" appended to integers.  2700
+// rows x 12 floats per 48-tile step are 21 ms of interpreter time that way; here one native call writes the comma-joined
+// floats of every row (rows separated by '\n'), the host code adds the string columns around them.
+#include <charconv>
+#include <cmath>
+#include <cstring>
+
+namespace {
+
+// repr(x) into `out`; returns the number of characters written (at most 24 + sign)
+inline int py_float_repr(double x, char* out) {
+    if (std::isnan(x)) { memcpy(out, "nan", 3); return 3; }
+    if (std::isinf(x)) { if (x < 0) { memcpy(out, "-inf", 4); return 4; } memcpy(out, "inf", 3); return 3; }
+    char* o = out;
+    if (std::signbit(x)) { *o++ = '-'; x = -x; }
+    if (x == 0.0) { memcpy(o, "0.0", 3); return (int)(o - out) + 3; }
+    char sci[40];
+    const auto r = std::to_chars(sci, sci + sizeof(sci), x, std::chars_format::scientific);     // d[.ddd]e[+-]XX, shortest digits
+    const char* e = sci;
+    while (e < r.ptr && *e != 'e') ++e;
+    char digits[24];
+    int nd = 0;
+    for (const char* c = sci; c < e; ++c)
+        if (*c != '.') digits[nd++] = *c;
+    int ex = 0;
+    {
+        const char* c = e + 1;
+        const bool neg = *c == '-';
+        if (*c == '+' || *c == '-') ++c;
+        for (; c < r.ptr; ++c) ex = ex * 10 + (*c - '0');
+        if (neg) ex = -ex;
+    }
+    const int decpt = ex + 1;
+    if (decpt <= -4 || decpt > 16) {
+        *o++ = digits[0];
+        if (nd > 1) { *o++ = '.'; memcpy(o, digits + 1, nd - 1); o += nd - 1; }
+        *o++ = 'e';
+        int xe = decpt - 1;
+        *o++ = xe < 0 ? '-' : '+';
+        if (xe < 0) xe = -xe;
+        char tmp[8];
+        int nt = 0;
+        do { tmp[nt++] = (char)('0' + xe % 10); xe /= 10; } while (xe);
+        if (nt < 2) tmp[nt++] = '0';
+        while (nt) *o++ = tmp[--nt];
+    } else if (decpt <= 0) {
+        *o++ = '0'; *o++ = '.';
+        for (int i = 0; i < -decpt; ++i) *o++ = '0';
+        memcpy(o, digits, nd); o += nd;
+    } else if (decpt >= nd) {
+        memcpy(o, digits, nd); o += nd;
+        for (int i = 0; i < decpt - nd; ++i) *o++ = '0';
+        *o++ = '.'; *o++ = '0';
+    } else {
+        memcpy(o, digits, decpt); o += decpt;
+        *o++ = '.';
+        memcpy(o, digits + decpt, nd - decpt); o += nd - decpt;
+    }
+    return (int)(o - out);
+}
+
+}  // namespace
+
+// vals [rows][cols] f64 -> out: per row the repr() of its floats joined by ',', rows separated by '\n' (no trailing one).
+// Returns the number of bytes written, or -1 if `cap` is too small (needs at most rows * cols * 26 bytes).
+extern "C" int64_t demia_host_repr_rows(const double* vals, int64_t rows, int cols, char* out, int64_t cap) {
+    if (!vals || !out || rows < 0 || cols <= 0) return -1;
+    int64_t pos = 0;
+    for (int64_t r = 0; r < rows; ++r) {
+        if (pos + (int64_t)cols * 26 + 1 > cap) return -1;
+        if (r) out[pos++] = '\n';
+        for (int c = 0; c < cols; ++c) {
+            if (c) out[pos++] = ',';
+            pos += py_float_repr(vals[r * cols + c], out + pos);
+        }
+    }
+    return pos;
+}

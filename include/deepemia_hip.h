@@ -367,6 +367,10 @@ int demia_host_greedy_keep(const int32_t* inter, int ld, const int32_t* row_firs
 int demia_host_dedup_smart(const int32_t* inter, int ld, const int32_t* row_first, const int64_t* area, const int64_t* bbox,
                            const int32_t* items, const double* scores, const int32_t* classes, const int32_t* tile_off, int T,
                            double thr, int32_t* keep_out, int32_t* keep_cnt);
+/* The float columns of measurements_results.csv as text (inference.py:1209-1230 writes them with csv.writer, i.e. repr()):
+ * vals [rows][cols] f64 -> per row the Python repr() of its floats joined by ',', rows separated by '\n'.  Returns the
+ * bytes written, -1 if cap < rows * cols * 26 + rows. */
+int64_t demia_host_repr_rows(const double* vals, int64_t rows, int cols, char* out, int64_t cap);
 int demia_mask_place_tiles(const uint32_t* src, uint32_t* dst, const int32_t* x_off, const int32_t* y_off, int64_t T,
                            int src_h, int src_w, int tile_h, int tile_w, int H, int W, void* stream);
 /* Instance tables (what the ranks exchange before the global duplicate / containment filters,

@@ -611,3 +611,51 @@ def test_native_greedy_keep_and_smart_dedup_equal_the_python_loops():
                 want = IP._dedup_smart_order(alg, k0, sc.tolist(), cl.tolist(), bb, thr) if k0 else []
                 got = keep_out[off_a[t]:off_a[t] + keep_cnt[t]].tolist()
                 assert got == want, (trial, t, thr)
+
+
+def test_native_csv_text_equals_csv_writer_byte_for_byte():
+    """``measurement_csv_text`` (float columns through ``demia_host_repr_rows``) against ``csv.writer`` over
+    ``measurement_rows`` -- what ``write_measurements`` writes: random measurement values of every magnitude (random bit
+    patterns, integers, tiny / huge exponents, signed zeros, inf / nan), several tiles, contours below the area gate, class
+    ids beyond the class list, and a name that needs quoting (falls back to csv.writer)."""
+    import csv, io
+    from deepemia_amd.functions.inference import measurement_csv_text, measurement_rows
+
+    g = np.random.default_rng(3)
+    special = np.array([0.0, -0.0, 1.0, 1e16, 1e15, 9999999999999998.0, 1e-4, 1e-5, 5e-324, 1.7976931348623157e308, 0.1, 1 / 3,
+                        float("inf"), float("-inf"), float("nan"), 123456789012345678.0, 1e22, 2.5e-7, 100.0, 0.30000000000000004])
+
+    def recs_for(n_inst):
+        out = []
+        for _ in range(n_inst):
+            cont = []
+            for _ in range(int(g.integers(1, 4))):
+                kind = g.integers(0, 4)
+                if kind == 0:
+                    v = g.random(12) * 10.0 ** g.integers(-9, 20, 12)
+                elif kind == 1:
+                    v = np.frombuffer(g.bytes(96), dtype=np.float64).copy()
+                elif kind == 2:
+                    v = g.integers(0, 10 ** 7, 12).astype(np.float64)
+                else:
+                    v = g.choice(special, 12)
+                cont.append({"area": float(g.choice([1.0, 3.0, 50.0, 900.0])), "values": v})
+            out.append(cont)
+        return out
+
+    for names in (["tile0.tif", "em_12.png", "a b.tif"], ['we,ird "name".tif', "x.tif"]):
+        tiles = []
+        for nm in names:
+            n_inst = int(g.integers(0, 40))
+            tiles.append((nm, g.integers(0, 4, n_inst).tolist(), recs_for(n_inst)))
+        got = measurement_csv_text(tiles, ("pore", "throat"), 5.0, psum="600")
+        buf = io.StringIO()
+        w = csv.writer(buf)
+        rows = 0
+        for nm, cl, rc in tiles:
+            for r in measurement_rows(nm, cl, rc, ("pore", "throat"), 5.0, None, "600"):
+                w.writerow(r)
+                rows += 1
+        assert got == buf.getvalue()
+        assert rows > 10
+    assert measurement_csv_text([("t.tif", [], [])], ("a",), 5.0) == ""
