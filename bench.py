@@ -111,6 +111,7 @@ def main() -> None:
                     "without the 3-tile cpu_baseline timing (the -m gpu configs[4] job)")
     ap.add_argument("--no-h2d-leg", action="store_true", help="skip the second timed leg that uploads every step's tiles from pinned "
                     "host memory on a copy stream (reported as `h2d`, never as `value`)")
+    ap.add_argument("--no-plane-pools", action="store_true", help="(A/B) gather mask sets into fresh zero-filled planes instead of the plane pools")
     ap.add_argument("--no-csv-text", action="store_true", help="leave the CSV text (a19) of every step out of the timed region")
     ap.add_argument("--no-overlap", action="store_true", help="do not overlap batch i+1's network with batch i's post-processing")
     ap.add_argument("--forward-only", action="store_true", help="time predictor(tile) only, without the per-tile post-processing")
@@ -160,6 +161,7 @@ def main() -> None:
     pipe.forward_batch = args.batch             # ONE forward per step over the whole batch (the CLI default chunks at 16)
     # the loop below consumes batch i's detections before it launches forward i + 2: two graph slots, results read in place
     pipe.graph_slots, pipe.clone_graph_outputs = 2, False
+    pipe.pooled_planes = not args.no_plane_pools   # ... and its masks before the next step's post-processing: plane pools
     # tiles 0..NUMPY_TILES-1 of the batch are the byte-reproducible numpy tiles (tile 0 is what the parity leg checks, the
     # CPU baseline times tiles 0..2); the rest of a large batch comes from the device generator (1.4 s of host numpy per tile)
     n_np = min(args.batch, NUMPY_TILES)
@@ -216,12 +218,21 @@ def main() -> None:
 
     def _post(i, handle):
         dets = pipe.finish_forward(handle)
+        tq0 = time.perf_counter()
+        try:
+            return _post_after_forward(i, dets)
+        finally:
+            last["post_after_fwd_s"] = last.get("post_after_fwd_s", 0.0) + time.perf_counter() - tq0
+
+    def _post_after_forward(i, dets):
         if DIAG_POST == "wait":          # (diagnostic: the forward's tables fetched, no post-processing kernels at all)
             time.sleep(0.02)
             return 0, 0
         res = pipe.process_tile_batch(f"step{i}", x, SMALL_CLASSES, CLASS_THRESHOLDS, dets=dets)
         if i >= 0 and i % len(xs) == 0 or not args.total_tiles:
-            last["res"] = res          # the step whose tile 0 is synthetic tile 0 (the parity check's reference)
+            # the step whose tile 0 is synthetic tile 0 (the parity check's reference); with plane pools the masks are views
+            # that the next step overwrites, and a multi-step job checks step 0 at the end: keep tile 0's own copy
+            last["res"] = [(res[0][0].clone() if (res[0][0] is not None and args.total_tiles) else res[0][0],) + tuple(res[0][1:])] + list(res[1:])
         n_inst = sum(0 if r[0] is None else int(r[0].shape[0]) for r in res)
         if args.no_csv_text:
             n_rows = sum(len(c) for r in res for c in r[3])
@@ -257,7 +268,7 @@ def main() -> None:
     sync_all()
     eng.conv_events = None if (args.no_conv_events or args.graph) else []
     waits0 = pipe.d2h_waits
-    last["post_s"] = 0.0
+    last["post_s"] = last["post_after_fwd_s"] = 0.0
     t0 = time.perf_counter()
     if args.forward_only or args.no_overlap:
         for i in range(args.steps):
@@ -274,6 +285,7 @@ def main() -> None:
     dt = time.perf_counter() - t0
     d2h_waits_per_step = (pipe.d2h_waits - waits0) / max(args.steps, 1)
     post_wall_ms = last.get("post_s", 0.0) / max(args.steps, 1) * 1e3     # host wall time inside the post-processing of a step (incl. its waits)
+    post_after_fwd_ms = last.get("post_after_fwd_s", 0.0) / max(args.steps, 1) * 1e3   # ... of which after the step's own forward had finished
     events, eng.conv_events = eng.conv_events or [], None
 
     def snapshot(res):
@@ -399,7 +411,8 @@ def main() -> None:
                        "csv_rows_last_step_rank0": rows_total, "stage": "predictor only" if args.forward_only else "whole per-tile path",
                        "overlap": (not args.forward_only) and (not args.no_overlap), "hipgraph_forward": bool(args.graph),
                        "post_d2h_waits_per_step": None if args.forward_only else d2h_waits_per_step,
-                       "post_wall_ms_per_step": None if args.forward_only else post_wall_ms},
+                       "post_wall_ms_per_step": None if args.forward_only else post_wall_ms,
+                       "post_after_forward_ms_per_step": None if args.forward_only else post_after_fwd_ms},
             "roofline": {"bound": "mfma", "kernel": ("conv_igemm_split_kernel (implicit-GEMM conv, f32 operands as 3 bf16 planes, 6 bf16 MFMAs "
                                                      "per product; peak = bf16 dense peak / 6)" if args.precision == "f32x3" else
                                                      "conv_p32_kernel (implicit-GEMM conv, both operands as 2 pre-scaled fp16 planes moved by LDS-DMA, "

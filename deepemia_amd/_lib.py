@@ -144,6 +144,8 @@ EXPORTS = {
                                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "demia_mask_crop_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "demia_mask_gather_regions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "demia_mask_gather_regions_pooled": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                                    C.c_int, C.c_void_p]),
     "demia_mask_crop_unpack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "demia_mask_gray_histogram": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "demia_contour_work_ints": (C.c_int64, [C.c_int, C.c_int, C.c_int]),

@@ -365,6 +365,38 @@ __global__ __launch_bounds__(256) void gather_regions_kernel(const uint32_t* __r
     }
 }
 
+// The same gather into a POOL of planes that are known to be zero outside `prev` (the box the previous use of the slot could
+// have set): only the union of the slot's old box and the new one is written -- a few hundred words instead of a 512-KiB
+// plane -- and `prev` becomes the new box grown by `grow` pixels (what the in-place stages that follow may still set: a
+// dilation reaches one pixel beyond its input).  One block per slot.
+__global__ __launch_bounds__(256) void gather_regions_pooled_kernel(const uint32_t* __restrict__ src, const long* __restrict__ index,
+                                                                    const int* __restrict__ bbox, uint32_t* __restrict__ dst,
+                                                                    int* __restrict__ prev, int H, int W, int grow) {
+    const int m = blockIdx.x;
+    const int wpr = (W + 31) >> 5;
+    const int4 nb = reinterpret_cast<const int4*>(bbox)[m];       // y0, x0, y1, x1 (inclusive), -1: empty
+    const int4 pb = reinterpret_cast<const int4*>(prev)[m];
+    __syncthreads();                                              // every thread has read prev before thread 0 rewrites it
+    const bool has_n = nb.x >= 0, has_p = pb.x >= 0;
+    if (threadIdx.x == 0) {
+        int4 g = make_int4(-1, -1, -1, -1);
+        if (has_n) g = make_int4(max(nb.x - grow, 0), max(nb.y - grow, 0), min(nb.z + grow, H - 1), min(nb.w + grow, W - 1));
+        reinterpret_cast<int4*>(prev)[m] = g;
+    }
+    if (!has_n && !has_p) return;
+    const int ry0 = min(has_n ? nb.x : 1 << 30, has_p ? pb.x : 1 << 30), ry1 = max(has_n ? nb.z : -1, has_p ? pb.z : -1);
+    const int c0 = min(has_n ? nb.y >> 5 : 1 << 30, has_p ? pb.y >> 5 : 1 << 30), c1 = max(has_n ? nb.w >> 5 : -1, has_p ? pb.w >> 5 : -1);
+    const int nc0 = nb.y >> 5, nc1 = nb.w >> 5;
+    const uint32_t* sp = src + index[m] * (long)H * wpr;
+    uint32_t* dp = dst + (long)m * H * wpr;
+    const int cols = c1 - c0 + 1, rows = ry1 - ry0 + 1;
+    for (int t = threadIdx.x; t < rows * cols; t += blockDim.x) {
+        const int ry = ry0 + t / cols, cx = c0 + t % cols;
+        const bool in = has_n && ry >= nb.x && ry <= nb.z && cx >= nc0 && cx <= nc1;
+        dp[(long)ry * wpr + cx] = in ? sp[(long)ry * wpr + cx] : 0u;
+    }
+}
+
 inline int grid_for(long total, int block) {
     long g = (total + block - 1) / block;
     return (int)(g > 32768 ? 32768 : (g < 1 ? 1 : g));
@@ -519,6 +551,17 @@ extern "C" int demia_mask_gather_regions(const uint32_t* src, const int64_t* ind
     hipLaunchKernelGGL(gather_regions_kernel, dim3((unsigned)M, (unsigned)chunks), dim3(256), 0, (hipStream_t)stream, src,
                        reinterpret_cast<const long*>(index), bbox, dst, H, wpr, rows_per_block);
     DEMIA_CHECK_LAUNCH("gather_regions_kernel");
+    return DEMIA_OK;
+}
+
+extern "C" int demia_mask_gather_regions_pooled(const uint32_t* src, const int64_t* index, const int32_t* bbox, int64_t M, int H, int W,
+                                                uint32_t* pool, int32_t* prev, int grow, void* stream) {
+    DEMIA_REQUIRE(src && index && bbox && pool && prev && W > 0 && H > 0 && grow >= 0, "args");
+    if (M == 0) return DEMIA_OK;
+    DEMIA_REQUIRE(M <= 0x7fffffffL, "M");
+    hipLaunchKernelGGL(gather_regions_pooled_kernel, dim3((unsigned)M), dim3(256), 0, (hipStream_t)stream, src,
+                       reinterpret_cast<const long*>(index), bbox, pool, prev, H, W, grow);
+    DEMIA_CHECK_LAUNCH("gather_regions_pooled_kernel");
     return DEMIA_OK;
 }
 

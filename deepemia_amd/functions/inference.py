@@ -291,6 +291,10 @@ class InferencePipeline:
         self.graph_after = 2                                                   # ... from their second occurrence on
         self._shape_seen: Dict[tuple, int] = {}
         self.graph_slots, self.clone_graph_outputs = 1, True                  # (see forward_async)
+        # tile-batch loops that consume a batch's masks before the next batch is processed (bench.py) keep the intermediate
+        # and final mask sets in plane pools that stay zero outside per-slot boxes: a gather writes boxes, not 512-KiB planes.
+        # The planes a call returns are then views of a pool, valid until the next call.
+        self.pooled_planes = False
         self.last_batch_stats = None
         self.forward_calls = 0
         self.d2h_waits = 0                       # device-to-host waits of the post-processing (finish_forward + process_tile_batch)
@@ -791,13 +795,19 @@ class InferencePipeline:
             out.append((packed, scores, classes, recs))
         return out
 
-    def _gather_selected(self, dets: Sequence[_Detections], sels: Sequence[np.ndarray]):
+    def _gather_selected(self, dets: Sequence[_Detections], sels: Sequence[np.ndarray], pool_name: Optional[str] = None):
         """Our own copy of the selected masks of many detections sets (every later stage works on it in place) and
-        their bbox hints: ONE gather per run of sets that share a forward's table."""
+        their bbox hints: ONE gather per run of sets that share a forward's table.  ``pool_name`` (tile-batch loop with
+        ``pooled_planes``): the copy goes into that plane pool -- boxes written, not planes."""
         dev = self.dev
         lens = [len(x) for x in sels]
         T = len(dets)
-        packed = torch.empty((sum(lens),) + tuple(dets[0].packed.shape[1:]), dtype=dets[0].packed.dtype, device=dev)
+        pool = None
+        if pool_name is not None and self.pooled_planes and all(d.base is not None for d in dets):
+            pool = self.ops.pool(pool_name, sum(lens), int(dets[0].packed.shape[1]), int(dets[0].packed.shape[2]))
+            packed = pool.planes[:sum(lens)]
+        else:
+            packed = torch.empty((sum(lens),) + tuple(dets[0].packed.shape[1:]), dtype=dets[0].packed.dtype, device=dev)
         bbox = torch.empty((sum(lens), 4), dtype=torch.int32, device=dev)
         have_hint, pos, t = True, 0, 0
         while t < T:
@@ -808,9 +818,12 @@ class InferencePipeline:
                 gi = np.concatenate([dets[u].base_idx[sels[u]] for u in range(t, t1)])
                 if len(gi):
                     # the masks of a forward are zero outside their paste boxes: copy the boxes, write the planes once
-                    gt = torch.from_numpy(gi).to(dev)
+                    gt = self.ops.upload(gi)
                     torch.index_select(dets[t].base_bbox, 0, gt, out=bbox[pos:pos + len(gi)])
-                    self.ops.gather_regions(dets[t].base, gt, bbox[pos:pos + len(gi)], out=packed[pos:pos + len(gi)])
+                    if pool is not None:
+                        self.ops.gather_regions_pooled(dets[t].base, gt, bbox[pos:pos + len(gi)], pool, first=pos)
+                    else:
+                        self.ops.gather_regions(dets[t].base, gt, bbox[pos:pos + len(gi)], out=packed[pos:pos + len(gi)])
                 pos += len(gi)
                 t = t1
             else:
@@ -1097,7 +1110,9 @@ class InferencePipeline:
         if total == 0:
             return out
         # ---- what survives, gathered once per class into `allp` (class-major; a (class, tile) run is contiguous) -------
-        allp = torch.empty((total,) + tuple(passes[0][1].shape[1:]), dtype=passes[0][1].dtype, device=dev)
+        H_, wpr_ = int(passes[0][1].shape[1]), int(passes[0][1].shape[2])
+        apool = ops.pool("all", total, H_, wpr_) if self.pooled_planes else None
+        allp = apool.planes[:total] if apool is not None else torch.empty((total, H_, wpr_), dtype=passes[0][1].dtype, device=dev)
         tile_items: List[List[int]] = [[] for _ in range(T)]
         scores_all = np.zeros(total, dtype=np.float64)
         classes_all = np.zeros(total, dtype=np.int32)
@@ -1116,7 +1131,10 @@ class InferencePipeline:
                 run_count[p0:p0 + k] = k
                 p0 += k
             classes_all[off:off + len(src)] = cls
-            ops.gather_regions(big, src, calg.bbox[src], out=allp[off:off + len(src)])   # tight boxes of the class pass
+            if apool is not None:
+                ops.gather_regions_pooled(big, src, calg.bbox[src], apool, first=off, grow=0)
+            else:
+                ops.gather_regions(big, src, calg.bbox[src], out=allp[off:off + len(src)])   # tight boxes of the class pass
             area_parts.append(calg.area[src])
             bbox_parts.append(calg.bbox[src])
             off += len(src)
@@ -1162,7 +1180,10 @@ class InferencePipeline:
         flat = [i for gl in final_idx for i in gl]
         if not flat:
             return out
-        finalp = ops.gather_regions(allp, flat, bbox_all[flat])
+        if self.pooled_planes:
+            finalp = ops.gather_regions_pooled(allp, flat, bbox_all[flat], ops.pool("final", len(flat), H_, wpr_), grow=0)
+        else:
+            finalp = ops.gather_regions(allp, flat, bbox_all[flat])
         recs = cset.records(um_pix=um_pix, measure=True, select=flat)
         pos = 0
         self.last_batch_stats = [(area_all[final_idx[t]], bbox_all[final_idx[t]]) for t in range(T)]
@@ -1192,7 +1213,7 @@ class InferencePipeline:
         n = int(lens.sum())
         if n == 0:
             return None
-        packed, bbox = self._gather_selected(dets, sels)
+        packed, bbox = self._gather_selected(dets, sels, pool_name=f"class{target_class}")
         is_small = target_class in small_classes
         min_size = self.class_specific_settings.get(f"class_{target_class}", {}).get("min_size", 5 if is_small else 25)
         starts = np.concatenate(([0], np.cumsum(lens))).astype(np.int32)

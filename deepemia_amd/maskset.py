@@ -16,6 +16,20 @@ import torch
 from . import _lib
 
 
+class PlanePool:
+    """Mask planes that stay ZERO outside per-slot boxes (``demia_mask_gather_regions_pooled``): a gather into the pool
+    writes the union of a slot's previous box and its new one instead of whole 512-KiB planes.  The planes handed out are
+    views of the pool -- valid until the pool is used again (callers that keep masks longer take fresh planes)."""
+
+    def __init__(self, device, H: int, wpr: int, cap: int):
+        self.H, self.wpr, self.cap = int(H), int(wpr), int(cap)
+        self.planes = torch.zeros((self.cap, self.H, self.wpr), dtype=torch.int32, device=device)
+        self.prev = torch.full((self.cap, 4), -1, dtype=torch.int32, device=device)
+
+    def fits(self, n: int, H: int, wpr: int) -> bool:
+        return n <= self.cap and (H, wpr) == (self.H, self.wpr)
+
+
 class MaskOps:
     """Thin, stateless wrapper of the packed-mask entry points for one device."""
 
@@ -197,6 +211,30 @@ class MaskOps:
     def components_gt1(self, packed: torch.Tensor, bbox: Optional[torch.Tensor] = None) -> torch.Tensor:
         """``label(mask).max() > 1`` per mask (the masks are not changed)."""
         return self.program_(packed, ["flag_multi"], bbox)[2]
+
+    def pool(self, name: str, n: int, H: int, wpr: int) -> PlanePool:
+        """The named plane pool, (re)allocated when it is too small or of another frame size."""
+        pools = self.__dict__.setdefault("_pools", {})
+        p = pools.get(name)
+        if p is None or not p.fits(n, H, wpr):
+            pools.pop(name, None)
+            p = pools[name] = PlanePool(self.device, H, wpr, max(int(n * 1.25) + 64, 256))
+        return p
+
+    def gather_regions_pooled(self, src: torch.Tensor, index, bbox, pool: PlanePool, first: int = 0, grow: int = 2) -> torch.Tensor:
+        """``src[index]`` into slots ``first ..`` of ``pool`` (see :class:`PlanePool`); returns the view of those slots."""
+        idx = index if torch.is_tensor(index) else self.upload(np.asarray(index, dtype=np.int64))
+        idx = idx.to(device=self.device, dtype=torch.int64).contiguous()
+        bb = bbox if torch.is_tensor(bbox) else self.upload(np.ascontiguousarray(bbox, dtype=np.int32))
+        bb = bb.to(device=self.device, dtype=torch.int32).contiguous()
+        n = int(idx.shape[0])
+        _, H, wpr = src.shape
+        assert bb.shape == (n, 4) and src.is_contiguous() and src.dtype == torch.int32 and pool.fits(first + n, H, wpr)
+        out = pool.planes[first:first + n]
+        _lib.check(self.lib.demia_mask_gather_regions_pooled(_lib.ptr(src), _lib.ptr(idx), _lib.ptr(bb), n, H, self._w(src), _lib.ptr(out),
+                                                             _lib.ptr(pool.prev[first:first + n]), int(grow), self._stream()),
+                   "demia_mask_gather_regions_pooled")
+        return out
 
     def gather_regions(self, src: torch.Tensor, index, bbox, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """``src[index]`` for masks that are zero outside ``bbox`` (a superset of their tight boxes; -1 = empty): reads the

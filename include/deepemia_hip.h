@@ -385,6 +385,12 @@ int demia_mask_crop_pack(const uint32_t* masks, const int32_t* bbox, const int64
  * outside the box).  index [M] i64 into src [*, H, W/32]; bbox [M, 4] (-1: empty -> a zero plane); dst [M, H, W/32]. */
 int demia_mask_gather_regions(const uint32_t* src, const int64_t* index, const int32_t* bbox, int64_t M, int H, int W,
                               uint32_t* dst, void* stream);
+/* The same gather into a POOL of planes that stay zero outside per-slot boxes: pool [>= M, H, W/32] zeroed once, prev [>= M, 4]
+ * i32 initialised to -1.  Slot m receives src[index[m]] (zero outside bbox[m]); only the union of prev[m] and bbox[m] is
+ * written, and prev[m] becomes bbox[m] grown by `grow` pixels -- the reach of the in-place stages that follow (a dilation:
+ * 1).  For callers that consume a batch's planes before the pool comes round again (the tile-batch loop). */
+int demia_mask_gather_regions_pooled(const uint32_t* src, const int64_t* index, const int32_t* bbox, int64_t M, int H, int W,
+                                     uint32_t* pool, int32_t* prev, int grow, void* stream);
 int demia_mask_crop_unpack(const uint32_t* payload, const int32_t* bbox, const int64_t* offsets, int64_t M, int H, int W,
                            uint32_t* masks, void* stream);
 

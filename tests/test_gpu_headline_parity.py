@@ -89,3 +89,34 @@ def test_f16x2_forward_is_batch_invariant(env):
         assert torch.equal(one.scores[0, :n], full.scores[i, :n])
         assert torch.equal(one.boxes[0, :n], full.boxes[i, :n])
         assert torch.equal(one.packed[0, :n], full.packed[i, :n])
+
+
+def test_plane_pools_give_the_same_tiles_as_fresh_planes(env):
+    """``pooled_planes`` (bench.py's tile-batch loop): the class-pass, cross-class and final mask sets live in pools that stay
+    zero outside per-slot boxes, so a gather writes boxes instead of planes.  Three consecutive batches of DIFFERENT tiles
+    (different instance counts and boxes per slot, so every slot sees stale boxes of another instance) must give the bits the
+    fresh-plane path gives."""
+    pipe, dev, synth = env["pipe"], env["dev"], env["synth"]
+    batches = [torch.from_numpy(np.stack([synth.em_tile(i, 2048) for i in idx])).to(dev) for idx in ((0, 1, 2), (5, 3), (4, 0, 6))]
+    batches[1][1] = 0                                        # a tile with (next to) nothing on it: slots fall empty
+    want = []
+    for b, x in enumerate(batches):
+        res = pipe.process_tile_batch(f"fresh{b}", x, SMALL, CLASS_THRESHOLDS, um_pix=0.5)
+        want.append([(None if p is None else p.clone(), s, c, r) for p, s, c, r in res])
+    pipe.pooled_planes = True
+    try:
+        for b, x in enumerate(batches):
+            got = pipe.process_tile_batch(f"pool{b}", x, SMALL, CLASS_THRESHOLDS, um_pix=0.5)
+            assert len(got) == len(want[b])
+            for (pa, sa, ca, ra), (pb, sb, cb, rb) in zip(got, want[b]):
+                assert (pa is None) == (pb is None)
+                if pa is not None:
+                    assert torch.equal(pa, pb)
+                assert [float(v) for v in sa] == [float(v) for v in sb] and list(ca) == list(cb)
+                for ia, ib in zip(ra or [], rb or []):
+                    assert len(ia) == len(ib)
+                    for u, v in zip(ia, ib):
+                        assert np.array_equal(u["points"], v["points"]) and u["area"] == v["area"] and np.array_equal(u["values"], v["values"])
+        assert any(p is not None and p.shape[0] > 10 for p, *_ in want[0])
+    finally:
+        pipe.pooled_planes = False
