@@ -171,29 +171,74 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiP p) {
         }
         __syncthreads();
         if (!lane_on) return;
-        for (int bin = wave; bin < PP; bin += 4) {
-            const int ph = bin / p.P, pw = bin - ph * p.P;
-            const int y0 = s_lo[0][ph], ny = s_n[0][ph], x0 = s_lo[1][pw], nx = s_n[1][pw];
-            float acc[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int yy = 0; yy < ny; ++yy) {
-                const float wy = s_w[0][ph * 8 + yy];
-                const char* rowp = feat + ((long)(y0 + yy) * W + x0) * pixb;
-                float t[4] = {0.f, 0.f, 0.f, 0.f};
-                for (int xx = 0; xx < nx; ++xx) {
-                    const float wx = s_w[1][pw * 8 + xx];
-                    float v[4];
-                    A::load(rowp + (long)xx * pixb, inv_s, v);
+        // A wave walks a PAIR of neighbouring bin columns top to bottom.  Neighbouring bins share feature pixels: down a column
+        // the last row of bin ph is the first of bin ph + 1 (bins less than a pixel high share both), and a row's x-combination
+        // t = sum_x Wx[x] f[y][x] does not depend on ph -- the two rows combined last are kept, so a column reads g rows per
+        // bin instead of g + 1; across the pair the last pixel column of the left bin is the first of the right one (adjacent
+        // samples are at most a pixel apart: the union of the two ranges has no gap) -- a row's pixels are loaded once for
+        // both, each column taking its own weights (0 outside its range: t + 0 v = t).  Every value sees the same operations in
+        // the same order as in the bin-by-bin walk (same bits: checksums of both outputs on the boxes of a 48-tile forward,
+        // scripts/gpu_roi_ab.py): 7x7 2190 -> 1825 (row cache) -> 1717 us, 14x14 820 -> 596 -> 531 us.
+        for (int pa = 2 * wave; pa < p.P; pa += 8) {
+            const bool two = pa + 1 < p.P;
+            const int xa0 = s_lo[1][pa], nxa = s_n[1][pa];
+            const int xb0 = two ? s_lo[1][pa + 1] : 0, nxb = two ? s_n[1][pa + 1] : 0;
+            const int ux0 = nxa > 0 ? (nxb > 0 ? min(xa0, xb0) : xa0) : xb0;
+            const int ux1 = max(nxa > 0 ? xa0 + nxa : 0, nxb > 0 ? xb0 + nxb : 0);       // (both empty: no pixel is read)
+            const int nu = (nxa > 0 || nxb > 0) ? ux1 - ux0 : 0;
+            int ya = -1, yb = -1;
+            float ta[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, tb[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            for (int ph = 0; ph < p.P; ++ph) {
+                const int y0 = s_lo[0][ph], ny = s_n[0][ph];
+                float acc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+                for (int yy = 0; yy < ny; ++yy) {
+                    const float wy = s_w[0][ph * 8 + yy];
+                    const int y = y0 + yy;
+                    if (y == ya) {                         // (wave-uniform branches)
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) t[c] += wx * v[c];
+                        for (int k = 0; k < 2; ++k)
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) { const float u = ta[k][c]; ta[k][c] = tb[k][c]; tb[k][c] = u; }
+                        ya = yb;
+                        yb = y;
+                    } else if (y != yb) {
+                        const char* rowp = feat + ((long)y * W + ux0) * pixb;
+                        float t[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+                        for (int xx = 0; xx < nu; ++xx) {
+                            const int ia = ux0 + xx - xa0, ib = ux0 + xx - xb0;
+                            const float wa = (unsigned)ia < (unsigned)nxa ? s_w[1][pa * 8 + ia] : 0.f;
+                            const float wb = (unsigned)ib < (unsigned)nxb ? s_w[1][(pa + 1) * 8 + ib] : 0.f;
+                            float v[4];
+                            A::load(rowp + (long)xx * pixb, inv_s, v);
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                t[0][c] += wa * v[c];
+                                t[1][c] += wb * v[c];
+                            }
+                        }
+#pragma unroll
+                        for (int k = 0; k < 2; ++k)
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) { ta[k][c] = tb[k][c]; tb[k][c] = t[k][c]; }
+                        ya = yb;
+                        yb = y;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 2; ++k)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) acc[k][c] += wy * tb[k][c];
                 }
 #pragma unroll
-                for (int c = 0; c < 4; ++c) acc[c] += wy * t[c];
-            }
-            float o[4];
+                for (int k = 0; k < 2; ++k) {
+                    if (k == 1 && !two) break;
+                    float o[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) o[c] = acc[c] / cnt;
-            A::store(out0 + (long)bin * pixb, s_out, o);
-            if (P32 && p.single) *reinterpret_cast<uint2*>(out0 + (long)bin * pixb + 64) = make_uint2(0u, 0u);
+                    for (int c = 0; c < 4; ++c) o[c] = acc[k][c] / cnt;
+                    const long bin = (long)ph * p.P + pa + k;
+                    A::store(out0 + bin * pixb, s_out, o);
+                    if (P32 && p.single) *reinterpret_cast<uint2*>(out0 + bin * pixb + 64) = make_uint2(0u, 0u);
+                }
+            }
         }
         return;
     }

@@ -25,3 +25,8 @@ for _ in range(2):
     a = t(lambda: eng.roi_align(feats, props, pcount, 7))
     b = t(lambda: eng.roi_align(feats, det_boxes, det_count, 14))
     print(os.environ.get('AB_LIB', 'default'), f'B={B} 7x7 {a*1e3:.0f} us  14x14 {b*1e3:.0f} us', flush=True)
+# checksums of the two outputs (planes as int16 words): the same for two libraries that compute the same bits
+for P_, bx, ct in ((7, props, pcount), (14, det_boxes, det_count)):
+    o = eng.roi_align(feats, bx, ct, P_).buf
+    w = o.view(torch.int16).to(torch.int64)
+    print(f'checksum {P_}x{P_}:', int(w.sum()), int((w * (torch.arange(w.numel(), device=w.device) % 8191)).sum()), flush=True)
