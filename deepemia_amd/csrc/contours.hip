@@ -210,7 +210,7 @@ struct ContourP {
 // never meets a pixel that precedes its start in raster order, i.e. iff it is where OpenCV's raster scan starts
 // that border; valid ones are walked a second time to emit their points.
 template <int TW, int CM>
-__global__ __launch_bounds__(256) void contour_trace_kernel(const ContourP p) {
+__device__ void contour_trace_one(const ContourP& p, const int m, int* __restrict__ worklist) {
     constexpr bool SMALL = TW != TRACE_WORDS;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t* regA = smem;                              // TW
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void contour_trace_kernel(const ContourP p) {
     int* cand = reinterpret_cast<int*>(smem + 2 * TW);  // CM
     __shared__ int ncand, ncont, s_changed, first_cand;
     __shared__ Walkers wk;
-    const int m = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int tid = threadIdx.x, nt = blockDim.x;
     const int wpr = (p.W + 31) >> 5;
     const int y0 = p.bbox[m * 4 + 0], x0 = p.bbox[m * 4 + 1], y1 = p.bbox[m * 4 + 2], x1 = p.bbox[m * 4 + 3];
     if (y0 < 0) { if (tid == 0 && SMALL) p.count[m] = 0; return; }
@@ -226,7 +226,10 @@ __global__ __launch_bounds__(256) void contour_trace_kernel(const ContourP p) {
     g.H = p.H; g.W = p.W; g.wpr = wpr;
     mreg::region_of(y0, x0, y1, x1, 1, p.H, p.W, g.ry0, g.wx0, g.rh, g.rw);
     const int ps = g.rw + 2, pn = (g.rh + 2) * ps;      // padded LDS image
-    if (SMALL ? pn > TW : (pn <= TRACE_WORDS_SMALL && p.count[m] != -1)) return;    // the other variant's mask
+    if (SMALL ? pn > TW : (pn <= TRACE_WORDS_SMALL && p.count[m] != -1)) {           // the other variant's mask
+        if (SMALL && worklist && tid == 0) worklist[2 + atomicAdd(&worklist[0], 1)] = m;
+        return;
+    }
     if (tid == 0) { ncand = 0; ncont = 0; first_cand = 0x7FFFFFFF; wk.K = 0; wk.fail = 0; }
     const int n = g.rh * g.rw;
     const bool use_lds = pn <= TW;
@@ -276,7 +279,10 @@ __global__ __launch_bounds__(256) void contour_trace_kernel(const ContourP p) {
     __syncthreads();
     if (ncand > CM) {
         if (tid == 0) {
-            if (SMALL) p.count[m] = -1;                       // more candidates than this variant holds: the large one takes it
+            if (SMALL) {                                      // more candidates than this variant holds: the large one takes it
+                p.count[m] = -1;
+                if (worklist) worklist[2 + atomicAdd(&worklist[0], 1)] = m;
+            }
             else { atomicOr(&p.counters[1], 1); p.count[m] = 0; }
         }
         return;
@@ -404,6 +410,29 @@ __global__ __launch_bounds__(256) void contour_trace_kernel(const ContourP p) {
     }
     __syncthreads();
     if (tid == 0) p.count[m] = ncont < p.C ? ncont : p.C;
+}
+
+// One workgroup per mask; `worklist` (optional, SMALL variant): the masks it leaves to the large variant are appended to
+// worklist[2 ..] (count in worklist[0]).
+template <int TW, int CM>
+__global__ __launch_bounds__(256) void contour_trace_kernel(const ContourP p, int* __restrict__ worklist) {
+    contour_trace_one<TW, CM>(p, blockIdx.x, worklist);
+}
+
+// The large variant over that list: a fixed grid, every workgroup takes the next listed mask until the list is empty
+// (as mask_program_list_kernel in maskops.hip: one 78-KiB workgroup per MASK mostly found out that its mask was small).
+template <int TW, int CM>
+__global__ __launch_bounds__(256) void contour_trace_list_kernel(const ContourP p, int* __restrict__ worklist) {
+    __shared__ int s_next;
+    const int count = worklist[0];
+    for (;;) {
+        if (threadIdx.x == 0) s_next = atomicAdd(&worklist[1], 1);
+        __syncthreads();
+        const int i = s_next;
+        if (i >= count) break;                               // (block-uniform; every workgroup gets here)
+        contour_trace_one<TW, CM>(p, worklist[2 + i], nullptr);
+        __syncthreads();
+    }
 }
 
 // =============================================================================================
@@ -926,28 +955,43 @@ extern "C" int64_t demia_contour_work_ints(int M, int C, int max_points) { retur
 extern "C" int64_t demia_contour_work_floats(int M, int C, int max_points) { return 5L * max_points + 16L * M * C + 16; }
 extern "C" int64_t demia_contour_work_doubles(int M, int C, int max_points) { return 5L * max_points + 8L * M * C + 16; }
 
-extern "C" int demia_mask_contours(const uint32_t* masks, uint32_t* scratch, const int32_t* bbox, int M, int H, int W, int C,
-                                   int max_points, int32_t* count, int32_t* info, double* red, int32_t* points,
-                                   int32_t* counters, void* stream) {
+extern "C" int demia_mask_contours_wl(const uint32_t* masks, uint32_t* scratch, const int32_t* bbox, int M, int H, int W, int C,
+                                      int max_points, int32_t* count, int32_t* info, double* red, int32_t* points,
+                                      int32_t* counters, int32_t* worklist, void* stream) {
     DEMIA_REQUIRE(masks && scratch && bbox && count && info && red && points && counters && W > 0, "args");
     DEMIA_REQUIRE((long)H * W < (1L << 31) && C > 0 && max_points > 0, "sizes");
     if (M == 0) return DEMIA_OK;
-    hipError_t e = hipMemsetAsync(counters, 0, 4 * sizeof(int32_t), (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(counters, 0, 4 * sizeof(int32_t), st);
+    if (e == hipSuccess && worklist) e = hipMemsetAsync(worklist, 0, 2 * sizeof(int32_t), st);
     if (e != hipSuccess) { demia_set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return DEMIA_ELAUNCH; }
     constexpr int smem = (2 * TRACE_WORDS + CAND_MAX) * 4, smem_small = (2 * TRACE_WORDS_SMALL + CAND_SMALL) * 4;
     auto k_small = contour_trace_kernel<TRACE_WORDS_SMALL, CAND_SMALL>;
     auto k_large = contour_trace_kernel<TRACE_WORDS, CAND_MAX>;
+    auto k_list = contour_trace_list_kernel<TRACE_WORDS, CAND_MAX>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_large), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_list), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_done = true;
     }
     ContourP p{masks, scratch, bbox, M, H, W, C, max_points, count, info, red, points, counters};
-    hipLaunchKernelGGL(k_small, dim3(M), dim3(256), smem_small, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(k_small, dim3(M), dim3(256), smem_small, st, p, worklist);
     DEMIA_CHECK_LAUNCH("contour_trace_kernel<small>");
-    hipLaunchKernelGGL(k_large, dim3(M), dim3(256), smem, (hipStream_t)stream, p);
-    DEMIA_CHECK_LAUNCH("contour_trace_kernel<large>");
+    if (worklist) {
+        hipLaunchKernelGGL(k_list, dim3(M < 512 ? M : 512), dim3(256), smem, st, p, worklist);     // two 78-KiB workgroups per CU
+        DEMIA_CHECK_LAUNCH("contour_trace_list_kernel<large>");
+    } else {
+        hipLaunchKernelGGL(k_large, dim3(M), dim3(256), smem, st, p, (int*)nullptr);
+        DEMIA_CHECK_LAUNCH("contour_trace_kernel<large>");
+    }
     return DEMIA_OK;
+}
+
+extern "C" int demia_mask_contours(const uint32_t* masks, uint32_t* scratch, const int32_t* bbox, int M, int H, int W, int C,
+                                   int max_points, int32_t* count, int32_t* info, double* red, int32_t* points,
+                                   int32_t* counters, void* stream) {
+    return demia_mask_contours_wl(masks, scratch, bbox, M, H, W, C, max_points, count, info, red, points, counters, nullptr, stream);
 }
 
 extern "C" int demia_contour_measure(const int32_t* select, const int32_t* count, const int32_t* info, const double* red,

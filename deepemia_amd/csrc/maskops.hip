@@ -41,11 +41,11 @@ struct ProgP {
     int* flag;
 };
 
-template <int RW, int NT>
-__global__ __launch_bounds__(NT) void mask_program_kernel(const ProgP p, const int lo) {
-    __shared__ uint32_t lds[2 * RW];
-    __shared__ int s_changed, s_first, s_area, s_y0, s_y1, s_x0, s_x1;
-    const long m = blockIdx.x;
+// One mask through the program; every thread of the block calls it (block-uniform control flow).  `lo` / RW as in the
+// kernels below.  Returns true when mask m belongs to a LARGER variant than this one (n > RW and RW is not the largest).
+template <int RW>
+__device__ __forceinline__ bool run_mask_program(const ProgP& p, const long m, const int lo, uint32_t* lds, int* s_changed, int* s_first, int* s_area,
+                                                 int* s_y0, int* s_y1, int* s_x0, int* s_x1) {
     const int tid = threadIdx.x, nt = blockDim.x;
     const int wpr = (p.W + 31) >> 5;
     int cy0 = p.bbox[m * 4 + 0], cx0 = p.bbox[m * 4 + 1], cy1 = p.bbox[m * 4 + 2], cx1 = p.bbox[m * 4 + 3];
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(NT) void mask_program_kernel(const ProgP p, const i
             if (p.bbox_out) { p.bbox_out[m * 4 + 0] = -1; p.bbox_out[m * 4 + 1] = -1; p.bbox_out[m * 4 + 2] = -1; p.bbox_out[m * 4 + 3] = -1; }
             if (p.flag) p.flag[m] = 0;
         }
-        return;
+        return false;
     }
     int ndil = 0;
     for (uint32_t q = p.program; q; q >>= 4) ndil += (q & 15u) == DEMIA_MOP_DILATE;
@@ -63,7 +63,8 @@ __global__ __launch_bounds__(NT) void mask_program_kernel(const ProgP p, const i
     g.H = p.H; g.W = p.W; g.wpr = wpr;
     mreg::region_of(cy0, cx0, cy1, cx1, ndil + 1, p.H, p.W, g.ry0, g.wx0, g.rh, g.rw);
     const int n = g.rh * g.rw;
-    if (n <= lo || (n > RW && RW != REG_WORDS)) return;       // the other variant's mask
+    if (n <= lo) return false;                                // a smaller variant's mask
+    if (n > RW && RW != REG_WORDS) return true;               // a larger variant's mask
     const bool use_lds = n <= RW;
     uint32_t* home = p.masks + m * (long)p.H * wpr + (long)g.ry0 * wpr + g.wx0;
     if (use_lds) {
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(NT) void mask_program_kernel(const ProgP p, const i
     for (uint32_t q = p.program; q; q >>= 4) {
         const uint32_t op = q & 15u;
         if (op == DEMIA_MOP_FILL) {
-            mreg::fill_holes(g, cy0, cx0, cy1, cx1, &s_changed);
+            mreg::fill_holes(g, cy0, cx0, cy1, cx1, s_changed);
         } else if (op == DEMIA_MOP_DILATE || op == DEMIA_MOP_ERODE) {
             if (op == DEMIA_MOP_DILATE) {
                 mreg::morph_cross<true>(g);
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(NT) void mask_program_kernel(const ProgP p, const i
             }
             uint32_t* t = g.A; g.A = g.B; g.B = t;
         } else if (op == DEMIA_MOP_DROP_MULTI || op == DEMIA_MOP_FLAG_MULTI) {
-            const bool multi = mreg::more_than_one_component(g, cy0, cx0, cy1, cx1, &s_first, &s_changed);
+            const bool multi = mreg::more_than_one_component(g, cy0, cx0, cy1, cx1, s_first, s_changed);
             flagged |= multi;
             if (multi && op == DEMIA_MOP_DROP_MULTI) {
                 for (int i = tid; i < n; i += nt) g.A[(i / g.rw) * g.stride + i % g.rw] = 0u;
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(NT) void mask_program_kernel(const ProgP p, const i
         }
     }
     // ---- write back + area / tight bbox -------------------------------------------------------------------
-    if (tid == 0) { s_area = 0; s_y0 = 1 << 30; s_x0 = 1 << 30; s_y1 = -1; s_x1 = -1; }
+    if (tid == 0) { *s_area = 0; *s_y0 = 1 << 30; *s_x0 = 1 << 30; *s_y1 = -1; *s_x1 = -1; }
     __syncthreads();
     int a = 0, y0 = 1 << 30, y1 = -1, x0 = 1 << 30, x1 = -1;
     const bool copy = g.A != home;
@@ -120,19 +121,50 @@ __global__ __launch_bounds__(NT) void mask_program_kernel(const ProgP p, const i
         y1 = max(y1, __shfl_down(y1, o, 64)); x1 = max(x1, __shfl_down(x1, o, 64));
     }
     if ((tid & 63) == 0 && a) {
-        atomicAdd(&s_area, a);
-        atomicMin(&s_y0, y0); atomicMin(&s_x0, x0);
-        atomicMax(&s_y1, y1); atomicMax(&s_x1, x1);
+        atomicAdd(s_area, a);
+        atomicMin(s_y0, y0); atomicMin(s_x0, x0);
+        atomicMax(s_y1, y1); atomicMax(s_x1, x1);
     }
     __syncthreads();
     if (tid == 0) {
-        const bool e = s_area == 0;
-        if (p.area) p.area[m] = s_area;
+        const bool e = *s_area == 0;
+        if (p.area) p.area[m] = *s_area;
         if (p.bbox_out) {
-            p.bbox_out[m * 4 + 0] = e ? -1 : s_y0; p.bbox_out[m * 4 + 1] = e ? -1 : s_x0;
-            p.bbox_out[m * 4 + 2] = e ? -1 : s_y1; p.bbox_out[m * 4 + 3] = e ? -1 : s_x1;
+            p.bbox_out[m * 4 + 0] = e ? -1 : *s_y0; p.bbox_out[m * 4 + 1] = e ? -1 : *s_x0;
+            p.bbox_out[m * 4 + 2] = e ? -1 : *s_y1; p.bbox_out[m * 4 + 3] = e ? -1 : *s_x1;
         }
         if (p.flag) p.flag[m] = flagged;
+    }
+    return false;
+}
+
+// One workgroup per mask.  `worklist` (optional, the SMALL variant only): masks that need the large variant are appended to
+// worklist[2 ..] (count in worklist[0]) instead of being found again by a second launch over all masks.
+template <int RW, int NT>
+__global__ __launch_bounds__(NT) void mask_program_kernel(const ProgP p, const int lo, int* __restrict__ worklist) {
+    __shared__ uint32_t lds[2 * RW];
+    __shared__ int s_changed, s_first, s_area, s_y0, s_y1, s_x0, s_x1;
+    const long m = blockIdx.x;
+    const bool larger = run_mask_program<RW>(p, m, lo, lds, &s_changed, &s_first, &s_area, &s_y0, &s_y1, &s_x0, &s_x1);
+    if (larger && worklist && threadIdx.x == 0) worklist[2 + atomicAdd(&worklist[0], 1)] = (int)m;
+}
+
+// The large variant over a worklist: a fixed grid whose workgroups take the next listed mask until the list is empty (the
+// list is complete: the small variant ran before this kernel on the same stream).  Three of four masks of a real batch are
+// small -- a launch of one 64-KiB-LDS workgroup per MASK spent most of its workgroups finding that out, each waiting for a
+// CU with 64 KiB to spare beside the convolution workgroups of the other stream.
+template <int RW, int NT>
+__global__ __launch_bounds__(NT) void mask_program_list_kernel(const ProgP p, const int lo, int* __restrict__ worklist) {
+    __shared__ uint32_t lds[2 * RW];
+    __shared__ int s_changed, s_first, s_area, s_y0, s_y1, s_x0, s_x1, s_next;
+    const int count = worklist[0];
+    for (;;) {
+        if (threadIdx.x == 0) s_next = atomicAdd(&worklist[1], 1);
+        __syncthreads();
+        const int i = s_next;
+        if (i >= count) break;                                 // (block-uniform; every workgroup gets here)
+        run_mask_program<RW>(p, worklist[2 + i], lo, lds, &s_changed, &s_first, &s_area, &s_y0, &s_y1, &s_x0, &s_x1);
+        __syncthreads();
     }
 }
 
@@ -443,17 +475,33 @@ __global__ __launch_bounds__(256) void gray_hist_kernel(const uint32_t* __restri
 
 }  // namespace
 
-extern "C" int demia_mask_program(uint32_t* masks, uint32_t* scratch, const int32_t* bbox, const uint8_t* active, uint32_t program,
-                                  int64_t M, int H, int W, int32_t* area, int32_t* bbox_out, int32_t* flag, void* stream) {
+extern "C" int demia_mask_program_wl(uint32_t* masks, uint32_t* scratch, const int32_t* bbox, const uint8_t* active, uint32_t program,
+                                     int64_t M, int H, int W, int32_t* area, int32_t* bbox_out, int32_t* flag, int32_t* worklist, void* stream) {
     DEMIA_REQUIRE(masks && scratch && bbox && masks != scratch && W > 0 && H > 0, "args");
     for (uint32_t q = program; q; q >>= 4) DEMIA_REQUIRE((q & 15u) <= DEMIA_MOP_GATE, "unknown stage code");
     if (M == 0) return DEMIA_OK;
+    DEMIA_REQUIRE(M <= 0x7ffffff0L, "M");
     ProgP p{masks, scratch, bbox, active, program, H, W, area, bbox_out, flag};
-    hipLaunchKernelGGL((mask_program_kernel<REG_WORDS_SMALL, 256>), dim3((int)M), dim3(256), 0, (hipStream_t)stream, p, 0);
+    hipStream_t st = (hipStream_t)stream;
+    if (worklist) {
+        if (hipMemsetAsync(worklist, 0, 2 * sizeof(int32_t), st) != hipSuccess) { demia_set_error("demia_mask_program: hipMemsetAsync failed"); return DEMIA_ELAUNCH; }
+    }
+    hipLaunchKernelGGL((mask_program_kernel<REG_WORDS_SMALL, 256>), dim3((int)M), dim3(256), 0, st, p, 0, worklist);
     DEMIA_CHECK_LAUNCH("mask_program_kernel<small>");
-    hipLaunchKernelGGL((mask_program_kernel<REG_WORDS, 512>), dim3((int)M), dim3(512), 0, (hipStream_t)stream, p, REG_WORDS_SMALL);
-    DEMIA_CHECK_LAUNCH("mask_program_kernel<large>");
+    if (worklist) {
+        const int grid = (int)(M < 512 ? M : 512);            // two 64-KiB workgroups per CU
+        hipLaunchKernelGGL((mask_program_list_kernel<REG_WORDS, 512>), dim3(grid), dim3(512), 0, st, p, REG_WORDS_SMALL, worklist);
+        DEMIA_CHECK_LAUNCH("mask_program_list_kernel<large>");
+    } else {
+        hipLaunchKernelGGL((mask_program_kernel<REG_WORDS, 512>), dim3((int)M), dim3(512), 0, st, p, REG_WORDS_SMALL, (int*)nullptr);
+        DEMIA_CHECK_LAUNCH("mask_program_kernel<large>");
+    }
     return DEMIA_OK;
+}
+
+extern "C" int demia_mask_program(uint32_t* masks, uint32_t* scratch, const int32_t* bbox, const uint8_t* active, uint32_t program,
+                                  int64_t M, int H, int W, int32_t* area, int32_t* bbox_out, int32_t* flag, void* stream) {
+    return demia_mask_program_wl(masks, scratch, bbox, active, program, M, H, W, area, bbox_out, flag, nullptr, stream);
 }
 
 extern "C" int demia_mask_overlap_prefix(uint32_t* masks, const int32_t* seg, const int32_t* bbox, int64_t M, int H, int W,

@@ -10,10 +10,15 @@ from __future__ import annotations
 
 from typing import List, Optional, Sequence, Tuple
 
+import os
 import numpy as np
 import torch
 
 from . import _lib
+
+
+# (A/B switch) 0: the large-region variants of the per-mask kernels run over all masks again instead of over a worklist
+_WORKLISTS = os.environ.get("DEEPEMIA_MASK_WORKLISTS", "1") != "0"
 
 
 class PlanePool:
@@ -181,9 +186,10 @@ class MaskOps:
         bbox_out = torch.empty((M, 4), dtype=torch.int32, device=self.device)
         flag = torch.empty((M,), dtype=torch.int32, device=self.device)
         scratch = torch.empty_like(packed)       # only touched by regions that do not fit in LDS
-        _lib.check(self.lib.demia_mask_program(_lib.ptr(packed), _lib.ptr(scratch), _lib.ptr(bbox), _lib.ptr(active), prog, M, H,
-                                               self._w(packed), _lib.ptr(area), _lib.ptr(bbox_out), _lib.ptr(flag),
-                                               self._stream()), "demia_mask_program")
+        worklist = torch.empty((M + 2,), dtype=torch.int32, device=self.device) if _WORKLISTS else None    # masks for the large-region variant
+        _lib.check(self.lib.demia_mask_program_wl(_lib.ptr(packed), _lib.ptr(scratch), _lib.ptr(bbox), _lib.ptr(active), prog, M, H,
+                                                  self._w(packed), _lib.ptr(area), _lib.ptr(bbox_out), _lib.ptr(flag),
+                                                  _lib.ptr(worklist), self._stream()), "demia_mask_program_wl")
         return area, bbox_out, flag
 
     def fill_holes(self, packed: torch.Tensor, bbox: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -282,9 +288,10 @@ class MaskOps:
         C = max_contours
         cs = ContourSet(self, M, C, max_points)
         scratch = torch.empty_like(packed)       # only touched by regions that do not fit in LDS
-        _lib.check(self.lib.demia_mask_contours(_lib.ptr(packed), _lib.ptr(scratch), _lib.ptr(bbox), M, H, W, C, max_points,
-                                                _lib.ptr(cs.count), _lib.ptr(cs.info), _lib.ptr(cs.red), _lib.ptr(cs.points),
-                                                _lib.ptr(cs.counters), self._stream()), "demia_mask_contours")
+        worklist = torch.empty((M + 2,), dtype=torch.int32, device=self.device) if _WORKLISTS else None    # masks for the large-region variant
+        _lib.check(self.lib.demia_mask_contours_wl(_lib.ptr(packed), _lib.ptr(scratch), _lib.ptr(bbox), M, H, W, C, max_points,
+                                                   _lib.ptr(cs.count), _lib.ptr(cs.info), _lib.ptr(cs.red), _lib.ptr(cs.points),
+                                                   _lib.ptr(cs.counters), _lib.ptr(worklist), self._stream()), "demia_mask_contours_wl")
         return cs
 
     def contours(self, packed: torch.Tensor, max_contours: int = 64, max_points: Optional[int] = None,

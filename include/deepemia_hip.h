@@ -344,6 +344,11 @@ enum { DEMIA_MOP_END = 0, DEMIA_MOP_FILL = 1, DEMIA_MOP_DILATE = 2, DEMIA_MOP_ER
        DEMIA_MOP_FLAG_MULTI = 5, DEMIA_MOP_GATE = 6 };
 int demia_mask_program(uint32_t* masks, uint32_t* scratch, const int32_t* bbox, const uint8_t* active, uint32_t program,
                        int64_t M, int H, int W, int32_t* area, int32_t* bbox_out, int32_t* flag, void* stream);
+/* The same with a WORKLIST [M + 2] i32 (device, contents ignored on entry): the launch over all masks handles the small
+ * regions and lists the masks that need the 64-KiB-LDS variant, which then runs as a fixed grid over that list instead of
+ * one workgroup per mask (three of four masks of a real batch are small).  worklist == NULL: demia_mask_program. */
+int demia_mask_program_wl(uint32_t* masks, uint32_t* scratch, const int32_t* bbox, const uint8_t* active, uint32_t program,
+                          int64_t M, int H, int W, int32_t* area, int32_t* bbox_out, int32_t* flag, int32_t* worklist, void* stream);
 int demia_mask_overlap_prefix(uint32_t* masks, const int32_t* seg, const int32_t* bbox, int64_t M, int H, int W, void* stream);
 int demia_mask_column_counts(const uint32_t* masks, const int32_t* seg, const int32_t* bbox, int64_t M, int H, int W,
                              int32_t* counts, void* stream);
@@ -425,6 +430,11 @@ int64_t demia_contour_work_doubles(int M, int C, int max_points);
 int demia_mask_contours(const uint32_t* masks, uint32_t* scratch, const int32_t* bbox, int M, int H, int W, int C,
                         int max_points, int32_t* count, int32_t* info, double* red, int32_t* points,
                         int32_t* counters, void* stream);
+/* The same with a WORKLIST [M + 2] i32 (device, contents ignored on entry), as demia_mask_program_wl: the large-region variant
+ * runs over the masks the small one listed instead of over all M.  worklist == NULL: demia_mask_contours. */
+int demia_mask_contours_wl(const uint32_t* masks, uint32_t* scratch, const int32_t* bbox, int M, int H, int W, int C,
+                           int max_points, int32_t* count, int32_t* info, double* red, int32_t* points,
+                           int32_t* counters, int32_t* worklist, void* stream);
 int demia_contour_measure(const int32_t* select /* [M] or NULL */, const int32_t* count, const int32_t* info,
                           const double* red, const int32_t* points, int M,
                           int C, int max_points, int32_t* work_i, float* work_f, double* work_d, double um_pix,
