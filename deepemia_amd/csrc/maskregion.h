@@ -69,6 +69,49 @@ __device__ void flood(const uint32_t* P, uint32_t inv, uint32_t* R, int stride, 
         if (threadIdx.x == 0) *s_changed = 0;
         __syncthreads();
         bool ch = false;
+        if (rw <= 64) {
+            // The usual region (at most 64 words = 2048 pixels wide): lane = word, and the row the sweep has just left is the
+            // value the lane computed a step ago -- it stays in a register (its left / right neighbours for the diagonal
+            // links come by lane shuffle), the next row's words are requested before this row's front is worked out, and
+            // no fence is needed between row steps: a step reads nothing another lane wrote during this sweep.  (The general
+            // loop below re-read the left row from LDS behind a workgroup fence: three dependent LDS round trips per row.)
+            const int lx = lane;
+            const bool act = lx < rw;
+            const int nrows = yb1 - yb0;
+            for (int dir = 0; dir < 2 && nrows > 0; ++dir) {
+                const int step = dir == 0 ? 1 : -1;
+                int y = dir == 0 ? yb0 : yb1 - 1;
+                const int ya0 = y - step;                                  // the neighbouring band's row (or outside the region)
+                uint32_t prev = 0u;
+                if (act && (unsigned)ya0 < (unsigned)rh) prev = R[ya0 * stride + lx];
+                uint32_t pass_n = 0u, r_n = 0u;
+                if (act) { pass_n = P[y * stride + lx] ^ inv; r_n = R[y * stride + lx]; }
+                for (int k = 0; k < nrows; ++k, y += step) {
+                    const uint32_t pass = pass_n, r = r_n;
+                    if (k + 1 < nrows && act) { pass_n = P[(y + step) * stride + lx] ^ inv; r_n = R[(y + step) * stride + lx]; }
+                    uint32_t vt = prev;
+                    if (EIGHT) {
+                        const uint32_t pl = __shfl_up(prev, 1, 64), pr = __shfl_down(prev, 1, 64);
+                        vt |= (prev << 1) | (prev >> 1);
+                        if (lx > 0) vt |= pl >> 31;
+                        if (lx < rw - 1) vt |= pr << 31;
+                    }
+                    uint32_t v = (r | vt) & pass;
+                    for (;;) {
+                        v = fill_runs(v, pass);
+                        uint32_t l = __shfl_up(v, 1, 64), rr = __shfl_down(v, 1, 64);
+                        if (lane == 0) l = 0u;
+                        if (lane == 63) rr = 0u;
+                        const uint32_t nv = v | (((l >> 31) | (rr << 31)) & pass);
+                        const bool grow = nv != v;
+                        v = nv;
+                        if (!__any(grow)) break;
+                    }
+                    if (act && v != r) { R[y * stride + lx] = v; ch = true; }
+                    prev = v;
+                }
+            }
+        } else
         for (int dir = 0; dir < 2; ++dir) {
             for (int k = 0; k < yb1 - yb0; ++k) {
                 const int y = dir == 0 ? yb0 + k : yb1 - 1 - k;
