@@ -93,6 +93,7 @@ struct RpnP {
     float cell[5][3][4];
     int head_ld, N, img_h, img_w, pre_topk, post_topk;
     float nms_thresh;
+    int force_radix;    // (test switch, DEMIA_RPN_SELECT=radix) the five-pass selection for every level
     float* out_boxes;
     float* out_scores;
     int* out_count;
@@ -120,68 +121,151 @@ __global__ __launch_bounds__(1024) void rpn_level_kernel(const RpnP p) {
     const float* head = p.head[lvl] + (long)n * H * W * p.head_ld;
     auto logit = [&](int i) -> float { return head[(long)(i / 3) * p.head_ld + (i % 3)]; };
 
-    // ---- radix select: threshold key T = k-th largest -------------------------------------
-    unsigned prefix = 0, pmask = 0;
-    int need = k;  // how many still to take among keys matching the prefix
-    for (int pass = 3; pass >= 0; --pass) {
-        for (int i = tid; i < 256; i += blockDim.x) hist[i] = 0;
-        __syncthreads();
-        const int shift = pass * 8;
-        for (int i = tid; i < total; i += blockDim.x) {
-            const unsigned key = f2key(logit(i));
-            if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
-        }
-        __syncthreads();
-        if (tid == 0) {
-            int acc = 0, d = 255;
-            for (; d > 0; --d) {
-                if (acc + (int)hist[d] >= need) break;
-                acc += hist[d];
-            }
-            sh[0] = d;
-            sh[1] = need - acc;
-        }
-        __syncthreads();
-        prefix |= ((unsigned)sh[0]) << shift;
-        pmask |= 255u << shift;
-        need = sh[1];
-        __syncthreads();
-    }
-    const unsigned T = prefix;  // exactly `need` elements equal to T are taken, lowest index first
-
-    // ---- ordered compaction ------------------------------------------------------------------
-    if (tid == 0) { sh[2] = 0; sh[3] = 0; }  // running counts: selected, equal-taken
+    // ---- the k largest logits, ties by lowest index: keys[] <- (key << 32 | ~index), in any order (sorted below) ----------
+    // TWO passes over the level's logits: (A) a 4096-bin histogram of the top 12 key bits (sign, exponent, 3 mantissa bits)
+    // gives the bin T12 that holds the k-th largest and how many of its members are still needed; (B) everything above
+    // T12 is selected outright, the members of T12 go to a candidate list in LDS (the suppression matrix is not live yet),
+    // which is sorted by (key, ~index) and cut.  Objectness and deltas share one 64-byte row per pixel, so a pass pulls
+    // the whole 17 MB head of p2 through one CU: the four 8-bit radix passes + the ordered compaction this replaces
+    // were five of them, with two workgroup barriers per 1024 logits in the last.  A bin with more members than the list
+    // holds (logits that all share their top 12 bits) falls back to those five passes (`rpn_select_radix`).
+    constexpr int CAND_CAP = 8192;
+    unsigned* hist12 = reinterpret_cast<unsigned*>(mat);                    // [4096]
+    unsigned long long* cand = mat + 2048;                                  // [CAND_CAP], behind the histogram
+    const int npix = H * W;
+    const bool rows16 = (p.head_ld & 3) == 0 && (reinterpret_cast<unsigned long long>(head) & 15ull) == 0;
+    for (int i = tid; i < 4096; i += blockDim.x) hist12[i] = 0u;
     for (int i = tid; i < RPN_MAXK; i += blockDim.x) keys[i] = 0ull;
+    if (tid == 0) { sh[4] = 0; sh[5] = 0; sh[6] = -1; sh[7] = 0; }
     __syncthreads();
-    for (int base = 0; base < total; base += blockDim.x) {
-        const int i = base + tid;
-        unsigned key = 0;
-        bool gt = false, eq = false;
-        if (i < total) {
-            key = f2key(logit(i));
-            gt = key > T;
-            eq = key == T;
+    auto for_each_logit = [&](auto&& f) {                                 // f(index, key): index = pixel * 3 + anchor
+        for (int loc = tid; loc < npix; loc += blockDim.x) {
+            float v0, v1, v2;
+            if (rows16) {
+                const float4 v = *reinterpret_cast<const float4*>(head + (long)loc * p.head_ld);
+                v0 = v.x; v1 = v.y; v2 = v.z;
+            } else {
+                const float* q = head + (long)loc * p.head_ld;
+                v0 = q[0]; v1 = q[1]; v2 = q[2];
+            }
+            f(loc * 3, f2key(v0));
+            f(loc * 3 + 1, f2key(v1));
+            f(loc * 3 + 2, f2key(v2));
         }
-        const unsigned long long bg = __ballot(gt), be = __ballot(eq);
-        if (lane == 0) { sh[8 + wave] = __popcll(bg); sh[24 + wave] = __popcll(be); }
+    };
+    bool radix = p.force_radix != 0;
+    if (!radix) {
+        for_each_logit([&](int, unsigned key) { atomicAdd(&hist12[key >> 20], 1u); });
         __syncthreads();
-        int off_g = 0, off_e = 0;
-        for (int w = 0; w < wave; ++w) { off_g += sh[8 + w]; off_e += sh[24 + w]; }
-        const unsigned long long lt = (1ull << lane) - 1ull;
-        const int my_g = off_g + __popcll(bg & lt);
-        const int my_e = off_e + __popcll(be & lt);
-        const int base_sel = sh[2], base_eq = sh[3];
-        int tot_g = 0, tot_e = 0;
-        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { tot_g += sh[8 + w]; tot_e += sh[24 + w]; }
-        const int eq_room = need - base_eq;               // equal keys still allowed
-        const int eq_take = tot_e < eq_room ? tot_e : (eq_room > 0 ? eq_room : 0);
-        // slot layout inside this chunk: all gt first (index order), then the taken eq (index order)
-        if (gt) keys[base_sel + my_g] = ((unsigned long long)key << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
-        if (eq && my_e < eq_take)
-            keys[base_sel + tot_g + my_e] = ((unsigned long long)key << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
+        // suffix sums from the top bin: thread t owns bins 4 t .. 4 t + 3
+        unsigned mine[4], s_t = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { mine[q] = hist12[4 * tid + q]; s_t += mine[q]; }
+        unsigned x = s_t;                                                   // -> sum over this wave's lanes >= lane
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned y = __shfl_down(x, o, 64);
+            if (lane + o < 64) x += y;
+        }
+        if (lane == 0) sh[8 + wave] = (int)x;
         __syncthreads();
-        if (tid == 0) { sh[2] = base_sel + tot_g + eq_take; sh[3] = base_eq + eq_take; }
+        unsigned above = x - s_t;
+        for (int w = wave + 1; w < (int)(blockDim.x >> 6); ++w) above += (unsigned)sh[8 + w];
+        if (above < (unsigned)k && above + s_t >= (unsigned)k) {            // exactly one thread
+            unsigned acc = above;
+#pragma unroll
+            for (int q = 3; q >= 0; --q) {
+                if (acc + mine[q] >= (unsigned)k) { sh[6] = 4 * tid + q; sh[7] = k - (int)acc; break; }
+                acc += mine[q];
+            }
+        }
         __syncthreads();
+        const int T12 = sh[6], need12 = sh[7];
+        radix = T12 < 0 || hist12[T12 < 0 ? 0 : T12] > (unsigned)CAND_CAP;  // (block-uniform)
+        __syncthreads();
+        if (!radix) {
+            for_each_logit([&](int i, unsigned key) {
+                const int k12 = (int)(key >> 20);
+                if (k12 < T12) return;
+                const unsigned long long c = ((unsigned long long)key << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
+                if (k12 > T12) keys[atomicAdd(&sh[4], 1)] = c;              // fewer than k of them
+                else cand[atomicAdd(&sh[5], 1)] = c;                        // at most CAND_CAP
+            });
+            __syncthreads();
+            const int nsel = sh[4], ncand = sh[5];
+            int n2 = 2;
+            while (n2 < ncand) n2 <<= 1;
+            for (int i = ncand + tid; i < n2; i += blockDim.x) cand[i] = 0ull;
+            __syncthreads();
+            bitonic_desc(cand, n2);
+            for (int i = tid; i < need12; i += blockDim.x) keys[nsel + i] = cand[i];
+            __syncthreads();
+        }
+    }
+    if (radix) {
+        // ---- radix select: threshold key T = k-th largest -------------------------------------
+        unsigned prefix = 0, pmask = 0;
+        int need = k;  // how many still to take among keys matching the prefix
+        for (int pass = 3; pass >= 0; --pass) {
+            for (int i = tid; i < 256; i += blockDim.x) hist[i] = 0;
+            __syncthreads();
+            const int shift = pass * 8;
+            for (int i = tid; i < total; i += blockDim.x) {
+                const unsigned key = f2key(logit(i));
+                if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int acc = 0, d = 255;
+                for (; d > 0; --d) {
+                    if (acc + (int)hist[d] >= need) break;
+                    acc += hist[d];
+                }
+                sh[0] = d;
+                sh[1] = need - acc;
+            }
+            __syncthreads();
+            prefix |= ((unsigned)sh[0]) << shift;
+            pmask |= 255u << shift;
+            need = sh[1];
+            __syncthreads();
+        }
+        const unsigned T = prefix;  // exactly `need` elements equal to T are taken, lowest index first
+
+        // ---- ordered compaction ------------------------------------------------------------------
+        if (tid == 0) { sh[2] = 0; sh[3] = 0; }  // running counts: selected, equal-taken
+        for (int i = tid; i < RPN_MAXK; i += blockDim.x) keys[i] = 0ull;
+        __syncthreads();
+        for (int base = 0; base < total; base += blockDim.x) {
+            const int i = base + tid;
+            unsigned key = 0;
+            bool gt = false, eq = false;
+            if (i < total) {
+                key = f2key(logit(i));
+                gt = key > T;
+                eq = key == T;
+            }
+            const unsigned long long bg = __ballot(gt), be = __ballot(eq);
+            if (lane == 0) { sh[8 + wave] = __popcll(bg); sh[24 + wave] = __popcll(be); }
+            __syncthreads();
+            int off_g = 0, off_e = 0;
+            for (int w = 0; w < wave; ++w) { off_g += sh[8 + w]; off_e += sh[24 + w]; }
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            const int my_g = off_g + __popcll(bg & lt);
+            const int my_e = off_e + __popcll(be & lt);
+            const int base_sel = sh[2], base_eq = sh[3];
+            int tot_g = 0, tot_e = 0;
+            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { tot_g += sh[8 + w]; tot_e += sh[24 + w]; }
+            const int eq_room = need - base_eq;               // equal keys still allowed
+            const int eq_take = tot_e < eq_room ? tot_e : (eq_room > 0 ? eq_room : 0);
+            // slot layout inside this chunk: all gt first (index order), then the taken eq (index order)
+            if (gt) keys[base_sel + my_g] = ((unsigned long long)key << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
+            if (eq && my_e < eq_take)
+                keys[base_sel + tot_g + my_e] = ((unsigned long long)key << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
+            __syncthreads();
+            if (tid == 0) { sh[2] = base_sel + tot_g + eq_take; sh[3] = base_eq + eq_take; }
+            __syncthreads();
+        }
     }
     bitonic_desc(keys, RPN_MAXK);
 
@@ -447,6 +531,10 @@ extern "C" int demia_rpn_proposals(const demia_rpn_desc* d, void* stream) {
     }
     p.head_ld = d->head_ld; p.N = d->N; p.img_h = d->img_h; p.img_w = d->img_w;
     p.pre_topk = d->pre_topk; p.post_topk = d->post_topk; p.nms_thresh = d->nms_thresh;
+    {
+        const char* env = getenv("DEMIA_RPN_SELECT");
+        p.force_radix = env && env[0] == 'r';
+    }
     p.out_boxes = d->out_boxes; p.out_scores = d->out_scores; p.out_count = d->out_count;
     char* ws = reinterpret_cast<char*>(d->workspace);
     const long slots = (long)d->N * 5 * RPN_MAXK;

@@ -810,3 +810,56 @@ def test_batch_whose_activations_exceed_2gib_is_consistent(env):
             t = getattr(out, name)
             assert torch.equal(t[:16], t[16 * g:16 * (g + 1)]), (name, g)
     assert torch.equal(out.packed[:16], out.packed[48:])
+
+
+def test_rpn_two_pass_selection_equals_the_radix_passes_incl_ties(env, monkeypatch):
+    """The RPN's top-k per level: the two-pass selection (12-bit histogram, candidate list, sort) against the five radix /
+    compaction passes it replaced (``DEMIA_RPN_SELECT=radix``), bit for bit, on heads that make every branch run: smooth random
+    logits, logits quantised to a few dozen values (thousands of ties at the threshold: lowest index first), a level whose
+    threshold bin overflows the candidate list (falls back to the radix passes) and an all-equal level."""
+    from deepemia_amd import _lib, engine as E
+
+    eng, dev = env["eng"], env["dev"]
+    g = torch.Generator().manual_seed(5)
+    shapes = [(200, 200), (100, 100), (50, 50), (25, 25), (13, 13)]
+    cell = E.cell_anchor_table()
+
+    def run(heads, select):
+        if select:
+            monkeypatch.setenv("DEMIA_RPN_SELECT", select)
+        else:
+            monkeypatch.delenv("DEMIA_RPN_SELECT", raising=False)
+        n = heads[0].shape[0]
+        boxes = torch.zeros((n, 1000, 4), device=dev)
+        scores = torch.zeros((n, 1000), device=dev)
+        count = torch.zeros((n,), dtype=torch.int32, device=dev)
+        ws = torch.empty((int(eng.lib.demia_rpn_workspace_bytes(n)),), dtype=torch.uint8, device=dev)
+        desc = _lib.RpnDesc()
+        for i, hd in enumerate(heads):
+            desc.head[i] = _lib.ptr(hd)
+            desc.H[i], desc.W[i], desc.stride[i] = hd.shape[1], hd.shape[2], E.STRIDES[i]
+        desc.cell_anchors = cell.ctypes.data
+        desc.head_ld, desc.N, desc.img_h, desc.img_w = 16, n, 800, 800
+        desc.pre_topk, desc.post_topk, desc.nms_thresh = 1000, 1000, 0.7
+        desc.out_boxes, desc.out_scores, desc.out_count, desc.workspace = map(_lib.ptr, (boxes, scores, count, ws))
+        _lib.check(eng.lib.demia_rpn_proposals(C.byref(desc), eng._stream()), "rpn")
+        torch.cuda.synchronize()
+        return boxes.cpu(), scores.cpu(), count.cpu()
+
+    for kind in ("smooth", "quantised", "narrow", "equal"):
+        heads = []
+        for (h, w) in shapes:
+            hd = torch.randn(3, h, w, 16, generator=g)
+            hd[..., 3:15] *= 0.3
+            if kind == "quantised":
+                hd[..., :3] = torch.round(hd[..., :3] * 8) / 8                 # ~50 distinct logits: thousands of ties per value
+            elif kind == "narrow":
+                hd[..., :3] = 1.0 + hd[..., :3] * 1e-4                         # all logits in one 12-bit bin: list overflow on p2 / p3
+            elif kind == "equal":
+                hd[..., :3] = -2.5
+            heads.append(hd.to(dev).contiguous())
+        a = run(heads, None)
+        b = run(heads, "radix")
+        assert torch.equal(a[2], b[2]) and int(a[2].min()) > 0, kind
+        assert torch.equal(a[1], b[1]), kind
+        assert torch.equal(a[0], b[0]), kind
