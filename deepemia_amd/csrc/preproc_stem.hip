@@ -92,6 +92,10 @@ __global__ __launch_bounds__(256) void resize_h_row_kernel(const uint8_t* __rest
     for (int t = dmis + 4 * nw + threadIdx.x; t < ob; t += 256) d[t] = outb[t];
 }
 
+// (Round 3 also tried keeping a thread's taps in registers, for 1, 2 or 16 rows per workgroup, so that the 19 KB coefficient
+//  table is not re-read per row: same bytes out, 0.3 ms SLOWER for 48 tiles -- the table reads hit L1 and the dynamic tap loop
+//  beats eight predicated taps; one short-lived workgroup per row it stays.)
+
 // vertical pass + (x - mean) + write into the zero-bordered, 4-channel f32 stem input
 __global__ void resize_v_norm_kernel(const uint8_t* __restrict__ tmp, float* __restrict__ dst, long total, int H, int newW,
                                      int newH, int PH, int PW, const int* __restrict__ ymin,
@@ -123,6 +127,43 @@ __global__ void resize_v_norm_kernel(const uint8_t* __restrict__ tmp, float* __r
     }
 }
 
+// The same with FOUR output pixels per thread: a tap row contributes 12 consecutive bytes = three aligned dwords (the plain
+// version issued 3 one-byte loads per pixel and tap).  Needs newW % 4 == 0 (then every row of `tmp` starts on a dword).
+__global__ void resize_v_norm4_kernel(const uint8_t* __restrict__ tmp, float* __restrict__ dst, long total4, int H, int newW,
+                                      int newH, int PH, int PW, const int* __restrict__ ymin,
+                                      const int* __restrict__ ysize, const int* __restrict__ yk, int ks,
+                                      float m0, float m1, float m2) {
+    const int DW = PW + 8, DH = PH + 6;
+    const int q4 = newW >> 2;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        const int xq = (int)(i % q4);
+        const long t = i / q4;
+        const int yy = (int)(t % newH);
+        const long n = t / newH;
+        const uint32_t* s = reinterpret_cast<const uint32_t*>(tmp + ((n * H + ymin[yy]) * (long)newW + xq * 4) * 3);
+        const int cnt = ysize[yy];
+        const int* k = yk + (long)yy * ks;
+        int acc[12];
+#pragma unroll
+        for (int c = 0; c < 12; ++c) acc[c] = 1 << 21;
+        const long rs = (long)newW * 3 / 4;                                // dwords per row
+        for (int y = 0; y < cnt; ++y) {
+            const int kv = k[y];
+            const uint32_t w0 = s[y * rs], w1 = s[y * rs + 1], w2 = s[y * rs + 2];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                acc[c] += (int)((w0 >> (8 * c)) & 255u) * kv;
+                acc[4 + c] += (int)((w1 >> (8 * c)) & 255u) * kv;
+                acc[8 + c] += (int)((w2 >> (8 * c)) & 255u) * kv;
+            }
+        }
+        float* o = dst + ((n * DH + yy + 3) * (long)DW + xq * 4 + 3) * 4;
+#pragma unroll
+        for (int px = 0; px < 4; ++px)
+            *reinterpret_cast<float4*>(o + 4 * px) = make_float4((float)clip8(acc[3 * px]) - m0, (float)clip8(acc[3 * px + 1]) - m1,
+                                                                 (float)clip8(acc[3 * px + 2]) - m2, 0.f);
+    }
+}
 
 // cv2.resize(INTER_LINEAR) on 8-bit 3-channel images, OpenCV's fixed-point path:
 // horizontal: S[sx]*a0 + S[sx+1]*a1 (11-bit coefficients), vertical:
@@ -630,6 +671,12 @@ extern "C" int demia_resize_v_norm(const uint8_t* tmp, void* dst, int N, int H, 
     DEMIA_REQUIRE(PH >= newH && PW >= newW && PH % 32 == 0 && PW % 32 == 0, "padded size");
     const long total = (long)N * newH * newW;
     if (total == 0) return DEMIA_OK;
+    if ((newW & 3) == 0 && (reinterpret_cast<unsigned long long>(tmp) & 3ull) == 0 && !getenv("DEMIA_RESIZE_PLAIN")) {
+        hipLaunchKernelGGL(resize_v_norm4_kernel, dim3(grid_for(total / 4, 256)), dim3(256), 0, (hipStream_t)stream, tmp,
+                           (float*)dst, total / 4, H, newW, newH, PH, PW, ymin, ysize, yk, ksy, mean3[0], mean3[1], mean3[2]);
+        DEMIA_CHECK_LAUNCH("resize_v_norm4_kernel");
+        return DEMIA_OK;
+    }
     hipLaunchKernelGGL(resize_v_norm_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, tmp,
                        (float*)dst, total, H, newW, newH, PH, PW, ymin, ysize, yk, ksy, mean3[0], mean3[1], mean3[2]);
     DEMIA_CHECK_LAUNCH("resize_v_norm_kernel");
