@@ -445,12 +445,16 @@ __global__ __launch_bounds__(256, 2) void stem_mfma_kernel(const float* __restri
 // 7 x 7 outputs whose windows lie inside the tile.  Tiles therefore overlap by two conv rows / columns (1.31 x the conv
 // work, which is the cheap part).  Conv positions outside the image count as 0: every real value is >= 0 after the ReLU,
 // so a 0 never changes the maximum over the valid ones (torch pads the pool with -inf).
-constexpr int SP_CROW = 16 * 68;                 // words per conv row in LDS: 16 pixels x (64 channels + 4 pad)
-__global__ __launch_bounds__(256, 2) void stem_pool_mfma_kernel(const float* __restrict__ in, const _Float16* __restrict__ wpl,
+// The conv tile goes through LDS in two HALVES of 32 channels (= the two 128-byte groups of a P32 pixel): 34.8 KB instead of
+// 69.6 KB per workgroup, THREE workgroups per CU instead of two (four would cap a wave at 128 registers: spills) -- a workgroup is a chain of staging, 336 MFMAs per wave,
+// tile write and pooling, and only other workgroups hide it (1.15 -> see DESIGN §8 for the measured time).
+constexpr int SP_CPX = 36;                       // words per conv pixel in LDS: 32 channels + 4 pad
+constexpr int SP_CROW = 16 * SP_CPX;             // words per conv row in LDS
+__global__ __launch_bounds__(256, 3) void stem_pool_mfma_kernel(const float* __restrict__ in, const _Float16* __restrict__ wpl,
                                                                 const float* __restrict__ scale, const float* __restrict__ bias,
                                                                 char* __restrict__ out, float* __restrict__ meta, int PH, int PW,
                                                                 float s_in, float s_out, int groups, int single) {
-    __shared__ __attribute__((aligned(16))) char smem[16 * SP_CROW * 4];               // conv tile (69.6 KB); first the input planes
+    __shared__ __attribute__((aligned(16))) char smem[16 * SP_CROW * 4];               // half a conv tile (36.9 KB); first the input planes (23.7 KB)
     char* sx = smem;
     const int Ho = PH / 2, Wo = PW / 2, Hp = (Ho + 2 - 3) / 2 + 1, Wp = (Wo + 2 - 3) / 2 + 1, DW = PW + 8, DH = PH + 6;
     const int n = blockIdx.z, pi0 = blockIdx.y * 7, pj0 = blockIdx.x * 7;
@@ -515,7 +519,6 @@ __global__ __launch_bounds__(256, 2) void stem_pool_mfma_kernel(const float* __r
             }
         }
     }
-    __syncthreads();                                            // the input planes are dead: the conv tile takes their place
     float* cv = reinterpret_cast<float*>(smem);
     float sc4[4], bs4[4];
 #pragma unroll
@@ -523,49 +526,54 @@ __global__ __launch_bounds__(256, 2) void stem_pool_mfma_kernel(const float* __r
         sc4[nb] = scale[nb * 16 + (lane & 15)];
         bs4[nb] = bias[nb * 16 + (lane & 15)];
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int tr = wave * 4 + i, ho = hb + tr;
-        const bool row_ok = ho >= 0 && ho < Ho;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int px = 4 * (lane >> 4) + r, wx = wb + px;
-            const bool ok = row_ok && wx >= 0 && wx < Wo;
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) {
-                const float v = acc[i][nb][r] * sc4[nb] + bs4[nb];
-                cv[tr * SP_CROW + px * 68 + nb * 16 + (lane & 15)] = (ok && v > 0.f) ? v : 0.f;
-            }
-        }
-    }
-    __syncthreads();
     float vmax = 0.f;
-    for (int it = tid; it < 49 * 8; it += 256) {
-        const int pp = it >> 3, cg = it & 7;
-        const int pi = pp / 7, pj = pp - pi * 7;
-        const int gi = pi0 + pi, gj = pj0 + pj;
-        if (gi >= Hp || gj >= Wp) continue;
-        float m[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();                                        // the input planes / the other half's tile are dead
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                const float* p = cv + (2 * pi + dy) * SP_CROW + (2 * pj + dx) * 68 + cg * 8;
-                const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
-                m[0] = fmaxf(m[0], a.x); m[1] = fmaxf(m[1], a.y); m[2] = fmaxf(m[2], a.z); m[3] = fmaxf(m[3], a.w);
-                m[4] = fmaxf(m[4], b.x); m[5] = fmaxf(m[5], b.y); m[6] = fmaxf(m[6], b.z); m[7] = fmaxf(m[7], b.w);
+        for (int i = 0; i < 4; ++i) {
+            const int tr = wave * 4 + i, ho = hb + tr;
+            const bool row_ok = ho >= 0 && ho < Ho;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int px = 4 * (lane >> 4) + r, wx = wb + px;
+                const bool ok = row_ok && wx >= 0 && wx < Wo;
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh) {
+                    const int nb = 2 * half + nh;
+                    const float v = acc[i][nb][r] * sc4[nb] + bs4[nb];
+                    cv[tr * SP_CROW + px * SP_CPX + nh * 16 + (lane & 15)] = (ok && v > 0.f) ? v : 0.f;
+                }
             }
-        f16x8 h, l;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            vmax = fmaxf(vmax, m[c]);
-            const float y = m[c] * s_out;
-            h[c] = (_Float16)y;
-            l[c] = single ? (_Float16)0.f : (_Float16)(y - (float)h[c]);
         }
-        char* o = out + 128 + (((long)n * Hp + gi) * Wp + gj) * 256L + (cg >> 2) * 128 + (cg & 3) * 16;
-        *reinterpret_cast<f16x8*>(o) = h;
-        *reinterpret_cast<f16x8*>(o + 64) = l;
+        __syncthreads();
+        for (int it = tid; it < 49 * 4; it += 256) {
+            const int pp = it >> 2, cg = it & 3;
+            const int pi = pp / 7, pj = pp - pi * 7;
+            const int gi = pi0 + pi, gj = pj0 + pj;
+            if (gi >= Hp || gj >= Wp) continue;
+            float m[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const float* p = cv + (2 * pi + dy) * SP_CROW + (2 * pj + dx) * SP_CPX + cg * 8;
+                    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+                    m[0] = fmaxf(m[0], a.x); m[1] = fmaxf(m[1], a.y); m[2] = fmaxf(m[2], a.z); m[3] = fmaxf(m[3], a.w);
+                    m[4] = fmaxf(m[4], b.x); m[5] = fmaxf(m[5], b.y); m[6] = fmaxf(m[6], b.z); m[7] = fmaxf(m[7], b.w);
+                }
+            f16x8 h, l;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                vmax = fmaxf(vmax, m[c]);
+                const float y = m[c] * s_out;
+                h[c] = (_Float16)y;
+                l[c] = single ? (_Float16)0.f : (_Float16)(y - (float)h[c]);
+            }
+            char* o = out + 128 + (((long)n * Hp + gi) * Wp + gj) * 256L + half * 128 + cg * 16;
+            *reinterpret_cast<f16x8*>(o) = h;
+            *reinterpret_cast<f16x8*>(o + 64) = l;
+        }
     }
     float* slot = meta + (groups > 1 ? 2 * n : 0);
 #pragma unroll

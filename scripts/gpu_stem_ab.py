@@ -2,6 +2,8 @@
 import sys, torch
 sys.path.insert(0, '.')
 from deepemia_amd import _lib, synth
+import os, pathlib
+if os.environ.get('AB_LIB'): _lib.LIB_PATH = pathlib.Path(os.environ['AB_LIB']).resolve()
 from deepemia_amd.engine import MaskRCNNEngine
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 48
 eng = MaskRCNNEngine(synth.random_d2_state_dict(101, 2, 0), 101, 2, 0.3, 'cuda:0', 'f16x2')
