@@ -39,6 +39,9 @@
                           // 1024 = no fragment reads (scripts/build_variant.sh, scripts/gpu_ablate.sh)
 #endif
 
+#ifndef P32_HEAD_DIRECT
+#define P32_HEAD_DIRECT 1  // 0: the fused-head layer through the general epilogue (A/B builds)
+#endif
 #ifndef P32_SINGLE
 #define P32_SINGLE 0      // 1: the flagged single-plane build of this file (Makefile: conv_p32_single.o, entry point
                           // demia_conv2d_p32_single): fp16 operands in the high plane, ONE MFMA per product, zero low plane out
@@ -562,6 +565,80 @@ __device__ __forceinline__ void p32_epilogue_planes(const ConvQ& p, const GroupS
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Epilogue of the fused-head layer (ConvTranspose2d(2, 2) as a GEMM + ReLU, the 1x1 mask predictor + sigmoid folded in;
+// the P32 output is never written) STRAIGHT FROM THE ACCUMULATORS.  In the 16x16 MFMA result layout a lane holds, per
+// tile, four consecutive rows of ONE column: it scales / shifts / activates its 2 TN columns of a row, multiplies them by
+// the head weights of those columns, and the 16 lanes that share the rows add up with four DPP row rotations; the WN waves
+// that share a row meet once in LDS ([WN][BM][HN] partial sums, one workgroup barrier), then one thread per (row, head row)
+// adds the four partials in wave order, the bias, applies the head activation and stores.  The general epilogue took the
+// tile through an LDS image in TM passes of two barriers each and reduced with a 5-step ds_bpermute butterfly per head row
+// and item: 320 LDS crossbar operations per thread and tile for a layer that writes 8 bytes per row.
+template <int WM, int WN, int TM, int TN, int HN>
+__device__ __forceinline__ void p32_epilogue_head_direct(const ConvQ& p, const GroupScales& gs, char* smem, const f32x4 (&acc16)[2 * TM][2 * TN],
+                                                         int wm, int wn, int m0, int n0) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    static_assert(BN == 256, "the fused head needs a 256-wide tile");
+    const int tid = threadIdx.x, lane = tid & 63, c16 = lane & 15, rq = lane >> 4;
+    const int b1 = __builtin_amdgcn_readfirstlane(gs.b1), b2 = __builtin_amdgcn_readfirstlane(gs.b2);
+    const float post0 = uniform(gs.post0), post1 = uniform(gs.post1), post2 = uniform(gs.post2);
+    float sc[2 * TN], bs[2 * TN], hw[HN][2 * TN];
+#pragma unroll
+    for (int jn = 0; jn < 2 * TN; ++jn) {
+        const int cl = wn * TN * 32 + jn * 16 + c16;              // column inside the 256-wide tile
+        sc[jn] = p.scale ? p.scale[n0 + cl] : 1.0f;
+        bs[jn] = p.bias ? p.bias[n0 + cl] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < HN; ++j) hw[j][jn] = j < p.head_n ? p.head_w[j * 256 + cl] : 0.f;
+    }
+    const float act_lo = p.act == DEMIA_ACT_RELU ? 0.f : -INFINITY;
+    float* part = reinterpret_cast<float*>(smem);                 // [WN][BM][HN]; every wave has passed the K loop's last barrier
+#pragma unroll
+    for (int i = 0; i < 2 * TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = wm * TM * 32 + i * 16 + rq * 4 + r;
+            const int m = m0 + row;
+            const int gd = (m >= b1) + (m >= b2);
+            const float post = gd == 0 ? post0 : (gd == 1 ? post1 : post2);
+            float a[HN];
+#pragma unroll
+            for (int j = 0; j < HN; ++j) a[j] = 0.f;
+#pragma unroll
+            for (int jn = 0; jn < 2 * TN; ++jn) {
+                const float v = fmaxf((acc16[i][jn][r] * post) * sc[jn] + bs[jn], act_lo);
+#pragma unroll
+                for (int j = 0; j < HN; ++j) a[j] = fmaf(v, hw[j][jn], a[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < HN; ++j) {
+                // all-reduce over the 16 lanes of the DPP row (same rows, 16 different columns): rotations by 8, 4, 2, 1
+                a[j] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a[j]), 0x128, 0xf, 0xf, false));
+                a[j] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a[j]), 0x124, 0xf, 0xf, false));
+                a[j] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a[j]), 0x122, 0xf, 0xf, false));
+                a[j] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a[j]), 0x121, 0xf, 0xf, false));
+            }
+            if (c16 == 0) {
+#pragma unroll
+                for (int j = 0; j < HN; ++j) part[((long)wn * BM + row) * HN + j] = a[j];
+            }
+        }
+    }
+    __syncthreads();
+    const int tile_n_ = n0 / BN;
+    for (int o = tid; o < BM * HN; o += WM * WN * 64) {
+        const int row = o / HN, j = o - row * HN;
+        const int m = m0 + row;
+        if (m >= p.M || j >= p.head_n) continue;
+        float z = 0.f;
+#pragma unroll
+        for (int w = 0; w < WN; ++w) z += part[((long)w * BM + row) * HN + j];
+        z += p.head_b[j];
+        p.head_out[((long)m * p.ntn + tile_n_) * p.head_ld + j] =
+            p.head_act == DEMIA_ACT_SIGMOID ? 1.0f / (1.0f + expf(-z)) : (p.head_act == DEMIA_ACT_RELU ? fmaxf(z, 0.f) : z);
+    }
+}
+
 
 constexpr int EPI_GENERIC = 0, EPI_PLANES = 1, EPI_HEAD = 2;
 
@@ -930,6 +1007,13 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 2 : 1) void conv_p32_k
         } else {
             p32_epilogue_planes<WM, WN, TM, TN>(p, gs, smem, [&](int i, float* e) { write_acc32<TN, TN * 32 + 4>(acc[i], e, lane); }, wm, wn, m0, n0);
         }
+    } else if constexpr (M16 && HEAD && P32_HEAD_DIRECT) {
+        // (block-uniform) the layer's own activation is ReLU / none and the head has at most 2 rows (K = 2 classes): straight from
+        // the accumulators; anything else through the general epilogue
+        if (p.act != DEMIA_ACT_SIGMOID && p.head_n <= 2)
+            p32_epilogue_head_direct<WM, WN, TM, TN, 2>(p, gs, smem, acc16, wm, wn, m0, n0);
+        else
+            p32_epilogue<WM, WN, TM, TN, HEAD>(p, gs, smem, [&](int i, float* e) { write_acc16<TN, BN + 4>(acc16[2 * i], acc16[2 * i + 1], e, lane); }, wm, wn, m0, n0);
     } else if constexpr (M16) {
         p32_epilogue<WM, WN, TM, TN, HEAD>(p, gs, smem, [&](int i, float* e) { write_acc16<TN, BN + 4>(acc16[2 * i], acc16[2 * i + 1], e, lane); }, wm, wn, m0, n0);
     } else {
