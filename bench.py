@@ -113,6 +113,11 @@ def main() -> None:
                     "host memory on a copy stream (reported as `h2d`, never as `value`)")
     ap.add_argument("--no-plane-pools", action="store_true", help="(A/B) gather mask sets into fresh zero-filled planes instead of the plane pools")
     ap.add_argument("--no-csv-text", action="store_true", help="leave the CSV text (a19) of every step out of the timed region")
+    ap.add_argument("--lanes", type=int, default=1, help="(experiment, default 1) independent pipelines in flight on the GPU, each with its own "
+                    "engine arena, hipGraphs, streams and host thread; steps are dealt out round robin.  A second forward fills the CUs "
+                    "the first leaves idle at the end of every launch and in its HBM-bound layers: predictor only +6.5 %%, whole path "
+                    "+4-6.5 %% at K >= 40 timed steps, but 0-4 %% and unstable at K = 20 (with two forwards in flight one lane's "
+                    "post-processing stretches from 22 to 80-110 ms; DESIGN.md section 8)")
     ap.add_argument("--no-overlap", action="store_true", help="do not overlap batch i+1's network with batch i's post-processing")
     ap.add_argument("--forward-only", action="store_true", help="time predictor(tile) only, without the per-tile post-processing")
     ap.add_argument("--post-priority", choices=["default", "high", "low"], default="default", help="(experiment) priority of the post-processing stream")
@@ -153,15 +158,25 @@ def main() -> None:
     from deepemia_amd.predictor import Predictor
 
     sd = synth.random_d2_state_dict(args.depth, 2, seed=0)
-    eng = MaskRCNNEngine(sd, args.depth, 2, args.threshold, dev, args.precision, args.min_size_test, args.max_size_test)
-    pipe = InferencePipeline([Predictor(eng)], "bench", {}, {})
     args.graph = not args.eager and args.precision in ("f16x2", "f16")
-    pipe.use_graphs = bool(args.graph)
-    pipe.graph_after = 1
-    pipe.forward_batch = args.batch             # ONE forward per step over the whole batch (the CLI default chunks at 16)
-    # the loop below consumes batch i's detections before it launches forward i + 2: two graph slots, results read in place
-    pipe.graph_slots, pipe.clone_graph_outputs = 2, False
-    pipe.pooled_planes = not args.no_plane_pools   # ... and its masks before the next step's post-processing: plane pools
+    if args.no_overlap or args.eager or not args.graph or world > 1:
+        args.lanes = 1          # (N > 1: the lanes' host threads would issue the step's collective in any order)
+    args.lanes = max(1, min(args.lanes, 4))
+    import types
+    lanes = []
+    for li in range(args.lanes):
+        # a lane = one software pipeline (forward of batch i + L under the post-processing of batch i): its own engine, i.e. its
+        # own intermediates arena and hipGraphs (the weights are duplicated: 0.5 GB), its own plane pools, streams and host thread
+        e_ = MaskRCNNEngine(sd, args.depth, 2, args.threshold, dev, args.precision, args.min_size_test, args.max_size_test)
+        p_ = InferencePipeline([Predictor(e_)], f"bench{li}", {}, {})
+        p_.use_graphs = bool(args.graph)
+        p_.graph_after = 1
+        p_.forward_batch = args.batch             # ONE forward per step over the whole batch (the CLI default chunks at 16)
+        # the loop below consumes batch i's detections before it launches the lane's forward after next: two graph slots, results read in place
+        p_.graph_slots, p_.clone_graph_outputs = 2, False
+        p_.pooled_planes = not args.no_plane_pools   # ... and its masks before the lane's next post-processing: plane pools
+        lanes.append(types.SimpleNamespace(eng=e_, pipe=p_, last={}, net=None, post=None))
+    eng, pipe = lanes[0].eng, lanes[0].pipe       # (lane 0: the roofline instrumentation, the parity snapshot, the upload leg)
     # tiles 0..NUMPY_TILES-1 of the batch are the byte-reproducible numpy tiles (tile 0 is what the parity leg checks, the
     # CPU baseline times tiles 0..2); the rest of a large batch comes from the device generator (1.4 s of host numpy per tile)
     n_np = min(args.batch, NUMPY_TILES)
@@ -191,48 +206,66 @@ def main() -> None:
 
     DIAG_POST = os.environ.get("DEEPEMIA_BENCH_POST", "")
     MIN_AREA = max(5, args.size * args.size * 0.000005 * 0.05)      # inference.py:1175-1190
-    net_stream = torch.cuda.Stream(device=dev)      # network of batch i+1 ...
     prio = {"default": 0, "high": -1, "low": 1}[args.post_priority]
-    post_stream = torch.cuda.Stream(device=dev, priority=prio)     # ... runs under the post-processing of batch i
+    for ln in lanes:
+        ln.net = torch.cuda.Stream(device=dev)                      # network of the lane's next batch ...
+        ln.post = torch.cuda.Stream(device=dev, priority=prio)      # ... runs under the post-processing of its current one
+    net_stream, post_stream = lanes[0].net, lanes[0].post
+    last = lanes[0].last
+    import threading
+    post_lock = threading.Lock()
+    xchg = {}          # (lanes > 1) the start offset between lanes, set after the warm-up
 
-    def launch(i):
-        with torch.cuda.stream(net_stream):
-            return pipe.forward_async(0, xs[i % len(xs)] if i >= 0 else x)
+    TRACE = [] if os.environ.get("DEEPEMIA_BENCH_TRACE") else None      # (diagnostic) host timestamps of every lane's steps
 
-    def step(i, handle=None):
+    def launch(i, ln=lanes[0]):
+        if TRACE is not None:
+            TRACE.append((lanes.index(ln), i, "launch", time.perf_counter()))
+        with torch.cuda.stream(ln.net):
+            return ln.pipe.forward_async(0, xs[i % len(xs)] if i >= 0 else x)
+
+    def step(i, handle=None, ln=lanes[0]):
         """One pass of the hot path over this rank's batch of tiles."""
         if args.forward_only:
-            raw = (eng.forward_graphed if pipe.use_graphs else eng.forward)(xs[i % len(xs)] if i >= 0 else x)
-            return int(raw.count.sum().item()), 0
-        with torch.cuda.stream(post_stream):
-            return post(i, handle if handle is not None else launch(i))
+            with torch.cuda.stream(ln.net):
+                raw = (ln.eng.forward_graphed if ln.pipe.use_graphs else ln.eng.forward)(xs[i % len(xs)] if i >= 0 else x)
+                return int(raw.count.sum().item()), 0
+        with torch.cuda.stream(ln.post):
+            return post(i, handle if handle is not None else launch(i, ln), ln)
 
-    last = {}
-
-    def post(i, handle):
+    def post(i, handle, ln):
         tp0 = time.perf_counter()
         try:
-            return _post(i, handle)
+            return _post(i, handle, ln)
         finally:
-            last["post_s"] = last.get("post_s", 0.0) + time.perf_counter() - tp0
+            ln.last["post_s"] = ln.last.get("post_s", 0.0) + time.perf_counter() - tp0
 
-    def _post(i, handle):
-        dets = pipe.finish_forward(handle)
+    def _post(i, handle, ln):
+        dets = ln.pipe.finish_forward(handle)
         tq0 = time.perf_counter()
+        if TRACE is not None:
+            TRACE.append((lanes.index(ln), i, "fwd_done", tq0))
         try:
-            return _post_after_forward(i, dets)
+            # one lane post-processes at a time: two host loops at once share the interpreter lock and their kernels the same CUs
+            # (48-68 ms per pass instead of 22), and taking turns keeps the lanes half a period apart
+            with post_lock:
+                if TRACE is not None:
+                    TRACE.append((lanes.index(ln), i, "post_start", time.perf_counter()))
+                return _post_after_forward(i, dets, ln)
         finally:
-            last["post_after_fwd_s"] = last.get("post_after_fwd_s", 0.0) + time.perf_counter() - tq0
+            if TRACE is not None:
+                TRACE.append((lanes.index(ln), i, "post_done", time.perf_counter()))
+            ln.last["post_after_fwd_s"] = ln.last.get("post_after_fwd_s", 0.0) + time.perf_counter() - tq0
 
-    def _post_after_forward(i, dets):
+    def _post_after_forward(i, dets, ln):
         if DIAG_POST == "wait":          # (diagnostic: the forward's tables fetched, no post-processing kernels at all)
             time.sleep(0.02)
             return 0, 0
-        res = pipe.process_tile_batch(f"step{i}", x, SMALL_CLASSES, CLASS_THRESHOLDS, dets=dets)
+        res = ln.pipe.process_tile_batch(f"step{i}", x, SMALL_CLASSES, CLASS_THRESHOLDS, dets=dets)
         if i >= 0 and i % len(xs) == 0 or not args.total_tiles:
             # the step whose tile 0 is synthetic tile 0 (the parity check's reference); with plane pools the masks are views
-            # that the next step overwrites, and a multi-step job checks step 0 at the end: keep tile 0's own copy
-            last["res"] = [(res[0][0].clone() if (res[0][0] is not None and args.total_tiles) else res[0][0],) + tuple(res[0][1:])] + list(res[1:])
+            # that the lane's next step overwrites, and a multi-step job checks step 0 at the end: keep tile 0's own copy
+            ln.last["res"] = [(res[0][0].clone() if (res[0][0] is not None and args.total_tiles) else res[0][0],) + tuple(res[0][1:])] + list(res[1:])
         n_inst = sum(0 if r[0] is None else int(r[0].shape[0]) for r in res)
         if args.no_csv_text:
             n_rows = sum(len(c) for r in res for c in r[3])
@@ -241,7 +274,7 @@ def main() -> None:
             # memory: the float columns of all rows through one native call (measurement_csv_text; 4 ms per 2700 rows)
             text = measurement_csv_text([(f"tile{rank * args.batch + t_}.tif", r[2], r[3]) for t_, r in enumerate(res)],
                                         ("class_0", "class_1"), MIN_AREA)
-            n_rows, last["csv_bytes"] = text.count("\r\n"), len(text)
+            n_rows, ln.last["csv_bytes"] = text.count("\r\n"), len(text)
         if dist is not None:
             # the one exchange of the path: instance tables of every rank's tiles (unit id = global tile index);
             # areas / boxes come from the reductions the path has already done, the crop is one launch
@@ -251,7 +284,7 @@ def main() -> None:
                 scores = [s_ for r in res for s_ in r[1]]
                 classes = [c_ for r in res for c_ in r[2]]
                 units = [rank * args.batch + t for t, r in enumerate(res) for _ in r[1]]
-                stats = [st for st, r in zip(pipe.last_batch_stats, res) if r[0] is not None and r[0].shape[0]]
+                stats = [st for st, r in zip(ln.pipe.last_batch_stats, res) if r[0] is not None and r[0].shape[0]]
                 area = np.concatenate([a for a, _ in stats])
                 bbox = np.concatenate([b for _, b in stats])
                 hdr, pay = parallel.encode_instance_table(packed, scores, classes, units, bbox, area)
@@ -261,31 +294,75 @@ def main() -> None:
             parallel.all_gather_instance_tables(hdr, pay)
         return n_inst, n_rows
 
+    def run_lane(ln, idxs, out, launcher=launch):
+        """The lane's share of the timed steps, software-pipelined: the forward of its next batch is enqueued before the host
+        starts the post-processing of its current one, so the MFMA-bound network hides the latency-bound mask work."""
+        try:
+            torch.cuda.set_device(dev_index)
+            li = lanes.index(ln)
+            if li and xchg.get("stagger_s"):
+                # lanes start one after the other, a lane's share of the period apart: two forwards launched together run the same
+                # layers side by side (and finish, post-process and drain together); half a period apart one is in its MFMA-bound
+                # layers while the other is in its HBM-bound ones.  The GPU is not idle meanwhile: the earlier lanes are running.
+                time.sleep(li * xchg["stagger_s"])
+            if args.forward_only or args.no_overlap:
+                for i in idxs:
+                    out[0] = step(i, None, ln)
+                return
+            handle = launcher(idxs[0], ln) if idxs else None
+            for k, i in enumerate(idxs):
+                nxt = launcher(idxs[k + 1], ln) if k + 1 < len(idxs) else None
+                out[0] = step(i, handle, ln)
+                handle = nxt
+        except BaseException as e:      # re-raised by the main thread
+            out[1] = e
+
+    def run_steps(n_steps, launcher=launch):
+        """n_steps passes dealt out to the lanes round robin (step i -> lane i % L), one host thread per lane."""
+        outs = [[(0, 0), None] for _ in lanes]
+        if len(lanes) == 1:
+            run_lane(lanes[0], list(range(n_steps)), outs[0], launcher)
+        else:
+            ths = [threading.Thread(target=run_lane, args=(ln, list(range(li, n_steps, len(lanes))), outs[li], launcher))
+                   for li, ln in enumerate(lanes)]
+            for t_ in ths:
+                t_.start()
+            for t_ in ths:
+                t_.join()
+        for o in outs:
+            if o[1] is not None:
+                raise o[1]
+        return outs[(n_steps - 1) % len(lanes)][0]      # (instances, rows) of the last step
+
     det_total = 0
     waits0 = None
-    for i in range(args.warmup):
-        step(-1 - i)
+    t_warm = None
+    for ln in lanes:                          # W warm-up passes per lane (captures its graphs), one lane after the other
+        for i in range(args.warmup):
+            tw0 = time.perf_counter()
+            step(-1 - i, None, ln)
+            torch.cuda.synchronize()
+            t_warm = time.perf_counter() - tw0          # a pass alone, forward and post-processing one after the other
     sync_all()
+    # the start offset between lanes: with L forwards in flight a lane's forward takes about L single forwards, so the lanes sit
+    # one single forward apart (a warm-up pass is the forward + ~1/4 of it for the post-processing)
+    xchg["stagger_s"] = 0.8 * t_warm if (t_warm and len(lanes) > 1) else 0.0
     eng.conv_events = None if (args.no_conv_events or args.graph) else []
-    waits0 = pipe.d2h_waits
-    last["post_s"] = last["post_after_fwd_s"] = 0.0
+    waits0 = sum(ln.pipe.d2h_waits for ln in lanes)
+    for ln in lanes:
+        ln.last["post_s"] = ln.last["post_after_fwd_s"] = 0.0
     t0 = time.perf_counter()
-    if args.forward_only or args.no_overlap:
-        for i in range(args.steps):
-            det_total, rows_total = step(i)
-    else:
-        # K complete passes, software-pipelined: the forward of batch i+1 is enqueued before the host starts the
-        # post-processing of batch i, so the MFMA-bound network hides the latency-bound mask work
-        handle = launch(0)
-        for i in range(args.steps):
-            nxt = launch(i + 1) if i + 1 < args.steps else None
-            det_total, rows_total = step(i, handle)
-            handle = nxt
+    det_total, rows_total = run_steps(args.steps)      # K complete passes
     sync_all()
     dt = time.perf_counter() - t0
-    d2h_waits_per_step = (pipe.d2h_waits - waits0) / max(args.steps, 1)
-    post_wall_ms = last.get("post_s", 0.0) / max(args.steps, 1) * 1e3     # host wall time inside the post-processing of a step (incl. its waits)
-    post_after_fwd_ms = last.get("post_after_fwd_s", 0.0) / max(args.steps, 1) * 1e3   # ... of which after the step's own forward had finished
+    if TRACE is not None:
+        for li_, i_, what, t_ in TRACE:
+            if i_ >= 0:
+                print(f"[trace] lane {li_} step {i_:3d} {what:10s} {1e3 * (t_ - t0):9.2f} ms", file=sys.stderr)
+        TRACE.clear()
+    d2h_waits_per_step = (sum(ln.pipe.d2h_waits for ln in lanes) - waits0) / max(args.steps, 1)
+    post_wall_ms = sum(ln.last.get("post_s", 0.0) for ln in lanes) / max(args.steps, 1) * 1e3     # host wall time inside the post-processing of a step (incl. its waits)
+    post_after_fwd_ms = sum(ln.last.get("post_after_fwd_s", 0.0) for ln in lanes) / max(args.steps, 1) * 1e3   # ... of which after the step's own forward had finished
     events, eng.conv_events = eng.conv_events or [], None
 
     def snapshot(res):
@@ -321,34 +398,33 @@ def main() -> None:
         # second leg: the same K passes with every step's tiles UPLOADED from pinned host memory on a copy stream (two device
         # slots; the forward waits for its upload, the upload of step i+1 runs under the forward of step i)
         pinned = [t_.cpu().pin_memory() for t_ in xs]
-        slots_dev = [torch.empty_like(x), torch.empty_like(x)]
         copy_stream = torch.cuda.Stream(device=dev)
-        slot_free = [None, None]
         h2d_events = []
+        for ln in lanes:
+            ln.up_slots = [torch.empty_like(x), torch.empty_like(x)]
+            ln.up_free = [None, None]
+            ln.up_n = 0
 
-        def launch_up(i):
-            sl = i % 2
+        def launch_up(i, ln=lanes[0]):
+            sl = ln.up_n % 2
+            ln.up_n += 1
             with torch.cuda.stream(copy_stream):
-                if slot_free[sl] is not None:
-                    copy_stream.wait_event(slot_free[sl])
+                if ln.up_free[sl] is not None:
+                    copy_stream.wait_event(ln.up_free[sl])
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(copy_stream)
-                slots_dev[sl].copy_(pinned[i % len(pinned)], non_blocking=True)
+                ln.up_slots[sl].copy_(pinned[i % len(pinned)], non_blocking=True)
                 e1.record(copy_stream)
             h2d_events.append((e0, e1))
-            with torch.cuda.stream(net_stream):
-                net_stream.wait_event(e1)
-                hd = pipe.forward_async(0, slots_dev[sl])
-            slot_free[sl] = hd[1]
+            with torch.cuda.stream(ln.net):
+                ln.net.wait_event(e1)
+                hd = ln.pipe.forward_async(0, ln.up_slots[sl])
+            ln.up_free[sl] = hd[1]
             return hd
 
         sync_all()
         th = time.perf_counter()
-        handle = launch_up(0)
-        for i in range(args.steps):
-            nxt = launch_up(i + 1) if i + 1 < args.steps else None
-            step(i, handle)
-            handle = nxt
+        run_steps(args.steps, launcher=launch_up)
         sync_all()
         dth = time.perf_counter() - th
         up_ms = [a.elapsed_time(b) for a, b in h2d_events]
@@ -406,10 +482,12 @@ def main() -> None:
                                    "removal, component test, opening, greedy IoU dedup) -> cross-class dedup -> contour trace + 12 measurements" +
                                    ("" if args.no_csv_text else " -> measurement CSV text (csv.writer, in memory)")) +
                                    f"; random-init Detectron2-layout weights, K=2, threshold {args.threshold}"
+                                   + (f"; {args.lanes} pipelines in flight per GPU (steps dealt out round robin)" if args.lanes > 1 else "")
                                    + ("; all-gather of instance tables over ranks" if world > 1 and not args.forward_only else ""),
                        "tiles_per_step_per_gpu": args.batch, "instances_last_step_rank0": det_total,
                        "csv_rows_last_step_rank0": rows_total, "stage": "predictor only" if args.forward_only else "whole per-tile path",
                        "overlap": (not args.forward_only) and (not args.no_overlap), "hipgraph_forward": bool(args.graph),
+                       "lanes": args.lanes,
                        "post_d2h_waits_per_step": None if args.forward_only else d2h_waits_per_step,
                        "post_wall_ms_per_step": None if args.forward_only else post_wall_ms,
                        "post_after_forward_ms_per_step": None if args.forward_only else post_after_fwd_ms},
