@@ -122,3 +122,63 @@ def compare_tile(ref: dict, masks: np.ndarray, scores: Sequence[float], classes:
                ellipse_rows_skipped=skipped, masks_identical=int(same), masks_with_tie_pixels=int(n - same), tie_pixels_max=int(tie_max),
                ok=bool(iou_min >= 0.999 and err_same <= 1e-4 and err_own <= 1e-4 and smax <= 1e-4 and tie_max <= 8 and (n - same) <= max(3, n // 10)))
     return res
+
+
+def compare_predictor(raw: dict, boxes, scores, classes, masks, soft_tol: float = 3e-4, order_gap: float = 2e-6) -> dict:
+    """``predictor(tile)`` of the product (boxes [n, 4], scores [n], classes [n], dense bool masks [n, H, W]; torch CPU
+    tensors in detector order) against :func:`maskrcnn_ref.predict` of the same tile, WITHOUT assuming that the two lists
+    come in the same order: near-tied scores (the oracle's own fp32 scores a few 1e-7 apart) may legitimately sort the
+    other way round in an arithmetic that adds in a different order (inference.py:1395-1403 hands the list on in score order).
+
+    Every product instance is matched to the oracle instance of the same class with the nearest box; the result says
+    whether that is a bijection, which positions moved and how far apart the ORACLE's scores of the swapped detections are,
+    the score error and mask IoU against the matched instance, and for every mask that is not bit-identical the largest
+    distance from the 0.5 paste threshold of the oracle's own sampled probability (``paste_masks(soft=True)``) over the
+    differing pixels: a difference that is a threshold tie has |p - 0.5| of the size of the arithmetic error."""
+    import torch
+
+    rb, rs, rc, rm = raw["pred_boxes"], raw["scores"], raw["pred_classes"], raw["pred_masks"]
+    n, nr = int(scores.shape[0]), int(rs.shape[0])
+    res = {"instances": n, "instances_ref": nr, "bijection": False, "moved_positions": [], "order_gap_max": 0.0,
+           "score_max_abs_err": None, "box_max_abs_err": None, "masks_identical": 0, "masks_ge_0999": 0, "iou_min": None,
+           "differing": [], "tie_dist_max": 0.0, "ok": False}
+    if n != nr:
+        res["why"] = "instance count differs"
+        return res
+    if n == 0:
+        res.update(bijection=True, score_max_abs_err=0.0, box_max_abs_err=0.0, iou_min=1.0, ok=True)
+        return res
+    d = (boxes[:, None, :].float() - rb[None, :, :].float()).abs().amax(2)
+    d = d + (classes[:, None].long() != rc[None, :].long()).float() * 1e6
+    perm = d.argmin(1)
+    res["bijection"] = bool(perm.unique().numel() == n and float(d[torch.arange(n), perm].max()) < 0.5)
+    if not res["bijection"]:
+        res["why"] = "the product's instances are not a permutation of the oracle's (class + box within 0.5 px)"
+        return res
+    moved = [int(i) for i in (perm != torch.arange(n)).nonzero().flatten()]
+    gaps = [abs(float(rs[i]) - float(rs[int(perm[i])])) for i in moved]
+    res["moved_positions"] = [{"position": i, "oracle_position": int(perm[i]), "oracle_score_gap": g} for i, g in zip(moved, gaps)]
+    res["order_gap_max"] = max(gaps, default=0.0)
+    res["score_max_abs_err"] = float((scores.float() - rs[perm].float()).abs().max())
+    res["box_max_abs_err"] = float((boxes.float() - rb[perm].float()).abs().max())
+    h, w = rm.shape[1:]
+    iou_min, same, good, tie_max = 1.0, 0, 0, 0.0
+    for i in range(n):
+        j = int(perm[i])
+        a, b = masks[i], rm[j]
+        if torch.equal(a, b):
+            same += 1
+            good += 1
+            continue
+        diff = a != b
+        union = int((a | b).sum())
+        iou = 1.0 - int(diff.sum()) / max(union, 1)
+        soft = maskrcnn_ref.paste_masks(raw["mask_probs28"][j:j + 1], rb[j:j + 1], h, w, soft=True)[0]
+        tie = float((soft[diff] - 0.5).abs().max())
+        res["differing"].append({"position": i, "oracle_position": j, "iou": iou, "area": int(b.sum()), "pixels": int(diff.sum()),
+                                 "tie_dist": tie, "box_abs_err": float((boxes[i].float() - rb[j].float()).abs().max())})
+        iou_min, tie_max = min(iou_min, iou), max(tie_max, tie)
+        good += iou >= 0.999
+    res.update(masks_identical=same, masks_ge_0999=int(good), iou_min=iou_min, tie_dist_max=tie_max)
+    res["ok"] = bool(res["order_gap_max"] <= order_gap and res["score_max_abs_err"] <= 1e-4 and tie_max <= soft_tol)
+    return res
