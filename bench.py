@@ -47,7 +47,7 @@ def cpu_model() -> str:
     return "unknown"
 
 
-def cpu_baseline(depth: int, size: int, thr: float, sd, tiles: int = 3):
+def cpu_baseline(depth: int, size: int, thr: float, sd, tiles: int = 3):  # noqa: C901
     """Time the CPU oracle (a port of the reference's CPU path: Detectron2 predictor restatement + the dense numpy / scipy
     post-processing and measurements, ``oracle/tile_parity.py``) on a bounded sample of the workload: ``tiles`` tiles with
     all host threads of this GPU's share, plus the predictor alone with one thread (the post-processing is numpy / scipy
@@ -74,6 +74,7 @@ def cpu_baseline(depth: int, size: int, thr: float, sd, tiles: int = 3):
     base = {"value": 1.0 / secs["total"], "unit": "tiles/s", "cores": nthr, "kind": "port",
             "cpu_model": cpu_model(), "host_cores_visible": ncpu,
             "tiles_timed": tiles, "seconds_per_tile_median": secs["total"], "seconds_per_tile_min_max": [tot[0], tot[-1]],
+            "seconds_per_tile_p10_p90": [float(np.percentile(tot, 10)), float(np.percentile(tot, 90))],
             "stage_seconds_median": {k: v for k, v in secs.items() if k != "total"},
             "single_thread": {"value": 1.0 / total1, "cores": 1, "predictor_seconds": pred1,
                               "note": "predictor timed with torch.set_num_threads(1) on tile 0; the numpy / scipy stages are "
@@ -85,6 +86,31 @@ def cpu_baseline(depth: int, size: int, thr: float, sd, tiles: int = 3):
                       f"contour measurements on dense masks (oracle/postproc_ref.py); a restatement, not Detectron2 itself -- the "
                       f"reference's own prose claim is 30-120 s per image on CPU (docs/gpu-check.md:250)"}
     return base, refs[0]
+
+
+def resolve_lanes(lanes: int, world: int, overlap: bool, graph: bool) -> int:
+    """Pipelines in flight per GPU.  Forced to ONE whenever WORLD_SIZE > 1: every lane's host thread issues its step's
+    all-gather, and nothing orders the lanes' collectives alike on every rank -- two ranks x two lanes hung in mismatched
+    all-gathers until the lease ended (round 3, gpurun_out/two_rank_lanes.err).  Also one without overlap / hipGraph replay."""
+    if world > 1 or not overlap or not graph:
+        return 1
+    return max(1, min(int(lanes), 4))
+
+
+def load_or_make_device_tiles(first: int, n: int, size: int, dev, cache_dir):
+    """``n`` device-generated tiles (synth.em_tiles_device, seeds first ..).  With ``cache_dir`` they are read from / written
+    to ``<cache_dir>/tiles_<first>_<n>_<size>.npy``: a profiled run (rocprofv3 --pmc) then starts from a host copy and an
+    H2D memcpy instead of the generator's torch kernels (a --pmc pass crashed inside one of those in round 3)."""
+    from deepemia_amd import synth
+    if cache_dir:
+        path = Path(cache_dir) / f"tiles_{first}_{n}_{size}.npy"
+        if path.exists():
+            return torch.from_numpy(np.load(path)).to(dev)
+        t = synth.em_tiles_device(range(first, first + n), size, dev)
+        path.parent.mkdir(parents=True, exist_ok=True)
+        np.save(path, t.cpu().numpy())
+        return t
+    return synth.em_tiles_device(range(first, first + n), size, dev)
 
 
 def main() -> None:
@@ -104,6 +130,13 @@ def main() -> None:
     ap.add_argument("--max-size-test", type=int, default=1333)
     ap.add_argument("--total-tiles", type=int, default=0, help="BASELINE configs[4]: a job of this many DISTINCT tiles per GPU (e.g. 256), "
                     "walked in steps of --batch; overrides --steps")
+    ap.add_argument("--distinct-batches", type=int, default=2, help="the timed loop alternates this many DISTINCT resident batches (step i "
+                    "takes batch i %% n): batch 0 = the numpy tiles (tile 0 = the parity tile) + device-generated ones, the others all "
+                    "device-generated with their own seeds -- the incremental paste and the plane pools see changing boxes every step. "
+                    "1 = the same batch every step (also reported as the side field `same_batch_every_step`)")
+    ap.add_argument("--tiles-cache", default="", help="directory of .npy copies of the device-generated tiles: written when missing, "
+                    "read (numpy -> H2D copy, no generator kernels) when present -- make it with an unprofiled run, then profile")
+    ap.add_argument("--cpu-tiles", type=int, default=3, help="tiles of the timed CPU sample (cpu_baseline); ~27 s each")
     ap.add_argument("--repeat-tiles", action="store_true", help="(profiling passes) fill a batch beyond the 16 numpy tiles with copies of "
                     "them instead of device-generated tiles: no torch compute kernels before the forward (rocprofv3 --pmc crashed in one)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the timed CPU sample AND the parity leg")
@@ -159,9 +192,7 @@ def main() -> None:
 
     sd = synth.random_d2_state_dict(args.depth, 2, seed=0)
     args.graph = not args.eager and args.precision in ("f16x2", "f16")
-    if args.no_overlap or args.eager or not args.graph or world > 1:
-        args.lanes = 1          # (N > 1: the lanes' host threads would issue the step's collective in any order)
-    args.lanes = max(1, min(args.lanes, 4))
+    args.lanes = resolve_lanes(args.lanes, world, overlap=not args.no_overlap, graph=bool(args.graph))
     import types
     lanes = []
     for li in range(args.lanes):
@@ -181,12 +212,15 @@ def main() -> None:
     # CPU baseline times tiles 0..2); the rest of a large batch comes from the device generator (1.4 s of host numpy per tile)
     n_np = min(args.batch, NUMPY_TILES)
     tiles = np.stack([synth.em_tile(rank * args.batch + i, args.size) for i in range(n_np)])
-    x = torch.from_numpy(tiles).to(dev)
+    sha_tile0 = synth.hashlib.sha256(tiles[0].tobytes()).hexdigest()
+    x = torch.empty((args.batch, args.size, args.size, 3), dtype=torch.uint8, device=dev)
+    x[:n_np].copy_(torch.from_numpy(tiles))
     if args.batch > n_np and args.repeat_tiles:
-        x = x.repeat((args.batch + n_np - 1) // n_np, 1, 1, 1)[:args.batch].contiguous()
+        for k in range(n_np, args.batch, n_np):
+            x[k:k + n_np].copy_(x[:min(n_np, args.batch - k)])
     elif args.batch > n_np:
         first = 50000 + rank * args.batch
-        x = torch.cat([x, synth.em_tiles_device(range(first + n_np, first + args.batch), args.size, dev)])
+        x[n_np:].copy_(load_or_make_device_tiles(first + n_np, args.batch - n_np, args.size, dev, args.tiles_cache))
     xs = [x]
     if args.total_tiles:
         # configs[4]: every step sees DIFFERENT tiles.  Step 0 holds the numpy tiles (tile 0 is the parity check's tile); the
@@ -196,7 +230,14 @@ def main() -> None:
         args.steps = args.total_tiles // args.batch
         for k in range(1, args.steps):
             first = 100000 + (rank * args.steps + k) * args.batch
-            xs.append(synth.em_tiles_device(range(first, first + args.batch), args.size, dev))
+            xs.append(load_or_make_device_tiles(first, args.batch, args.size, dev, args.tiles_cache))
+    elif not args.repeat_tiles:
+        # the headline loop alternates DISTINCT resident batches: different boxes in every slot from one step to the next
+        for k in range(1, max(1, args.distinct_batches)):
+            first = 200000 + (rank * 16 + k) * args.batch
+            xs.append(load_or_make_device_tiles(first, args.batch, args.size, dev, args.tiles_cache))
+    # the last timed step that runs batch 0 (tile 0 = synthetic tile 0): the step the parity leg looks at
+    parity_step = 0 if args.total_tiles else ((args.steps - 1) // len(xs)) * len(xs)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -261,11 +302,11 @@ def main() -> None:
         if DIAG_POST == "wait":          # (diagnostic: the forward's tables fetched, no post-processing kernels at all)
             time.sleep(0.02)
             return 0, 0
-        res = ln.pipe.process_tile_batch(f"step{i}", x, SMALL_CLASSES, CLASS_THRESHOLDS, dets=dets)
-        if i >= 0 and i % len(xs) == 0 or not args.total_tiles:
+        res = ln.pipe.process_tile_batch(f"step{i}", xs[i % len(xs)] if i >= 0 else x, SMALL_CLASSES, CLASS_THRESHOLDS, dets=dets)
+        if i == parity_step or ln.last.get("keep_every"):
             # the step whose tile 0 is synthetic tile 0 (the parity check's reference); with plane pools the masks are views
-            # that the lane's next step overwrites, and a multi-step job checks step 0 at the end: keep tile 0's own copy
-            ln.last["res"] = [(res[0][0].clone() if (res[0][0] is not None and args.total_tiles) else res[0][0],) + tuple(res[0][1:])] + list(res[1:])
+            # that the lane's next step overwrites, and later steps may follow: keep tile 0's own copy
+            ln.last["res"] = [(res[0][0].clone() if (res[0][0] is not None and (i != args.steps - 1 or args.lanes > 1)) else res[0][0],) + tuple(res[0][1:])] + list(res[1:])
         n_inst = sum(0 if r[0] is None else int(r[0].shape[0]) for r in res)
         if args.no_csv_text:
             n_rows = sum(len(c) for r in res for c in r[3])
@@ -374,17 +415,20 @@ def main() -> None:
     # what the parity leg checks is the TIMED path's own result (graph replay in the default mode): taken here, before
     # anything else runs through the pipeline (total-tiles mode: step 0, the step whose tile 0 is synthetic tile 0)
     want_parity = rank == 0 and world == 1 and not args.no_cpu_baseline and not args.forward_only
-    timed_snap = snapshot(last["res"]) if (want_parity and "res" in last) else None
+    par_last = lanes[parity_step % len(lanes)].last          # the lane that ran the parity step
+    timed_snap = snapshot(par_last["res"]) if (want_parity and "res" in par_last) else None
     instrumented_s, eager_snap = None, None
     n_instr = 2
     if args.graph and not args.no_conv_events:
         # per-kernel HIP events cannot be taken inside a replayed graph: two eager, instrumented passes of the same path
         pipe.use_graphs = False
         last.pop("res", None)
+        last["keep_every"] = True
         step(0)
         sync_all()
+        last.pop("keep_every")
         if want_parity and "res" in last:
-            eager_snap = snapshot(last["res"])      # same input as the timed snapshot: eager launch vs graph replay
+            eager_snap = snapshot(last["res"])      # same input as the timed snapshot (batch 0): eager launch vs graph replay
         eng.conv_events = []
         ti = time.perf_counter()
         for i in range(n_instr):
@@ -393,6 +437,18 @@ def main() -> None:
         instrumented_s = time.perf_counter() - ti
         events, eng.conv_events = eng.conv_events, None
         pipe.use_graphs = True
+    same_batch = None
+    if len(xs) > 1 and not args.total_tiles and world == 1 and not args.no_h2d_leg:
+        # side figure: the loop of rounds 1-3, the SAME resident batch every step (paste and pools see identical boxes)
+        xs_all, xs = xs, [x]
+        sync_all()
+        ts = time.perf_counter()
+        run_steps(args.steps)
+        sync_all()
+        dts = time.perf_counter() - ts
+        xs = xs_all
+        same_batch = {"value": args.batch * args.steps / dts, "ms_per_step": dts / args.steps * 1e3,
+                      "note": "the same K passes over ONE resident batch repeated every step (the headline loop of rounds 1-3)"}
     h2d = None
     if world == 1 and not args.no_h2d_leg and not args.forward_only and not args.no_overlap:
         # second leg: the same K passes with every step's tiles UPLOADED from pinned host memory on a copy stream (two device
@@ -442,17 +498,26 @@ def main() -> None:
         all_conv_ms = sum(e[0].elapsed_time(e[1]) for e in events)
         # the dominant kernel = the conv kernel of the run's precision (f32x3: conv_igemm_split_kernel; the few layers
         # whose shape it does not take -- 15 / 11 / 2 output channels -- run on the exact-f32 kernel and are left out)
-        dom = [e for e in events if e[3] == args.precision]
+        # (f16x2: the launches of the stages that run single-plane by default -- the mask head, engine.DEFAULT_SINGLE_STAGES --
+        # are the same kernel with one MFMA per product; they carry the kind "f16" and are priced against the native fp16 peak)
+        kinds = {args.precision} | ({"f16"} if args.precision == "f16x2" else set())
+        dom = [e for e in events if e[3] in kinds]
         conv_ms = sum(e[0].elapsed_time(e[1]) for e in dom)
         conv_flops = sum(e[2] for e in dom)
         conv_bytes = sum(e[4] for e in dom)
         launches = len(dom)
+        single_launches = sum(1 for e in dom if e[3] == "f16" and args.precision != "f16")
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-        peak = PEAK_TFLOPS[args.precision]
+        # the roof of the MIX of launches: every launch's algorithmic FLOPs at the dense peak of ITS arithmetic (FLOP-weighted
+        # harmonic mean; = PEAK_TFLOPS[precision] when all launches compute alike)
+        roof_s = sum(e[2] / (PEAK_TFLOPS[e[3]] * 1e12) for e in dom)
+        peak = conv_flops / roof_s / 1e12 if roof_s > 0 else PEAK_TFLOPS[args.precision]
+        mfmas_per_product = {"f16x2": 3, "f16x2r": 3, "bf16x2": 3, "f32x3": 6}
+        executed_tflops = sum(e[2] * mfmas_per_product.get(e[3], 1) for e in dom) / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         # the same launches against the roof that bounds EACH of them: a launch cannot take less than its FLOPs at the MFMA
         # roof or its algorithmic bytes at the HBM roof (8 TB/s, MI355X_MICROARCH.md), whichever is longer
-        attainable_ms = sum(max(e[2] / (peak * 1e12), e[4] / 8.0e12) for e in dom) * 1e3
-        hbm_bound = sum(1 for e in dom if e[4] / 8.0e12 > e[2] / (peak * 1e12))
+        attainable_ms = sum(max(e[2] / (PEAK_TFLOPS[e[3]] * 1e12), e[4] / 8.0e12) for e in dom) * 1e3
+        hbm_bound = sum(1 for e in dom if e[4] / 8.0e12 > e[2] / (PEAK_TFLOPS[e[3]] * 1e12))
         # HBM bytes per conv launch from the PMC passes committed under profiles/ (collected with separate
         # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this workload; FETCH_SIZE doubled per the gfx950 note)
         # a STORED value, not measured in this run: it is only reported when the stored pass was taken on this kernel
@@ -475,12 +540,13 @@ def main() -> None:
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": ("NON-PARITY single-plane fp16 arithmetic (flagged mode, parity bar not met -- see parity): " if args.precision == "f16" else "") +
                                    ("NON-PARITY native-resolution mode, not configs[1]: " if native else
-                                    (f"configs[4] (a job of {args.total_tiles} distinct tiles per GPU, {args.steps} steps): " if args.total_tiles else "configs[1]: ")) +
+                                    (f"configs[4] (a job of {args.total_tiles} distinct tiles per GPU, {args.steps} steps): " if args.total_tiles else
+                                     f"configs[1] ({len(xs)} distinct resident batches taken in turn): ")) +
                                    f"R{args.depth}-FPN, {args.size}x{args.size} synthetic EM tiles, "
                                    f"{args.batch} tiles per GPU per step; per tile: resize {args.min_size_test} -> backbone/FPN/RPN/ROI heads -> mask paste to "
                                    f"bit-packed {args.size}^2 masks" + ("" if args.forward_only else " -> class loop (fill holes, closing, overlap "
                                    "removal, component test, opening, greedy IoU dedup) -> cross-class dedup -> contour trace + 12 measurements" +
-                                   ("" if args.no_csv_text else " -> measurement CSV text (csv.writer, in memory)")) +
+                                   ("" if args.no_csv_text else " -> measurement CSV text in memory (byte for byte csv.writer's, floats by the native demia_host_repr_rows)")) +
                                    f"; random-init Detectron2-layout weights, K=2, threshold {args.threshold}"
                                    + (f"; {args.lanes} pipelines in flight per GPU (steps dealt out round robin)" if args.lanes > 1 else "")
                                    + ("; all-gather of instance tables over ranks" if world > 1 and not args.forward_only else ""),
@@ -494,7 +560,10 @@ def main() -> None:
             "roofline": {"bound": "mfma", "kernel": ("conv_igemm_split_kernel (implicit-GEMM conv, f32 operands as 3 bf16 planes, 6 bf16 MFMAs "
                                                      "per product; peak = bf16 dense peak / 6)" if args.precision == "f32x3" else
                                                      "conv_p32_kernel (implicit-GEMM conv, both operands as 2 pre-scaled fp16 planes moved by LDS-DMA, "
-                                                     "3 fp16 MFMAs per product; peak = fp16 dense peak / 3)" if args.precision == "f16x2" else
+                                                     "3 fp16 MFMAs per product: roof = fp16 dense peak / 3" +
+                                                     (f"; {single_launches} of the {launches} timed launches -- the mask head -- run ONE MFMA per product on the "
+                                                      "high planes: roof = fp16 dense peak; `peak` = the FLOP-weighted roof of the mix)" if single_launches else ")")
+                                                     if args.precision == "f16x2" else
                                                      "conv_p32_kernel in its flagged single-plane mode (fp16 operands, ONE fp16 MFMA per product, zero low "
                                                      "planes still moved: bytes as f16x2; peak = fp16 dense peak)" if args.precision == "f16" else
                                                      "conv_igemm_split_kernel (implicit-GEMM conv, f32 activations split into 2 scaled fp16 planes in "
@@ -511,12 +580,14 @@ def main() -> None:
                          "share_of_eager_instrumented_step_time": conv_ms * 1e-3 / (instrumented_s or dt),
                          "measured_over": ("two instrumented eager steps after the timed region (the timed steps replay hipGraphs)" if instrumented_s
                                            else "the timed region"),
-                         "frac_of_native_peak": achieved * 3.0 / 2500.0 if args.precision in ("f16x2", "f16x2r", "bf16x2") else None,
+                         # executed MFMA work (every product counted with the MFMAs it costs) against the native 16-bit dense peak
+                         "frac_of_native_peak": executed_tflops / 2500.0 if args.precision in ("f16x2", "f16x2r", "bf16x2", "f16", "f32x3") else None,
+                         "single_plane_launches": single_launches,
                          # the same achieved (algorithmic, f32-equivalent) rate against the NATIVE 16-bit dense peak, i.e. without
                          # crediting the three MFMAs a product costs in this arithmetic
                          "algorithmic_frac_of_native_16bit_peak": achieved / 2500.0,
                          "frac_of_per_launch_roof": attainable_ms / conv_ms if conv_ms > 0 else None,
-                         "per_launch_roof": f"sum over launches of max(FLOP / {peak:.0f} TFLOP/s, algorithmic bytes / 8 TB/s) / measured time; "
+                         "per_launch_roof": f"sum over launches of max(FLOP / the launch's MFMA roof, algorithmic bytes / 8 TB/s) / measured time; "
                                             f"{hbm_bound} of {launches} launches are HBM-bound by that measure",
                          "traffic": traffic, "traffic_source": traffic_source,
                          "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)"},
@@ -525,6 +596,12 @@ def main() -> None:
         sq = cands[-1] if cands else ROOT / "profiles" / "none.json"
         if h2d is not None:
             line["h2d"] = h2d
+        if same_batch is not None:
+            line["same_batch_every_step"] = same_batch
+        line["inputs"] = {"sha256_tile0": sha_tile0, "sha256_weights": synth.sha256_of_state(sd),
+                          "distinct_resident_batches": len(xs),
+                          "note": "tile 0 = synth.em_tile(0) (numpy PCG64, seed 1234); weights = synth.random_d2_state_dict(depth, 2, seed=0); "
+                                  f"batch 0 = {n_np} numpy tiles + device-generated tiles, the other batches device-generated (seeded per tile)"}
         if sq.exists():
             rec = json.loads(sq.read_text())
             if rec.get("kernel") == kernel_name:
@@ -539,14 +616,14 @@ def main() -> None:
                 from deepemia_amd import synth as _synth
                 ref0 = TP.reference_tile(_synth.em_tile(0, args.size), sd, args.depth, args.threshold, CLASS_THRESHOLDS, SMALL_CLASSES)
             else:
-                line["cpu_baseline"], ref0 = cpu_baseline(args.depth, args.size, args.threshold, sd)
+                line["cpu_baseline"], ref0 = cpu_baseline(args.depth, args.size, args.threshold, sd, args.cpu_tiles)
             dense, scores, classes, recs = timed_snap
             par = TP.compare_tile(ref0, dense, scores, classes, recs)
             line["parity"] = {k: par[k] for k in ("mask_iou_min", "csv_max_rel_err", "csv_max_rel_err_own_mask", "csv_max_rel_err_all",
                                                   "score_max_abs_err", "instances", "instances_ref", "masks_identical",
                                                   "masks_with_tie_pixels", "tie_pixels_max", "csv_rows", "csv_rows_own_mask",
                                                   "ellipse_rows_skipped", "ok")}
-            line["parity"]["checked"] = (("tile 0 of the first timed step" if args.total_tiles else "tile 0 of the last timed step") +
+            line["parity"]["checked"] = ((f"tile 0 of timed step {parity_step} (the last one over batch 0)") +
                                          (" (hipGraph replay)" if args.graph else " (eager launches)") +
                                          ", snapshot taken before any other pass, vs oracle/tile_parity.py; bar: every mask IoU >= 0.999, CSV "
                                          "within 1e-4 relative on the instances whose mask equals the reference's bit for bit; the others "
@@ -566,7 +643,7 @@ def main() -> None:
                 line["value_rejected"] = line["value"]
                 line["value"] = None          # a fast path whose results differ from the reference's is not measured
         elif world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"], _ = cpu_baseline(args.depth, args.size, args.threshold, sd)
+            line["cpu_baseline"], _ = cpu_baseline(args.depth, args.size, args.threshold, sd, args.cpu_tiles)
         print(json.dumps(line), flush=True)
         if not ok:
             sys.exit(3)

@@ -11,7 +11,8 @@ import os
 from pathlib import Path
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "csrc" / "libdeepemia_hip.so"
+# DEEPEMIA_DEV_LIB=1: the dev build (`make -C deepemia_amd/csrc DEV=1`) with the kernels of the non-default precisions
+LIB_PATH = _HERE / "csrc" / ("libdeepemia_hip_dev.so" if os.environ.get("DEEPEMIA_DEV_LIB", "0") == "1" else "libdeepemia_hip.so")
 
 F32, BF16, F32X3, BF16X2, F16X2, P32 = 0, 1, 2, 3, 4, 5
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
@@ -52,7 +53,7 @@ class ConvP32Desc(C.Structure):
         ("act", C.c_int32), ("res_mode", C.c_int32), ("out_f32", C.c_int32), ("out_ld", C.c_int32), ("tile_hint", C.c_int32),
         ("head_w", C.c_void_p), ("head_b", C.c_void_p), ("head_out", C.c_void_p),
         ("head_n", C.c_int32), ("head_ld", C.c_int32), ("head_act", C.c_int32),
-        ("groups", C.c_int32), ("group_rows", C.c_int32), ("row0", C.c_int32),
+        ("groups", C.c_int32), ("group_rows", C.c_int32), ("row0", C.c_int32), ("single", C.c_int32),
     ]
 
 
@@ -71,7 +72,7 @@ class RoiAlignDesc(C.Structure):
         ("feat", C.c_void_p * 4), ("H", C.c_int32 * 4), ("W", C.c_int32 * 4),
         ("N", C.c_int32), ("R", C.c_int32), ("C", C.c_int32), ("P", C.c_int32), ("dtype", C.c_int32),
         ("boxes", C.c_void_p), ("count", C.c_void_p), ("out", C.c_void_p),
-        ("meta", C.c_void_p * 4), ("out_meta", C.c_void_p), ("groups", C.c_int32),
+        ("meta", C.c_void_p * 4), ("out_meta", C.c_void_p), ("groups", C.c_int32), ("single", C.c_int32),
     ]
 
 
@@ -100,7 +101,7 @@ EXPORTS = {
     "demia_conv_f16x2_kstep": (C.c_int, []),
     "demia_last_error": (C.c_char_p, []),
     "demia_build_arch": (C.c_char_p, []),
-    "demia_p32_single_plane": (C.c_int, [C.c_int]),
+    "demia_build_flavor": (C.c_char_p, []),
     "demia_conv2d_nhwc": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "demia_conv2d_p32": (C.c_int, [C.POINTER(ConvP32Desc), C.c_void_p]),
     "demia_conv2d_p32_single": (C.c_int, [C.POINTER(ConvP32Desc), C.c_void_p]),
@@ -116,9 +117,10 @@ EXPORTS = {
     "demia_stem_conv_mfma": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float,
                                         C.c_void_p]),
     "demia_stem_pool_mfma": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
-                                        C.c_float, C.c_float, C.c_int, C.c_void_p]),
+                                        C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p]),
     "demia_maxpool3x3s2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
-    "demia_maxpool3x3s2_p32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "demia_maxpool3x3s2_p32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_void_p]),
     "demia_subsample2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "demia_rpn_workspace_bytes": (C.c_int64, [C.c_int]),
     "demia_rpn_proposals": (C.c_int, [C.POINTER(RpnDesc), C.c_void_p]),
@@ -187,6 +189,10 @@ def load() -> C.CDLL:
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def is_dev_build() -> bool:
+    return load().demia_build_flavor() == b"dev"
 
 
 def check(status: int, what: str) -> None:

@@ -15,7 +15,6 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 extern "C" void demia_set_error(const char* fmt, ...);
-extern int g_demia_single_plane;   // capi.hip: demia_p32_single_plane()
 
 #define DEMIA_CHECK_LAUNCH(name)                                                   \
     do {                                                                           \

@@ -21,6 +21,11 @@
 // Detectron2 0.6 `GeneralizedRCNN.inference` under `predictor(image)`
 // (reference src/functions/inference.py:1395,1398,1507,1669; src/data/models.py:107).
 #include "common.h"
+#ifndef DEMIA_DEV
+#define DEMIA_DEV 0       // 1 (`make DEV=1`): also the kernels of the non-default precisions -- f32x3, bf16x2, f16x2r (operands split in
+                          // the K loop: rounds 1-2) and plain bf16.  The product build keeps the exact-f32 MFMA kernel only: it is the
+                          // control arithmetic of the parity suite (`--precision f32`) and serves the CLI's f32 mode.
+#endif
 #ifndef F16_BK
 #define F16_BK 32      // K-step of the f16x2 kernel: 32 keeps a stage at 41 KiB and the kernel at <= 168 registers -> THREE workgroups per CU
 #endif
@@ -713,6 +718,7 @@ extern "C" int demia_conv2d_nhwc(const demia_conv_desc* d, void* stream) {
         DEMIA_REQUIRE((long)d->H * d->W * d->Cin * 4 * 2 < (1L << 30), "one image must stay below 512 MiB");
         p.w_bytes = (int)wb;
     }
+#if DEMIA_DEV
     if (d->dtype == DEMIA_F16X2) {
         if (d->CoutPad % 128 != 0) return launch_split_cfg<float, 4, 1, 1, 2, 2, true>(p, st);
         const long blocks128 = (long)cdiv(p.M, 128) * cdiv(p.CoutPad, 128);
@@ -739,6 +745,9 @@ extern "C" int demia_conv2d_nhwc(const demia_conv_desc* d, void* stream) {
         if (d->out_dtype == DEMIA_BF16) return launch_typed<bf16_t, bf16_t>(p, bn, st);
         return launch_typed<bf16_t, float>(p, bn, st);
     }
+#else
+    DEMIA_REQUIRE(d->dtype == DEMIA_F32, "product build: demia_conv2d_nhwc computes exact f32 only (f32x3 / bf16x2 / f16x2r / bf16 need `make DEV=1`)");
+#endif
     DEMIA_REQUIRE(d->out_dtype == DEMIA_F32, "f32 input requires f32 output");
     return launch_typed<float, float>(p, bn, st);
 }

@@ -78,6 +78,7 @@ struct ConvQ {
     int head_n, head_ld, head_act;
     int groups, group_rows, row0;   // scale groups (images): in_meta / res_meta / out_meta are [groups][2]; output row m of this
                                     // call belongs to group (m + row0) / group_rows
+    int zero_low;           // single-plane build only: write the output's low plane as zeros (demia_conv_p32_desc.single == 2)
     int stagger_ticks;      // > 0: the second half of the first resident set of workgroups starts this many 10-ns ticks late
     int resident;           // workgroups resident at once (256 CUs x workgroups per CU) -- for the stagger
 };
@@ -352,7 +353,7 @@ __device__ __forceinline__ void p32_epilogue(const ConvQ& p, const GroupScales& 
                         vm = fmaxf(vm, fabsf(v[q]));
                         const float y = v[q] * s_out;
                         h[q] = (_Float16)y;
-                        l[q] = P32_SINGLE ? (_Float16)0.f : (_Float16)(y - (float)h[q]);
+                        l[q] = (P32_SINGLE && p.zero_low) ? (_Float16)0.f : (_Float16)(y - (float)h[q]);
                     }
                     vmax3[0] = fmaxf(vmax3[0], gd == 0 ? vm : 0.f);
                     vmax3[1] = fmaxf(vmax3[1], gd == 1 ? vm : 0.f);
@@ -436,7 +437,7 @@ __device__ __forceinline__ void p32_epilogue_planes(const ConvQ& p, const GroupS
     const bool sigmoid_on = p.act == DEMIA_ACT_SIGMOID;
     const float act_lo = p.act == DEMIA_ACT_RELU ? 0.f : -INFINITY;
     const bool res_on = p.res_mode != DEMIA_RES_NONE;
-    constexpr bool single = P32_SINGLE != 0;
+    const bool single = P32_SINGLE != 0 && p.zero_low != 0;      // (the default object: constant false)
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.out_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(res_on ? p.res : p.out), 0, res_on ? (int)p.res_bytes : 0, 0x00020000);
     const unsigned cbytes = (unsigned)p.Cout * 4u;                                     // bytes per P32 pixel
@@ -660,6 +661,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 2 : 1) void conv_p32_k
     const int swz = xcd_remap(blockIdx.x, p.nwg);
     const int tile_n = swz % p.ntn, tile_m = swz / p.ntn;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+#if P32_DEV_TILES
     if (p.stagger_ticks > 0) {
         // Short-K layers alternate a K loop that barely touches HBM with an epilogue that saturates it, and every CU starts
         // in the same phase: delaying half of the first resident set by about half a tile period puts one half of the
@@ -671,6 +673,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 2 : 1) void conv_p32_k
             while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)p.stagger_ticks) __builtin_amdgcn_s_sleep(32);
         }
     }
+#endif
 
     const i32x4 rsrc_a = make_rsrc(p.in, p.in_bytes), rsrc_b = make_rsrc(p.w, p.w_bytes);
     const unsigned lds0 = (unsigned)(__SIZE_TYPE__)((lds_void*)smem);
@@ -1300,7 +1303,7 @@ extern "C" int demia_conv2d_p32_single(const demia_conv_p32_desc* d, void* strea
 #else
 extern "C" int demia_conv2d_p32_single(const demia_conv_p32_desc* d, void* stream);      // conv_p32_single.o: this file with -DP32_SINGLE=1
 extern "C" int demia_conv2d_p32(const demia_conv_p32_desc* d, void* stream) {
-    if (g_demia_single_plane) return demia_conv2d_p32_single(d, stream);              // flagged mode (demia_p32_single_plane)
+    if (d && d->single) return demia_conv2d_p32_single(d, stream);                    // one MFMA per product, chosen per launch
 #endif
     DEMIA_REQUIRE(d && d->in && d->in_meta && d->w && (d->out || d->head_n > 0), "null pointer");
     DEMIA_REQUIRE(d->out_f32 || d->out_meta || d->head_n > 0, "P32 output needs out_meta");
@@ -1331,6 +1334,7 @@ extern "C" int demia_conv2d_p32(const demia_conv_p32_desc* d, void* stream) {
     p.ksteps = p.taps * (d->Cin / 32);
     p.in_bytes = (unsigned)in_bytes; p.w_bytes = (unsigned)w_bytes;
     p.ntn = p.nwg = 0;
+    p.zero_low = d->single == 2;
     p.resident = 256;
     p.groups = d->groups > 1 ? d->groups : 1;
     p.group_rows = p.groups > 1 ? d->group_rows : (1 << 29);
@@ -1342,10 +1346,13 @@ extern "C" int demia_conv2d_p32(const demia_conv_p32_desc* d, void* stream) {
         DEMIA_REQUIRE(d->head_n <= 4 && d->head_w && d->head_b && d->head_out && d->head_ld >= d->head_n, "fused head: at most 4 rows, pointers, head_ld");
         DEMIA_REQUIRE(d->CoutPad % 256 == 0 && d->Cout == d->CoutPad && !d->out_f32, "fused head needs Cout % 256 == 0 and a planes layer");
     }
+    p.stagger_ticks = 0;
+#if P32_DEV_TILES
     {
-        static const char* env = getenv("DEMIA_P32_STAGGER_US");      // experiment switch (microseconds)
+        static const char* env = getenv("DEMIA_P32_STAGGER_US");      // experiment switch (microseconds), dev build only
         p.stagger_ticks = env ? atoi(env) * 100 : 0;
     }
+#endif
     if (p.M == 0) return DEMIA_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     // tile_hint: 0 = auto (the model above), else one of the instantiated tiles (dev / tuning: scripts/gpu_conv_p32_check.py)

@@ -729,7 +729,7 @@ extern "C" int demia_stem_conv_mfma(const float* in, const void* w_planes, const
 }
 
 extern "C" int demia_stem_pool_mfma(const float* in, const void* w_planes, const float* scale, const float* bias, void* out,
-                                    float* out_meta, int N, int PH, int PW, float s_in, float s_out, int groups, void* stream) {
+                                    float* out_meta, int N, int PH, int PW, float s_in, float s_out, int groups, int single, void* stream) {
     DEMIA_REQUIRE(in && w_planes && scale && bias && out && out_meta && s_in > 0.f && s_out > 0.f, "args");
     DEMIA_REQUIRE(PH % 32 == 0 && PW % 32 == 0, "padded size");
     DEMIA_REQUIRE(groups <= 1 || groups == N, "scale groups: one per image");
@@ -738,7 +738,7 @@ extern "C" int demia_stem_pool_mfma(const float* in, const void* w_planes, const
     if ((long)N * Hp * Wp == 0) return DEMIA_OK;
     hipLaunchKernelGGL(stem_pool_mfma_kernel, dim3(cdiv(Wp, 7), cdiv(Hp, 7), N), dim3(256), 0, (hipStream_t)stream, in,
                        reinterpret_cast<const _Float16*>(w_planes), scale, bias, (char*)out, out_meta, PH, PW, s_in, s_out, groups,
-                       g_demia_single_plane);
+                       single);
     DEMIA_CHECK_LAUNCH("stem_pool_mfma_kernel");
     return DEMIA_OK;
 }
@@ -759,7 +759,7 @@ extern "C" int demia_maxpool3x3s2(const void* in, void* out, int N, int H, int W
 }
 
 extern "C" int demia_maxpool3x3s2_p32(const float* in, void* out, float* out_meta, float s, int N, int H, int W, int C, int groups,
-                                      void* stream) {
+                                      int single, void* stream) {
     DEMIA_REQUIRE(in && out && out_meta && C % 32 == 0 && s > 0.f, "args");
     DEMIA_REQUIRE(groups <= 1 || groups == N, "scale groups: one per image");
     DEMIA_REQUIRE(N <= 65535, "N");
@@ -768,7 +768,7 @@ extern "C" int demia_maxpool3x3s2_p32(const float* in, void* out, float* out_met
     if (per_image * N == 0) return DEMIA_OK;
     const int gx = (int)((grid_for(per_image * N, 256) + N - 1) / N);
     hipLaunchKernelGGL(maxpool3x3s2_p32_kernel, dim3(gx, N), dim3(256), 0, (hipStream_t)stream, in, (char*)out, out_meta, s,
-                       per_image, H, W, C, Ho, Wo, groups, g_demia_single_plane);
+                       per_image, H, W, C, Ho, Wo, groups, single);
     DEMIA_CHECK_LAUNCH("maxpool3x3s2_p32_kernel");
     return DEMIA_OK;
 }

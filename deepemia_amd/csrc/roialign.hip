@@ -21,7 +21,7 @@ struct RoiP {
     const float* meta[4];   // P32 only: {amax, s} of each level, [groups][2]
     float* out_meta;        // P32 only, [groups][2]
     int groups;             // P32 only: 1, or N (one scale group per image)
-    int single;             // P32 only: write a zero low plane (demia_p32_single_plane)
+    int single;             // P32 only: write a zero low plane (demia_roialign_desc.single)
 };
 
 // Element access policies: bytes per pixel, a lane's byte offset inside a pixel (four channels per lane), load / store
@@ -299,7 +299,7 @@ extern "C" int demia_roi_align(const demia_roialign_desc* d, void* stream) {
     for (int l = 0; l < 4; ++l) p.meta[l] = d->meta[l];
     p.out_meta = d->out_meta;
     p.groups = d->groups > 1 ? d->groups : 1;
-    p.single = g_demia_single_plane;
+    p.single = d->single;
     DEMIA_REQUIRE(p.groups == 1 || p.groups == d->N, "scale groups: one per image");
     if (d->dtype == DEMIA_P32) {
         DEMIA_REQUIRE(d->C % 32 == 0 && d->out_meta && d->meta[0] && d->meta[1] && d->meta[2] && d->meta[3], "P32 needs C % 32 == 0 and the meta pointers");

@@ -22,7 +22,7 @@ import os
 import ctypes as C
 import math
 from dataclasses import dataclass
-from typing import Dict, List, Optional, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -35,6 +35,15 @@ PIXEL_MEAN = (103.530, 116.280, 123.675)
 ANCHOR_SIZES = (32, 64, 128, 256, 512)
 ANCHOR_RATIOS = (0.5, 1.0, 2.0)
 STRIDES = (4, 8, 16, 32, 64)
+# convolution stages that can be run single-plane one at a time (MaskRCNNEngine(single_stages=...))
+# ... and the ones that DO run single-plane by default in the f16x2 path: the mask head (4 x conv3x3 at 14 x 14 + the deconv GEMM,
+# 22 % of a tile's FLOPs).  Its output only feeds the 0.5 threshold of the paste -- no score, box, NMS or ordering decision --
+# and on the eight headline tiles it leaves the record of tests/test_gpu_multitile_parity.py unchanged (same instance lists,
+# 799 / 800 masks at IoU >= 0.999, same worst tie distance; profiles/r04_precision_map.json), while every
+# other stage moves scores by ~1e-3 and flips NMS decisions.  DEEPEMIA_SINGLE_STAGES="" (or single_stages=()) restores three
+# MFMAs per product everywhere.
+DEFAULT_SINGLE_STAGES = ("mask_fcn", "deconv")
+STAGES = ("res2", "res3", "res4", "res5", "fpn_lateral", "fpn_output", "rpn_conv", "rpn_pred", "fc1", "fc2", "box_pred", "mask_fcn", "deconv")
 BN_EPS = 1e-5
 PRE_NMS_TOPK = 1000
 POST_NMS_TOPK = 1000
@@ -200,6 +209,7 @@ class ConvLayer:
     scale3: Optional[torch.Tensor] = None   # f16x2: the output scale divided by the per-channel weight scale
     wbound: float = 0.0                 # f16x2: max_co(|scale_co| * sum_k |w_co,k|) and max |bias| -- the a-priori bound of
     bbound: float = 0.0                 #        |out| from which the epilogue derives the scale of its P32 output
+    single: int = 0                     # demia_conv_p32_desc.single of this layer's launches (0 = three MFMAs per product)
 
 
 @dataclass
@@ -218,7 +228,8 @@ class RawDetections:
 
 class MaskRCNNEngine:
     def __init__(self, state_dict: Dict[str, torch.Tensor], depth: int, num_classes: int, score_thresh: float,
-                 device: str = "cuda:0", precision: str = "f16x2", min_size_test: int = 800, max_size_test: int = 1333):
+                 device: str = "cuda:0", precision: str = "f16x2", min_size_test: int = 800, max_size_test: int = 1333,
+                 single_stages: Optional[Sequence[str]] = None):
         if depth not in RES_BLOCKS:
             raise ValueError(f"unsupported ResNet depth {depth}")
         if not torch.cuda.is_available():
@@ -248,8 +259,20 @@ class MaskRCNNEngine:
                              "bf16 pipe, 3-way split), 'bf16x2' (16-bit operands on the bf16 pipe), 'bf16', or 'f16' (flagged NON-parity: "
                              "the f16x2 path with single-plane fp16 operands, one MFMA per product -- the reference's autocast "
                              "arithmetic, inference.py:1390-1395)")
+        if precision not in ("f16x2", "f16", "f32") and not _lib.is_dev_build():
+            raise ValueError(f"precision '{precision}' needs the dev build of the library (make -C deepemia_amd/csrc DEV=1, then "
+                             f"DEEPEMIA_DEV_LIB=1): the product library computes f16x2 (default), f16 and exact f32 only")
         self.p32 = precision in ("f16x2", "f16")          # activations travel as P32 planes (deepemia_amd/p32.py)
-        self.single_plane = precision == "f16"            # ... with a zero low plane (demia_p32_single_plane)
+        self.single_plane = precision == "f16"            # ... with a zero low plane, every layer (conv desc `single` = 2)
+        # per-STAGE single-plane arithmetic inside the f16x2 path (the precision map): the convolutions of
+        # the named stages issue ONE MFMA per product on the high planes (conv desc `single` = 1); their outputs keep both planes
+        if single_stages is None:
+            env = os.environ.get("DEEPEMIA_SINGLE_STAGES")
+            single_stages = () if precision != "f16x2" else (DEFAULT_SINGLE_STAGES if env is None else tuple(t for t in env.split(",") if t))
+        unknown = set(single_stages) - set(STAGES)
+        if unknown or (single_stages and precision != "f16x2"):
+            raise ValueError(f"single_stages {sorted(unknown)}: choose from {STAGES}, with precision 'f16x2'")
+        self.single_stages = frozenset(single_stages)
         self._amax_buf: Optional[torch.Tensor] = None     # f16x2r: per-forward pool of |activation| bounds
         self._amax_i = 0
         self._meta_pool: Optional[torch.Tensor] = None    # f16x2: {max |x|, s} per activation tensor and image, zeroed once per forward
@@ -286,7 +309,7 @@ class MaskRCNNEngine:
         self._used.add(key)
         return sd[key].detach().to(torch.float32).cpu()
 
-    def _conv(self, sd, prefix, stride=1, pad=0, norm=False, bias=False, weight=None, bias_t=None) -> ConvLayer:
+    def _conv(self, sd, prefix, stride=1, pad=0, norm=False, bias=False, weight=None, bias_t=None, stage: str = "") -> ConvLayer:
         w = self._get(sd, prefix + ".weight") if weight is None else weight
         cout, cin, kh, kw = w.shape
         cout_pad = (cout + 63) // 64 * 64 if self.p32 else (cout + 31) // 32 * 32
@@ -316,7 +339,7 @@ class MaskRCNNEngine:
             return ConvLayer(None, None if scale is None else scale.to(dev).contiguous(), None if b is None else b.to(dev).contiguous(),
                              cin, cout, cout_pad, kh, kw, stride, pad, tile_weight_planes_p32(planes),
                              (base.to(dev) / sw[:cout]).contiguous(), float((base.abs() * l1).max()),
-                             0.0 if b is None else float(b.abs().max()))
+                             0.0 if b is None else float(b.abs().max()), 2 if self.single_plane else int(stage in self.single_stages))
         w3 = None
         if self.precision in ("f32x3", "bf16x2") and cout_pad % 64 == 0 and cin % 32 == 0:
             w3 = split3_bf16(wp.to(dev))                       # split on the device: same round-to-nearest casts
@@ -366,37 +389,37 @@ class MaskRCNNEngine:
                 stride = 2 if (i == 0 and stage > 2) else 1
                 blk = {}
                 if (p + "shortcut.weight") in sd:
-                    blk["shortcut"] = self._conv(sd, p + "shortcut", stride=stride, norm=True)
-                blk["conv1"] = self._conv(sd, p + "conv1", stride=stride, norm=True)
-                blk["conv2"] = self._conv(sd, p + "conv2", pad=1, norm=True)
-                blk["conv3"] = self._conv(sd, p + "conv3", norm=True)
+                    blk["shortcut"] = self._conv(sd, p + "shortcut", stride=stride, norm=True, stage=f"res{stage}")
+                blk["conv1"] = self._conv(sd, p + "conv1", stride=stride, norm=True, stage=f"res{stage}")
+                blk["conv2"] = self._conv(sd, p + "conv2", pad=1, norm=True, stage=f"res{stage}")
+                blk["conv3"] = self._conv(sd, p + "conv3", norm=True, stage=f"res{stage}")
                 stage_blocks.append(blk)
             self.blocks.append(stage_blocks)
-        self.fpn_lateral = {l: self._conv(sd, f"backbone.fpn_lateral{l}", bias=True) for l in (2, 3, 4, 5)}
-        self.fpn_output = {l: self._conv(sd, f"backbone.fpn_output{l}", pad=1, bias=True) for l in (2, 3, 4, 5)}
+        self.fpn_lateral = {l: self._conv(sd, f"backbone.fpn_lateral{l}", bias=True, stage="fpn_lateral") for l in (2, 3, 4, 5)}
+        self.fpn_output = {l: self._conv(sd, f"backbone.fpn_output{l}", pad=1, bias=True, stage="fpn_output") for l in (2, 3, 4, 5)}
         rp = "proposal_generator.rpn_head."
-        self.rpn_conv = self._conv(sd, rp + "conv", pad=1, bias=True)
+        self.rpn_conv = self._conv(sd, rp + "conv", pad=1, bias=True, stage="rpn_conv")
         wobj, wdel = self._get(sd, rp + "objectness_logits.weight"), self._get(sd, rp + "anchor_deltas.weight")
         bobj, bdel = self._get(sd, rp + "objectness_logits.bias"), self._get(sd, rp + "anchor_deltas.bias")
-        self.rpn_pred = self._conv(sd, "", bias=True, weight=torch.cat([wobj, wdel], 0), bias_t=torch.cat([bobj, bdel], 0))
+        self.rpn_pred = self._conv(sd, "", bias=True, weight=torch.cat([wobj, wdel], 0), bias_t=torch.cat([bobj, bdel], 0), stage="rpn_pred")
         bh = "roi_heads.box_head."
         w1 = self._get(sd, bh + "fc1.weight")
         w1 = w1.view(w1.shape[0], 256, 7, 7).permute(0, 2, 3, 1).reshape(w1.shape[0], 12544, 1, 1)
-        self.fc1 = self._conv(sd, "", bias=True, weight=w1, bias_t=self._get(sd, bh + "fc1.bias"))
+        self.fc1 = self._conv(sd, "", bias=True, weight=w1, bias_t=self._get(sd, bh + "fc1.bias"), stage="fc1")
         w2 = self._get(sd, bh + "fc2.weight")
-        self.fc2 = self._conv(sd, "", bias=True, weight=w2[:, :, None, None], bias_t=self._get(sd, bh + "fc2.bias"))
+        self.fc2 = self._conv(sd, "", bias=True, weight=w2[:, :, None, None], bias_t=self._get(sd, bh + "fc2.bias"), stage="fc2")
         bp = "roi_heads.box_predictor."
         wc, wb = self._get(sd, bp + "cls_score.weight"), self._get(sd, bp + "bbox_pred.weight")
         bc, bb = self._get(sd, bp + "cls_score.bias"), self._get(sd, bp + "bbox_pred.bias")
         if wc.shape[0] != self.K + 1 or wb.shape[0] != 4 * self.K:
             raise ValueError(f"checkpoint has {wc.shape[0] - 1} classes, dataset metadata says {self.K}")
         self.box_pred = self._conv(sd, "", bias=True, weight=torch.cat([wc, wb], 0)[:, :, None, None],
-                                   bias_t=torch.cat([bc, bb], 0))
+                                   bias_t=torch.cat([bc, bb], 0), stage="box_pred")
         mh = "roi_heads.mask_head."
-        self.mask_fcn = [self._conv(sd, f"{mh}mask_fcn{i}", pad=1, bias=True) for i in range(1, 5)]
+        self.mask_fcn = [self._conv(sd, f"{mh}mask_fcn{i}", pad=1, bias=True, stage="mask_fcn") for i in range(1, 5)]
         wd = self._get(sd, mh + "deconv.weight")  # [Cin, Cout, 2, 2]
         wd = wd.permute(2, 3, 1, 0).reshape(4 * wd.shape[1], wd.shape[0], 1, 1)
-        self.deconv = self._conv(sd, "", bias=True, weight=wd, bias_t=self._get(sd, mh + "deconv.bias").repeat(4))
+        self.deconv = self._conv(sd, "", bias=True, weight=wd, bias_t=self._get(sd, mh + "deconv.bias").repeat(4), stage="deconv")
         self.mask_pred = self._conv(sd, mh + "predictor", bias=True)
         # f32 copy of the class predictor for the fused deconv + predictor launch of the f16x2 path (K <= 4 classes)
         self.mask_pred_w32 = self._get(sd, mh + "predictor.weight").reshape(-1, 256).to(self.device).contiguous()
@@ -547,14 +570,14 @@ class MaskRCNNEngine:
                                  (optr + c0 * (ld if out_f32 else L.cout) * 4) if optr else 0, ometa, L.wbound, L.bbound, cn, h, w, cin,
                                  ho, wo, L.cout, L.cout_pad, L.kh, L.kw, L.stride, L.pad, act, res_mode, 1 if out_f32 else 0, out_ld,
                                  tile_hint, hw_ptr, hb_ptr, (ho_ptr + c0 * (L.cout // 256) * hld * 4) if ho_ptr else 0, hn, hld, hact,
-                                 groups, group_rows, c0)
+                                 groups, group_rows, c0, L.single)
             _lib.check(self.lib.demia_conv2d_p32(C.byref(d), self._stream()), "demia_conv2d_p32")
         if ev is not None:
             e1.record(torch.cuda.current_stream(self.device))
             # every operand once (planes are 4 bytes per element, like f32): the algorithmic traffic
             nbytes = (n * h * w * cin * 4 + L.cout_pad * L.kh * L.kw * cin * 4 + n * ho * wo * L.cout * 4 +
                       (0 if residual is None else residual.pixels * residual.channels * 4))
-            ev.append((e0, e1, 2.0 * n * ho * wo * L.cout * L.kh * L.kw * cin, self.precision, nbytes))
+            ev.append((e0, e1, 2.0 * n * ho * wo * L.cout * L.kh * L.kw * cin, "f16" if L.single else self.precision, nbytes))
         return out
 
     def conv(self, x, L: ConvLayer, act=ACT_NONE, residual=None, res_mode=RES_NONE,
@@ -682,7 +705,7 @@ class MaskRCNNEngine:
                 x = self.new_p32((b, ph // 4, pw // 4, 64))
                 _lib.check(self.lib.demia_stem_pool_mfma(_lib.ptr(xin), _lib.ptr(self.stem_planes), _lib.ptr(self.stem_scale_mfma),
                                                          _lib.ptr(self.stem_bias), _lib.ptr(x.buf), _lib.ptr(x.meta), b, ph, pw, self.stem_s_in,
-                                                         p32.plane_scale(self.stem_bound), x.groups, st), "demia_stem_pool_mfma")
+                                                         p32.plane_scale(self.stem_bound), x.groups, int(self.single_plane), st), "demia_stem_pool_mfma")
                 mid = None
             else:
                 mid = self._scratch(b * (ph // 2) * (pw // 2) * 64, torch.float32)
@@ -697,7 +720,7 @@ class MaskRCNNEngine:
             if mid is not None:
                 x = self.new_p32((b, ph // 4, pw // 4, 64))
                 _lib.check(self.lib.demia_maxpool3x3s2_p32(_lib.ptr(mid), _lib.ptr(x.buf), _lib.ptr(x.meta), p32.plane_scale(self.stem_bound),
-                                                           b, ph // 2, pw // 2, 64, x.groups, st), "demia_maxpool3x3s2_p32")
+                                                           b, ph // 2, pw // 2, 64, x.groups, int(self.single_plane), st), "demia_maxpool3x3s2_p32")
         else:
             mid = torch.empty((b, ph // 2, pw // 2, 64), dtype=self.tdt, device=self.device)
             _lib.check(self.lib.demia_stem_conv(_lib.ptr(xin), _lib.ptr(self.stem_w), _lib.ptr(self.stem_scale),
@@ -766,7 +789,7 @@ class MaskRCNNEngine:
                 f = feats[name]
                 d.feat[i], d.meta[i] = _lib.ptr(f.buf), _lib.ptr(f.meta)
                 d.H[i], d.W[i] = f.shape[1], f.shape[2]
-            d.N, d.R, d.C, d.P, d.dtype, d.groups = b, r, 256, P, _lib.P32, out.groups
+            d.N, d.R, d.C, d.P, d.dtype, d.groups, d.single = b, r, 256, P, _lib.P32, out.groups, int(self.single_plane)
             d.boxes, d.count, d.out, d.out_meta = _lib.ptr(boxes), _lib.ptr(count), _lib.ptr(out.buf), _lib.ptr(out.meta)
             _lib.check(self.lib.demia_roi_align(C.byref(d), self._stream()), "demia_roi_align")
             return out
@@ -848,8 +871,6 @@ class MaskRCNNEngine:
         assert images.dtype == torch.uint8 and images.dim() == 4 and images.shape[3] == 3
         images = images.contiguous()
         b, h, w, _ = images.shape
-        if self.p32:
-            self.lib.demia_p32_single_plane(1 if self.single_plane else 0)     # read by the launchers of this forward
         self._amax_buf = None            # f16x2r: a fresh (zeroed) pool of |activation| bounds per forward
         xin, newh, neww, ph, pw = self.preprocess(images)
         feats = self.backbone(xin, ph, pw)

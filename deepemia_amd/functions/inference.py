@@ -253,6 +253,16 @@ class EmptyEnsembleTypeError(ValueError):
     """Reference behaviour N4: ``np.array([]) + [masks...]`` raises and the image is skipped."""
 
 
+class PeerImageFailure(RuntimeError):
+    """Multi-GPU: some rank's local passes of an image failed; raised on EVERY rank after the image's exchange, so all
+    ranks skip the image together (reference semantics per image: log, skip, continue -- inference.py:928-931)."""
+
+
+class OutputWriteError(RuntimeError):
+    """Rank 0's host-side output section (CSV / overlay writers, after the last collective) failed -- the one kind of
+    failure ``main.py`` reports to the other ranks through its status all-reduce instead of ending the process."""
+
+
 class InferencePipeline:
     def __init__(self, predictors: Sequence, dataset_name: str, inf_settings: dict, global_config: dict):
         self.predictors = list(predictors)
@@ -301,6 +311,7 @@ class InferencePipeline:
         import torch.distributed as dist
         self.rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
         self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        self.exchange = parallel.ExchangeState()     # this job's agreed capacities: every rank builds its pipeline at the same point
 
     # ------------------------------------------------------------------ predictor plumbing
     def forward_async(self, model_idx: int, images: torch.Tensor):
@@ -699,13 +710,17 @@ class InferencePipeline:
                                        self.soft_nms_sigma, self.soft_nms_score_threshold)
         return self.deduplicate_masks_smart(packed, list(full_scores) + list(tile_scores), list(full_classes) + list(tile_classes), 0.4)
 
-    def gather_and_merge(self, locals_by_class: Dict[int, tuple], hw: Tuple[int, int], ensemble_by_class: Dict[int, bool]):
+    def gather_and_merge(self, locals_by_class: Dict[int, tuple], hw: Tuple[int, int], ensemble_by_class: Dict[int, bool], status: int = 0):
         """The ONE exchange of the multi-GPU path, once per IMAGE: every rank contributes the class-tagged instance tables
         of all its local class passes (full-image pass on rank 0, its tiles), every rank receives the global table ordered
         by (unit id, local order) and runs the per-class 0.4 merges on it -- deterministic and identical everywhere.
         Rows of one class keep the reference's order (full image first, tiles in row-major order, detector order inside),
         because each rank appends its classes in the same order and the merge is stable.  Returns {class: (masks, scores,
-        classes)}; a class whose merge would raise in the reference (N4) maps to an ``EmptyEnsembleTypeError`` instance."""
+        classes)}; a class whose merge would raise in the reference (N4) maps to an ``EmptyEnsembleTypeError`` instance.
+
+        ``status`` != 0: this rank's local passes of the image FAILED (its ``locals_by_class`` is empty).  It still takes part
+        in the exchange, and every rank -- the failed one included -- raises :class:`PeerImageFailure` right after it, so the
+        image is skipped by all ranks together and the next image's exchange finds every rank at the same collective."""
         h, w = hw
         hdrs, pays = [], []
         for cls, (fm, fs, fc, tm, ts, tc, tu) in locals_by_class.items():
@@ -728,8 +743,10 @@ class InferencePipeline:
                 pays.append(pay)
         hdr = torch.cat(hdrs, dim=0) if hdrs else torch.zeros((0, parallel.HDR), dtype=torch.int32, device=self.dev)
         pay = torch.cat(pays, dim=0) if pays else torch.zeros((0,), dtype=torch.int32, device=self.dev)
-        gh, gp = parallel.all_gather_instance_tables(hdr, pay)
-        packed_all, s_all, c_all, u_all = parallel.decode_instance_table(gh, gp, h, w, self.dev)
+        gt = parallel.all_gather_instance_tables(hdr, pay, status=status, state=self.exchange)
+        if bool((gt.status != 0).any()):
+            raise PeerImageFailure(f"local passes failed on rank(s) {np.nonzero(gt.status)[0].tolist()}: every rank skips this image")
+        packed_all, s_all, c_all, u_all = parallel.decode_instance_table(gt.header, gt.payload, h, w, self.dev, host_header=gt.host_header, offsets=gt.offsets)
         out = {}
         c_arr, u_arr = np.asarray(c_all, dtype=np.int64), np.asarray(u_all, dtype=np.int64)
         for cls in locals_by_class:
@@ -1468,7 +1485,7 @@ def run_inference(dataset_name, output_dir, visualize=True, threshold=0.65, draw
         try:
             image_host = None
             parts, all_scores, all_classes = [], [], []
-            locals_by_class, ens_by_class = {}, {}
+            locals_by_class, ens_by_class, local_err = {}, {}, None
             targets = range(num_classes) if classes_to_infer is None else [c for c in classes_to_infer if c < num_classes]
             for target_class in targets:
                 is_small = target_class in small_classes
@@ -1483,11 +1500,18 @@ def run_inference(dataset_name, output_dir, visualize=True, threshold=0.65, draw
                 use_ens = ensemble_enabled and (not ensemble_small_only or is_small)
                 model_ids = list(range(len(predictors))) if (use_ens and len(predictors) > 1) else [0]
                 if pipe.world > 1:
-                    # local passes only; ONE all-gather per image after the class loop
-                    locals_by_class[target_class] = pipe._tile_pipeline_local(model_ids, name, image_dev, target_class, small_classes, conf,
-                                                                              tile_size, overlap_ratio, upscale_factor, iou_thresh,
-                                                                              edge_filter_enabled)
-                    ens_by_class[target_class] = len(model_ids) > 1
+                    # local passes only; ONE all-gather per image after the class loop.  A failure of THIS rank's passes
+                    # (a kernel error, out of memory on its tiles) must not make it skip that all-gather: it takes part with
+                    # an empty table and status 1, and every rank skips the image together (PeerImageFailure below)
+                    if local_err is None:
+                        try:
+                            locals_by_class[target_class] = pipe._tile_pipeline_local(model_ids, name, image_dev, target_class, small_classes, conf,
+                                                                                      tile_size, overlap_ratio, upscale_factor, iou_thresh,
+                                                                                      edge_filter_enabled)
+                            ens_by_class[target_class] = len(model_ids) > 1
+                        except Exception as e:
+                            system_logger.error(f"Rank {pipe.rank}: local passes of image {name} failed: {e}", exc_info=True)
+                            local_err = e
                     continue
                 m, s, c = pipe.tile_based_inference_pipeline(model_ids, name, image_dev, target_class, small_classes, conf,
                                                              tile_size, overlap_ratio, upscale_factor, iou_thresh,
@@ -1497,7 +1521,8 @@ def run_inference(dataset_name, output_dir, visualize=True, threshold=0.65, draw
                     all_scores.extend(s)
                     all_classes.extend(c)
             if pipe.world > 1:
-                merged = pipe.gather_and_merge(locals_by_class, (int(image_dev.shape[0]), int(image_dev.shape[1])), ens_by_class)
+                merged = pipe.gather_and_merge({} if local_err is not None else locals_by_class, (int(image_dev.shape[0]), int(image_dev.shape[1])),
+                                               ens_by_class, status=0 if local_err is None else 1)
                 for target_class in targets:
                     r = merged[target_class]
                     if isinstance(r, Exception):
@@ -1537,17 +1562,22 @@ def run_inference(dataset_name, output_dir, visualize=True, threshold=0.65, draw
         system_logger.warning(f"Unprocessed images: {sorted(unprocessed)}")
     if pipe.rank != 0:
         return dedup_results     # every rank holds the same merged result; rank 0 alone writes the output files
-    with open(os.path.join(output_dir, "R50_flip_results.csv"), "w", newline="") as f:
-        wri = csv.writer(f)
-        wri.writerow(["ImageId", "EncodedPixels"])
-        for a, b in zip(Img_ID, EncodedPixels):
-            wri.writerow([a, b])
+    try:     # rank 0's host-side output section: no collective below this line
+        with open(os.path.join(output_dir, "R50_flip_results.csv"), "w", newline="") as f:
+            wri = csv.writer(f)
+            wri.writerow(["ImageId", "EncodedPixels"])
+            for a, b in zip(Img_ID, EncodedPixels):
+                wri.writerow([a, b])
 
-    write_measurements(pipe.ops, dedup_results, inpath, output_dir, metadata, dataset_name, draw_scalebar, visualize)
-    with open(os.path.join(output_dir, "class_color_legend.txt"), "w") as f:
-        f.write("Class Color Legend (BGR)\n")
-        for i, cname in enumerate(metadata.thing_classes):
-            f.write(f"Class {i} ({cname}): {CLASS_COLORS[i % len(CLASS_COLORS)]}\n")
+        write_measurements(pipe.ops, dedup_results, inpath, output_dir, metadata, dataset_name, draw_scalebar, visualize)
+        with open(os.path.join(output_dir, "class_color_legend.txt"), "w") as f:
+            f.write("Class Color Legend (BGR)\n")
+            for i, cname in enumerate(metadata.thing_classes):
+                f.write(f"Class {i} ({cname}): {CLASS_COLORS[i % len(CLASS_COLORS)]}\n")
+    except Exception as e:
+        if pipe.world > 1:
+            raise OutputWriteError(f"writing the outputs failed on rank 0: {e}") from e
+        raise
     return dedup_results
 
 

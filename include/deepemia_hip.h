@@ -52,12 +52,15 @@ extern "C" {
 int demia_abi_version(void);
 const char* demia_last_error(void);
 const char* demia_build_arch(void);   /* "gfx950" */
-/* Flagged NON-parity switch behind `--precision f16` (process-wide; read by the launchers, so a captured graph keeps the
- * setting it was captured with): on != 0 -> every P32 producer (conv epilogue, max pool, ROIAlign) writes a ZERO low plane and
- * the conv kernel issues one MFMA per product instead of three -- fp16 operands, f32 accumulation: the arithmetic of the
- * reference's autocast predictor (inference.py:1390-1395).  on < 0 only queries.  Returns the previous setting. */
-int demia_p32_single_plane(int on);
-/* (the conv entry point of that mode: demia_conv2d_p32 forwards to it while the switch is on; same descriptor) */
+/* "product": what the default path runs -- the P32 conv kernel (f16x2 / f16), the exact-f32 conv kernel (the parity suite's control
+ * arithmetic), every non-conv kernel.  "dev" (`make DEV=1` -> libdeepemia_hip_dev.so, loaded with DEEPEMIA_DEV_LIB=1): also the
+ * kernels of the non-default precisions behind demia_conv2d_nhwc (f32x3, bf16x2, f16x2r, bf16) and the experimental tiles /
+ * schedules of the P32 kernel reachable through tile hints.  Same symbols in both. */
+const char* demia_build_flavor(void);
+/* Single-plane arithmetic is chosen PER LAUNCH (`single` of demia_conv_p32_desc / demia_roialign_desc, the `single` argument of
+ * the stem / pool entry points), never process-wide: engines of different precisions may share the library.
+ * (demia_conv2d_p32_single is the conv entry point demia_conv2d_p32 forwards to when d->single != 0: the same source compiled
+ * with one MFMA per product; same descriptor.) */
 struct demia_conv_p32_desc;
 int demia_conv2d_p32_single(const struct demia_conv_p32_desc* d, void* stream);
 
@@ -152,6 +155,11 @@ typedef struct demia_conv_p32_desc {
      * else is in the batch.  group_rows >= 128; row0 is the global index of this call's first output row when a tensor
      * goes through in several calls.                                                                                   */
     int32_t groups, group_rows, row0;
+    /* 0: f16x2 -- three MFMAs per product (the default, f32-sized error).  1: ONE MFMA per product on the high planes of both
+     * operands (fp16 operands, f32 accumulation: the arithmetic of the reference's autocast predictor, inference.py:1390-1395),
+     * output still split into both planes -- the per-stage precision map of DESIGN.md section 7 runs single stages this way.
+     * 2: as 1, and the output's low plane is written as zeros (`--precision f16`, flagged NON-parity, every layer).          */
+    int32_t single;
 } demia_conv_p32_desc;
 int demia_conv2d_p32(const demia_conv_p32_desc* d, void* stream);
 
@@ -192,12 +200,14 @@ int demia_stem_conv_mfma(const float* in, const void* w_planes, const float* sca
 /* ... and stem + max pool (3x3 s2 p1) in ONE kernel, P32 planes out: the f32 stem output is never written.  out / out_meta /
  * s_out / groups as demia_maxpool3x3s2_p32 (s_out = the planes' power-of-two scale from the a-priori bound of the stem output). */
 int demia_stem_pool_mfma(const float* in, const void* w_planes, const float* scale, const float* bias, void* out, float* out_meta,
-                         int N, int PH, int PW, float s_in, float s_out, int groups, void* stream);
+                         int N, int PH, int PW, float s_in, float s_out, int groups, int single, void* stream);
 int demia_maxpool3x3s2(const void* in, void* out, int N, int H, int W, int C, int dtype, void* stream);
 /* the same pool from an f32 input into a P32 buffer scaled with the power of two `s` (the caller derives it from the
  * stem's a-priori bound); out_meta receives {max |out| (atomic max; zero it first), s} -- one pair (groups <= 1) or one
- * per image (groups == N, see demia_conv_p32_desc).  C % 32 == 0. */
-int demia_maxpool3x3s2_p32(const float* in, void* out, float* out_meta, float s, int N, int H, int W, int C, int groups, void* stream);
+ * per image (groups == N, see demia_conv_p32_desc).  C % 32 == 0.  single != 0: the low plane is written as zeros
+ * (`--precision f16`, as in demia_conv_p32_desc.single = 2). */
+int demia_maxpool3x3s2_p32(const float* in, void* out, float* out_meta, float s, int N, int H, int W, int C, int groups, int single,
+                           void* stream);
 /* LastLevelMaxPool (kernel 1, stride 2): p6 = p5[:, ::2, ::2, :] */
 int demia_subsample2(const void* in, void* out, int N, int H, int W, int C, int dtype, void* stream);
 
@@ -245,6 +255,7 @@ typedef struct demia_roialign_desc {
     const float* meta[4];    /* dtype DEMIA_P32: {max |x|, s} of each level (device floats); else ignored */
     float* out_meta;         /* dtype DEMIA_P32: receives {max over the levels' max |x|, min over the levels' s} */
     int32_t groups;          /* dtype DEMIA_P32: <= 1 = one meta pair per tensor; N = metas are [N][2], one scale group per image */
+    int32_t single;          /* dtype DEMIA_P32: != 0 writes a zero low plane (`--precision f16`) */
 } demia_roialign_desc;
 int demia_roi_align(const demia_roialign_desc* d, void* stream);
 

@@ -131,7 +131,7 @@ def main(argv=None) -> int:
         if dist is not None:
             dist.destroy_process_group()
         return 1
-    from deepemia_amd.functions.inference import run_inference
+    from deepemia_amd.functions.inference import OutputWriteError, run_inference
 
     t0 = time.perf_counter()
     run_ok = True
@@ -139,12 +139,13 @@ def main(argv=None) -> int:
         run_inference(args.dataset_name, str(split_dir), visualize=args.visualize, threshold=args.threshold, draw_id=args.draw_id,
                       dataset_format=args.dataset_format, draw_scalebar=args.draw_scalebar)
         system_logger.info(f"Inference task finished in {time.perf_counter() - t0:.2f}s; results in {split_dir}")
-    except Exception:
-        if dist is None:
-            raise
-        # an exception of one rank outside the collectives (rank 0's output writers): tell the others instead of leaving them
-        # at the barrier below.  (An exception INSIDE the sharded loop is per image and handled there on every rank alike.)
-        system_logger.error("run_inference failed", exc_info=True)
+    except OutputWriteError:
+        # rank 0's output writers, AFTER the last collective of the image loop: tell the other ranks through the all-reduce
+        # below instead of leaving them at a barrier.  (A failure of one rank's share of an image is agreed on inside the
+        # image's own exchange -- every rank skips that image together, inference.py::PeerImageFailure.  Anything else -- set-up,
+        # a collective itself -- is NOT caught: the process ends non-zero and torchrun tears the job down, because a rank that
+        # carried on would meet its peers at the wrong collective.)
+        system_logger.error("run_inference failed while writing the outputs", exc_info=True)
         run_ok = False
     if dist is not None:
         import torch

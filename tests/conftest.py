@@ -32,3 +32,11 @@ def gpu_device():
     if not torch.cuda.is_available():
         pytest.fail("GPU test selected but no HIP device is visible")
     return "cuda:0"
+
+
+def needs_dev_build(precision: str = "") -> None:
+    """Skip unless the loaded library is the dev build (``make -C deepemia_amd/csrc DEV=1`` + ``DEEPEMIA_DEV_LIB=1``): the product
+    library computes f16x2 (default), f16 and exact f32 only."""
+    from deepemia_amd import _lib
+    if precision in ("", "f32x3", "f16x2r", "bf16x2", "bf16") and not _lib.is_dev_build():
+        pytest.skip(f"precision {precision or '(non-default)'} needs the dev build of the library (DEEPEMIA_DEV_LIB=1)")

@@ -24,7 +24,7 @@ def test_c_abi_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.demia_abi_version() == 4
+    assert lib.demia_abi_version() == 5
     assert lib.demia_build_arch() == b"gfx950"
     # struct sizes agree with the header's layout (no hidden padding surprises)
     assert ctypes.sizeof(_lib.ConvDesc) == 6 * 8 + 18 * 4 + 2 * 8     # + amax_in, amax_out

@@ -149,9 +149,9 @@ for step, n in enumerate((37, 30, 90)):
     hdr, pay = PL.encode_instance_table(packed, scores, classes, units, bbox.cpu().numpy(), area.cpu().numpy())
     assert hdr.is_cuda and pay.is_cuda
     before = dict(PL.stats)
-    gh, gp = PL.all_gather_instance_tables(hdr, pay)        # world 1, backend nccl: goes through RCCL on the device
-    assert gh.is_cuda and gp.is_cuda and PL.stats["exchanges"] == before["exchanges"] + 1
-    got, gs, gc, gu = PL.decode_instance_table(gh, gp, h, w, "cuda:0")
+    gt = PL.all_gather_instance_tables(hdr, pay)        # world 1, backend nccl: goes through RCCL on the device
+    assert gt.header.is_cuda and gt.payload.is_cuda and PL.stats["exchanges"] == before["exchanges"] + 1
+    got, gs, gc, gu = PL.decode_instance_table(gt.header, gt.payload, h, w, "cuda:0", host_header=gt.host_header, offsets=gt.offsets)
     order = np.argsort(units, kind="stable")
     assert gu == [int(u) for u in units[order]] and gc == [int(c) for c in classes[order]]
     assert gs == [float(s) for s in scores[order]]

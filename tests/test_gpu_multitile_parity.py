@@ -1,5 +1,5 @@
 """The headline configuration (BASELINE.json configs[1]: R101-FPN, 2048 x 2048 tiles, threshold 0.3, K = 2) under the
-oracle on EIGHT tiles, in the default ``f16x2`` arithmetic and -- as the control that separates "the fp16 split" from
+oracle on EIGHT tiles, in the default ``f16x2`` arithmetic (mask head on one MFMA per product) and -- as the control that separates "the fp16 split" from
 "fp32 sums taken in another order" -- in the exact-f32 MFMA kernel (``--precision f32``).
 
 What is asserted is what is true of an fp32-sized arithmetic difference against the fp32 CPU path (``oracle/maskrcnn_ref.py``
@@ -36,21 +36,19 @@ def oracle_tiles(gpu_device):
     return sd, tiles, refs
 
 
-def run_precision(sd, tiles, refs, precision, device):
+def run_precision(sd, tiles, refs, precision, device, single_stages=None, tag=None):
     from deepemia_amd.engine import MaskRCNNEngine
     from deepemia_amd.predictor import Predictor
     from oracle import tile_parity as TP
 
-    pred = Predictor(MaskRCNNEngine(sd, 101, 2, THR, device, precision))
+    pred = Predictor(MaskRCNNEngine(sd, 101, 2, THR, device, precision, single_stages=single_stages))
     rows = []
     for t, r in zip(tiles, refs):
         inst = pred(t)["instances"].to("cpu")
         boxes = inst.pred_boxes if torch.is_tensor(inst.pred_boxes) else inst.pred_boxes.tensor
         rows.append(TP.compare_predictor(r, boxes, inst.scores, inst.pred_classes, inst.pred_masks))
-    del pred
-    torch.cuda.empty_cache()
     masks = sum(r["instances"] for r in rows)
-    summary = dict(precision=precision, tiles=len(rows), masks=masks, masks_ge_0999=sum(r["masks_ge_0999"] for r in rows),
+    summary = dict(precision=precision, single_stages=sorted(pred.engine.single_stages), tiles=len(rows), masks=masks, masks_ge_0999=sum(r["masks_ge_0999"] for r in rows),
                    masks_identical=sum(r["masks_identical"] for r in rows),
                    tiles_in_oracle_order=sum(1 for r in rows if r["bijection"] and not r["moved_positions"]),
                    order_gap_max=max(r["order_gap_max"] for r in rows),
@@ -60,16 +58,21 @@ def run_precision(sd, tiles, refs, precision, device):
                    iou_min=min(r["iou_min"] if r["iou_min"] is not None else 0.0 for r in rows), per_tile=rows,
                    config=f"R101-FPN, synthetic 2048^2 tiles 0..{len(rows) - 1}, threshold {THR}, K=2, seeded random Detectron2-layout weights; "
                           "oracle = fp32 torch-CPU restatement (oracle/maskrcnn_ref.py)")
+    del pred
+    torch.cuda.empty_cache()
     os.makedirs("gpurun_out", exist_ok=True)
-    with open(f"gpurun_out/multitile_parity_{precision}.json", "w") as f:
+    with open(f"gpurun_out/multitile_parity_{tag or precision}.json", "w") as f:
         json.dump(summary, f, indent=1)
     return summary
 
 
-@pytest.mark.parametrize("precision", ["f16x2", "f32"])
+@pytest.mark.parametrize("precision", ["f16x2", "f16x2_three_mfmas_everywhere", "f32"])
 def test_eight_headline_tiles_against_the_oracle(oracle_tiles, gpu_device, precision):
+    """f16x2 = the product default (mask head single-plane, engine.DEFAULT_SINGLE_STAGES); the same with three MFMAs per
+    product in every stage; exact f32."""
     sd, tiles, refs = oracle_tiles
-    s = run_precision(sd, tiles, refs, precision, gpu_device)
+    full = precision == "f16x2_three_mfmas_everywhere"
+    s = run_precision(sd, tiles, refs, "f16x2" if full else precision, gpu_device, single_stages=() if full else None, tag=precision)
     print({k: v for k, v in s.items() if k != "per_tile"})
     for i, r in enumerate(s["per_tile"]):
         assert r["instances"] == r["instances_ref"] == 100, (i, r["instances"], r["instances_ref"])

