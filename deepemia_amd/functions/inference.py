@@ -355,42 +355,66 @@ class InferencePipeline:
         return raws, ev, (int(images.shape[1]), int(images.shape[2]))
 
     def finish_forward(self, handle) -> List[_Detections]:
-        raws, ev, (h, w) = handle
+        return self.finish_forwards([handle])[0]
+
+    def finish_forwards(self, handles) -> List[List[_Detections]]:
+        """The small tables of one or MANY enqueued forwards (an ensemble's models) in ONE device-to-host copy -- the wait
+        for the forwards themselves."""
         cur = torch.cuda.current_stream(self.dev)
-        cur.wait_event(ev)
-        out: List[_Detections] = []
-        for raw in raws:
-            # the forward allocated these on ITS stream; they are consumed on this one: tell the caching allocator, or a
-            # later forward could be handed the blocks while kernels of this stream still read them
-            for t in (raw.packed, raw.bbox, raw.scores, raw.classes, raw.valid, raw.count, raw.boxes):
-                if t is not None:
-                    t.record_stream(cur)
-            # ONE device-to-host copy for the forward's small tables (the wait for the forward itself)
-            nb, nd = int(raw.count.shape[0]), int(raw.scores.shape[1])
-            tab = torch.cat([raw.count.reshape(-1), raw.valid.reshape(-1).to(torch.int32), raw.scores.reshape(-1).view(torch.int32),
-                             raw.classes.reshape(-1)]).cpu().numpy()
-            self.d2h_waits += 1
-            counts = tab[:nb]
-            valid = tab[nb:nb + nb * nd].reshape(nb, nd).astype(bool)
-            scores = tab[nb + nb * nd:nb + 2 * nb * nd].view(np.float32).reshape(nb, nd)
-            classes = tab[nb + 2 * nb * nd:].reshape(nb, nd).astype(np.int64)
-            # ONE view object per forward: detections of the same forward are recognised by `base is base`
-            base = None if raw.bbox is None else raw.packed.view((-1,) + tuple(raw.packed.shape[2:]))
-            base_bbox = None if raw.bbox is None else raw.bbox.view(-1, 4)
-            for b in range(raw.count.shape[0]):
-                n = int(counts[b])
-                sel = np.nonzero(valid[b, :n])[0]
-                if len(sel) == n:
-                    packed, bbox = raw.packed[b, :n], (None if raw.bbox is None else raw.bbox[b, :n])
-                else:
-                    si = torch.from_numpy(sel).to(self.dev)
-                    packed, bbox = raw.packed[b, si], (None if raw.bbox is None else raw.bbox[b, si])
-                det = _Detections(packed, scores[b, :n][sel], classes[b, :n][sel], (h, w), bbox)
-                if base is not None:
-                    det.base, det.base_bbox = base, base_bbox
-                    det.base_idx = (b * int(raw.packed.shape[1]) + sel).astype(np.int64)
-                out.append(det)
-        return out
+        parts, shapes = [], []
+        for raws, ev, _ in handles:
+            cur.wait_event(ev)
+            for raw in raws:
+                # the forward allocated these on ITS stream; they are consumed on this one: tell the caching allocator, or a
+                # later forward could be handed the blocks while kernels of this stream still read them
+                for t in (raw.packed, raw.bbox, raw.scores, raw.classes, raw.valid, raw.count, raw.boxes):
+                    if t is not None:
+                        t.record_stream(cur)
+                parts += [raw.count.reshape(-1), raw.valid.reshape(-1).to(torch.int32), raw.scores.reshape(-1).view(torch.int32),
+                          raw.classes.reshape(-1)]
+                shapes.append((int(raw.count.shape[0]), int(raw.scores.shape[1])))
+        tab_all = torch.cat(parts).cpu().numpy()           # ONE copy for all forwards' tables
+        self.d2h_waits += 1
+        outs: List[List[_Detections]] = []
+        pos, si = 0, 0
+        for raws, _, (h, w) in handles:
+            out: List[_Detections] = []
+            for raw in raws:
+                nb, nd = shapes[si]
+                si += 1
+                tab = tab_all[pos:pos + nb + 3 * nb * nd]
+                pos += nb + 3 * nb * nd
+                counts = tab[:nb]
+                valid = tab[nb:nb + nb * nd].reshape(nb, nd).astype(bool)
+                scores = tab[nb + nb * nd:nb + 2 * nb * nd].view(np.float32).reshape(nb, nd)
+                classes = tab[nb + 2 * nb * nd:].reshape(nb, nd).astype(np.int64)
+                # ONE view object per forward: detections of the same forward are recognised by `base is base`
+                base = None if raw.bbox is None else raw.packed.view((-1,) + tuple(raw.packed.shape[2:]))
+                base_bbox = None if raw.bbox is None else raw.bbox.view(-1, 4)
+                for b in range(raw.count.shape[0]):
+                    n = int(counts[b])
+                    sel = np.nonzero(valid[b, :n])[0]
+                    if len(sel) == n:
+                        packed, bbox = raw.packed[b, :n], (None if raw.bbox is None else raw.bbox[b, :n])
+                    else:
+                        si_ = torch.from_numpy(sel).to(self.dev)
+                        packed, bbox = raw.packed[b, si_], (None if raw.bbox is None else raw.bbox[b, si_])
+                    det = _Detections(packed, scores[b, :n][sel], classes[b, :n][sel], (h, w), bbox)
+                    if base is not None:
+                        det.base, det.base_bbox = base, base_bbox
+                        det.base_idx = (b * int(raw.packed.shape[1]) + sel).astype(np.int64)
+                    out.append(det)
+            outs.append(out)
+        return outs
+
+    def _predict_batches(self, model_ids: Sequence[int], key: str, images: torch.Tensor) -> List[List[_Detections]]:
+        """:meth:`_predict_batch` for several models at once: the forwards that are not cached yet are all enqueued first and
+        their tables come over in ONE wait."""
+        todo = [m for m in model_ids if (m, key) not in self._cache]
+        if todo:
+            for m, d in zip(todo, self.finish_forwards([self.forward_async(m, images) for m in todo])):
+                self._cache[(m, key)] = d
+        return [self._cache[(m, key)] for m in model_ids]
 
     def _predict_batch(self, model_idx: int, key: str, images: torch.Tensor) -> List[_Detections]:
         """Forward a batch of equally sized images once per (model, key); every class reuses it."""
@@ -1095,34 +1119,47 @@ class InferencePipeline:
         smart dedup (``demia_host_dedup_smart``).  With the forward's own result that is three device-to-host waits per
         batch, whatever its size.  Same keep lists, masks and records as the host-loop version, which stays as its checker
         (``tests/test_gpu_parity_maskops.py``)."""
-        if len(model_ids) > 1:
-            return self.process_tile_batch_hostloops(key, tiles, small_classes, class_thresholds, spatial_cfg, um_pix, model_ids, dets)
-        if dets is None:
-            dets = self._predict_batch(model_ids[0], key, tiles)
+        ensemble = len(model_ids) > 1
         ops, dev, lib = self.ops, self.dev, self.ops.lib
         ops.set_frame_width(int(tiles.shape[2]))
-        T = len(dets)
-        out = [(None, [], [], []) for _ in range(T)]
-        self.last_batch_stats = [(np.zeros((0,), dtype=np.int64), np.zeros((0, 4), dtype=np.int64)) for _ in range(T)]
-        # ---- class passes: enqueue all, wait once ---------------------------------------------------------------
-        handles = [self._single_class_pass_launch(dets, cls, small_classes, conf) for cls, (conf, _) in class_thresholds.items()]
-        live = [h for h in handles if h is not None]
-        if not live:
-            return out
-        host = torch.cat([t_ for h in live for t_ in (h["ncols"], h["area"], h["bbox"].reshape(-1), h["I"].reshape(-1))]).cpu().numpy()
-        self.d2h_waits += 1
-        passes, pos = [], 0
-        for (cls, (_, iou_thr)), h in zip(class_thresholds.items(), handles):
+        if ensemble:
+            # the ensemble (a10 + a14 per class, inference.py:1464-1598) on the same three waits: (1) the tables of ALL models'
+            # forwards, (2) the class passes of all classes -- one gather per model, one stage program per class, ONE contour
+            # trace and ONE pair matrix over (class, tile) runs, fetched together -- and the native smart dedup per class,
+            # (3) the cross-class stage below, shared with the single-model path
+            dets_per_model = self._predict_batches(model_ids, key, tiles)
+            T = len(dets_per_model[0])
+            out = [(None, [], [], []) for _ in range(T)]
+            self.last_batch_stats = [(np.zeros((0,), dtype=np.int64), np.zeros((0, 4), dtype=np.int64)) for _ in range(T)]
+            h = self._ensemble_passes_launch(dets_per_model, class_thresholds, small_classes)
             if h is None:
-                continue
-            n, ld = h["n"], h["ld"]
-            tabs = dict(ncols=host[pos:pos + T], area=host[pos + T:pos + T + n].astype(np.int64),
-                        bbox=host[pos + T + n:pos + T + 5 * n].reshape(n, 4).astype(np.int64),
-                        I=np.ascontiguousarray(host[pos + T + 5 * n:pos + T + 5 * n + n * ld]).reshape(n, ld))
-            pos += T + 5 * n + n * ld
-            big, res, calg = self._single_class_pass_finish(h, tabs, cls in small_classes, iou_thr)
-            if any(len(k) for k, _ in res):
-                passes.append((cls, big, res, calg))
+                return out
+            passes = self._ensemble_passes_finish(h, class_thresholds, small_classes)
+        else:
+            if dets is None:
+                dets = self._predict_batch(model_ids[0], key, tiles)
+            T = len(dets)
+            out = [(None, [], [], []) for _ in range(T)]
+            self.last_batch_stats = [(np.zeros((0,), dtype=np.int64), np.zeros((0, 4), dtype=np.int64)) for _ in range(T)]
+            # ---- class passes: enqueue all, wait once ---------------------------------------------------------------
+            handles = [self._single_class_pass_launch(dets, cls, small_classes, conf) for cls, (conf, _) in class_thresholds.items()]
+            live = [h for h in handles if h is not None]
+            if not live:
+                return out
+            host = torch.cat([t_ for h in live for t_ in (h["ncols"], h["area"], h["bbox"].reshape(-1), h["I"].reshape(-1))]).cpu().numpy()
+            self.d2h_waits += 1
+            passes, pos = [], 0
+            for (cls, (_, iou_thr)), h in zip(class_thresholds.items(), handles):
+                if h is None:
+                    continue
+                n, ld = h["n"], h["ld"]
+                tabs = dict(ncols=host[pos:pos + T], area=host[pos + T:pos + T + n].astype(np.int64),
+                            bbox=host[pos + T + n:pos + T + 5 * n].reshape(n, 4).astype(np.int64),
+                            I=np.ascontiguousarray(host[pos + T + 5 * n:pos + T + 5 * n + n * ld]).reshape(n, ld))
+                pos += T + 5 * n + n * ld
+                big, res, calg = self._single_class_pass_finish(h, tabs, cls in small_classes, iou_thr)
+                if any(len(k) for k, _ in res):
+                    passes.append((cls, big, res, calg))
         total = sum(len(k) for _, _, res, _ in passes for k, _ in res)
         if total == 0:
             return out
@@ -1163,7 +1200,7 @@ class InferencePipeline:
         cset.launch_measure(um_pix, slots=4)
         ld2 = int(run_count.max())
         I2 = ops.pair_matrix(allp, bbox_dev, run_first, run_count, None, ld2)
-        (I2h,) = cset.fetch(extra=[I2])
+        (I2h,) = cset.fetch(extra=[I2], with_points=True)
         self.d2h_waits += 1
         per0 = cset.first_contour_perimeter()
         ok = (bbox_all[:, 0] >= 0) & ~((per0 > 0) & ((4 * np.pi * area_all) / np.where(per0 > 0, per0, 1.0) ** 2 < 0.15))
@@ -1186,7 +1223,7 @@ class InferencePipeline:
             keep = keep_out[tile_off[t]:tile_off[t] + keep_cnt[t]].tolist()
             gl = [k0[i] for i in keep]
             sc, cl = [scores_all[i] for i in gl], [int(classes_all[i]) for i in gl]
-            sc = [self._score_type(v) for v in sc]
+            sc = [float(v) for v in sc] if ensemble else [self._score_type(v) for v in sc]     # ensemble scores: f64 products
             if gl and spatial_cfg is not None and spatial_cfg.get("enabled", False):
                 if alg is None:                 # the containment / overlap rules ask for arbitrary pairs: the general algebra
                     alg = DeviceMaskAlgebra(ops, allp, area=area_all, bbox=bbox_all, blocks=tile_items)
@@ -1202,6 +1239,7 @@ class InferencePipeline:
         else:
             finalp = ops.gather_regions(allp, flat, bbox_all[flat])
         recs = cset.records(um_pix=um_pix, measure=True, select=flat)
+        self.d2h_waits += cset.blocking_point_copies       # (0 in the steady state: the points came with the fetch above)
         pos = 0
         self.last_batch_stats = [(area_all[final_idx[t]], bbox_all[final_idx[t]]) for t in range(T)]
         for t in range(T):
@@ -1210,6 +1248,108 @@ class InferencePipeline:
                 out[t] = (finalp[pos:pos + n], out[t][1], out[t][2], recs[pos:pos + n])
             pos += n
         return out
+
+    # ---- ensemble class passes of ALL classes over many tiles, in two halves like the single-model pass below
+    def _ensemble_passes_launch(self, dets_per_model: Sequence[Sequence[_Detections]], class_thresholds, small_classes):
+        ops = self.ops
+        M, T = len(dets_per_model), len(dets_per_model[0])
+        cls_list = list(class_thresholds.items())
+        zero = np.zeros((0,), dtype=np.int64)
+        sel = {}
+        for ci, (cls, (conf, _)) in enumerate(cls_list):
+            for t in range(T):
+                for m in range(M):
+                    det = dets_per_model[m][t]
+                    sel[(ci, t, m)] = np.nonzero((det.classes == cls) & (det.scores >= conf))[0] if len(det.scores) else zero
+        # gather MODEL-major (one launch per model: the sets of a model share its forward's table) ...
+        flat_dets, flat_sels, mm_off, pos = [], [], {}, 0
+        for m in range(M):
+            for ci in range(len(cls_list)):
+                for t in range(T):
+                    flat_dets.append(dets_per_model[m][t])
+                    flat_sels.append(sel[(ci, t, m)])
+                    mm_off[(ci, t, m)] = pos
+                    pos += len(sel[(ci, t, m)])
+        n = pos
+        if n == 0:
+            return None
+        packed_mm, bbox_mm = self._gather_selected(flat_dets, flat_sels)
+        # ... then ONE permuting gather into (class, tile, model) order: a (class, tile) run is contiguous and holds the
+        # reference's order inside a tile (model by model, detector order: inference.py:1510-1540)
+        perm = np.empty(n, dtype=np.int64)
+        scores = np.empty(n, dtype=np.float64)
+        run_first = np.empty(n, dtype=np.int32)
+        run_count = np.empty(n, dtype=np.int32)
+        cls_bounds, runs, pos = [], {}, 0
+        for ci in range(len(cls_list)):
+            c0 = pos
+            for t in range(T):
+                r0 = pos
+                for m in range(M):
+                    s_ = sel[(ci, t, m)]
+                    k = len(s_)
+                    perm[pos:pos + k] = mm_off[(ci, t, m)] + np.arange(k)
+                    scores[pos:pos + k] = dets_per_model[m][t].scores[s_].astype(np.float64) * float(self.ensemble_weights[m])
+                    pos += k
+                run_first[r0:pos] = r0
+                run_count[r0:pos] = pos - r0
+                runs[(ci, t)] = (r0, pos)
+            cls_bounds.append((c0, pos))
+        if np.array_equal(perm, np.arange(n)):
+            packed, bbox0 = packed_mm, bbox_mm
+        else:
+            pd = ops.upload(perm)
+            bbox0 = bbox_mm.index_select(0, pd)
+            packed = ops.gather_regions(packed_mm, pd, bbox0)
+        areas, boxes = [], []
+        for (cls, _), (c0, c1) in zip(cls_list, cls_bounds):
+            if c1 > c0:
+                a_, b_, _ = ops.program_(packed[c0:c1], ["fill", "erode"] if cls in small_classes else ["fill", "erode", "dilate"], bbox0[c0:c1])
+                areas.append(a_)
+                boxes.append(b_)
+        area = torch.cat(areas) if len(areas) > 1 else areas[0]
+        bbox = (torch.cat(boxes) if len(boxes) > 1 else boxes[0]).contiguous()
+        # (the masks' areas are not on the host yet: the point pool is sized from the mask count alone)
+        cset = ops.trace(packed, max_contours=256, bbox=bbox, max_points=int(min(4096 * n + (1 << 16), 1 << 26)))
+        ld = int(run_count.max())
+        I = ops.pair_matrix(packed, bbox, run_first, run_count, None, ld)
+        return dict(packed=packed, area=area, bbox=bbox, cset=cset, I=I, ld=ld, n=n, T=T, scores=scores, run_first=run_first,
+                    runs=runs, hw=dets_per_model[0][0].hw)
+
+    def _ensemble_passes_finish(self, h: dict, class_thresholds, small_classes):
+        n, T, ld = h["n"], h["T"], h["ld"]
+        area_h, bbox_h, I_h = h["cset"].fetch(extra=[h["area"].to(torch.int32), h["bbox"], h["I"]])      # THE wait of the class passes
+        self.d2h_waits += 1
+        per0 = h["cset"].first_contour_perimeter()
+        area = np.ascontiguousarray(area_h, dtype=np.int64)
+        bbox = np.ascontiguousarray(bbox_h.reshape(n, 4), dtype=np.int64)
+        I = np.ascontiguousarray(I_h.reshape(n, ld), dtype=np.int32)
+        area_img = h["hw"][0] * h["hw"][1]
+        scores, run_first = h["scores"], h["run_first"]
+        compact_bad = (per0 > 0) & ((4 * np.pi * area) / np.where(per0 > 0, per0, 1.0) ** 2 < 0.15)
+        passes = []
+        for ci, (cls, (_, iou_thr)) in enumerate(class_thresholds.items()):
+            min_size = max(3, int(area_img * 0.000005)) if cls in small_classes else max(25, int(area_img * 0.0001))
+            ok = (area >= min_size) & (bbox[:, 0] >= 0) & ~compact_bad
+            k0_all = [np.nonzero(ok[r0:r1])[0] + r0 for r0, r1 in (h["runs"][(ci, t)] for t in range(T))]
+            items = np.ascontiguousarray(np.concatenate(k0_all), dtype=np.int32) if k0_all else np.zeros((0,), dtype=np.int32)
+            if len(items) == 0:
+                continue
+            tile_off = np.concatenate(([0], np.cumsum([len(k) for k in k0_all]))).astype(np.int32)
+            keep_out = np.zeros(len(items), dtype=np.int32)
+            keep_cnt = np.zeros(T, dtype=np.int32)
+            sc_items = np.ascontiguousarray(scores[items])
+            cl_items = np.full(len(items), cls, dtype=np.int32)
+            _L.check(self.ops.lib.demia_host_dedup_smart(I.ctypes.data, ld, run_first.ctypes.data, area.ctypes.data, bbox.ctypes.data,
+                                                         items.ctypes.data, sc_items.ctypes.data, cl_items.ctypes.data, tile_off.ctypes.data, T,
+                                                         float(iou_thr), keep_out.ctypes.data, keep_cnt.ctypes.data), "demia_host_dedup_smart")
+            res = []
+            for t in range(T):
+                keep = keep_out[tile_off[t]:tile_off[t] + keep_cnt[t]]
+                gl = k0_all[t][keep]
+                res.append((gl.tolist(), scores[gl].tolist()))
+            passes.append((cls, h["packed"], res, _PassTables(area, bbox)))
+        return passes
 
     @staticmethod
     def _score_type(v):

@@ -317,6 +317,8 @@ class ContourSet:
         self.points = torch.empty((max_points, 2), dtype=torch.int32, device=dev)
         self.counters = torch.zeros((4,), dtype=torch.int32, device=dev)
         self._host = None
+        self._pts_host = None             # contour points brought over by fetch(with_points=True)
+        self.blocking_point_copies = 0    # times records() had to fetch the points with a device-to-host copy of its own
 
     def host(self):
         if self._host is None:
@@ -346,11 +348,14 @@ class ContourSet:
                                                  _lib.ptr(self.points), M, C, mp, _lib.ptr(self._wi), _lib.ptr(self._wf), _lib.ptr(self._wd),
                                                  float(um_pix), _lib.ptr(self._vals_dev), self._mslots, ops._stream()), "demia_contour_measure")
 
-    def fetch(self, extra: Optional[Sequence[torch.Tensor]] = None):
+    def fetch(self, extra: Optional[Sequence[torch.Tensor]] = None, with_points: bool = False):
         """ONE device-to-host wait for everything the host decides on: counters, contour counts, the first ``slots``
         contour slots of every mask (info, area / perimeter, measurement values when :meth:`launch_measure` ran) and the
         int32 device tensors in ``extra`` (returned as numpy arrays).  Falls back to the sliced copy of :meth:`host` when a
-        mask has more contours than the slots fetched."""
+        mask has more contours than the slots fetched.  ``with_points``: the contour POINTS come over in the same copy --
+        how many are in use is only known after the wait, so the copy takes as many as the previous trace of this
+        ``MaskOps`` used (+ 25 %); when that was too few (the first call of a job) :meth:`records` copies them itself and
+        counts it in ``blocking_point_copies``."""
         M = self.M
         k = getattr(self, "_mslots", 4)
         k = min(k, self.C)
@@ -360,6 +365,9 @@ class ContourSet:
             f64.append(self._vals_dev.reshape(-1))
         extra = list(extra or [])
         parts += [e.reshape(-1) for e in extra]
+        n_pts = min(int(getattr(self.ops, "_points_hint", 0)), self.max_points) if with_points else 0
+        if n_pts:
+            parts.append(self.points[:n_pts].reshape(-1))
         if sum(int(t.numel()) for t in parts) % 2:            # keep the float64 block 8-byte aligned in the host copy
             parts.append(torch.zeros((1,), dtype=torch.int32, device=self.ops.device))
         ints = torch.cat(parts)
@@ -373,6 +381,11 @@ class ContourSet:
         for e in extra:
             outs.append(host[pos:pos + e.numel()].reshape(tuple(e.shape)))
             pos += e.numel()
+        if with_points:
+            used = int(cnt[0])
+            if n_pts >= used:
+                self._pts_host = host[pos:pos + 2 * used].reshape(used, 2)
+            self.ops._points_hint = used + used // 4 + 4096
         d = host[int(ints.numel()):].view(np.float64)
         red = d[:M * k * 2].reshape(M, k, 2)
         if cnt[1] != 0:
@@ -429,7 +442,13 @@ class ContourSet:
         """Per (selected) mask the list of contour dicts in OpenCV's order (reverse raster order of the start)."""
         vals = self.measure(um_pix, select) if measure else None
         count, info, red, used = self.host()
-        pts = self.points[:used].cpu().numpy() if with_points else None
+        pts = None
+        if with_points:
+            if self._pts_host is not None and self._pts_host.shape[0] == used:
+                pts = self._pts_host                      # came over with fetch(with_points=True): no wait of its own
+            else:
+                pts = self.points[:used].cpu().numpy()
+                self.blocking_point_copies += 1
         out = []
         for m in (range(self.M) if select is None else select):
             recs = []

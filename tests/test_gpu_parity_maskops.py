@@ -660,3 +660,81 @@ def test_three_wait_tile_batch_equals_the_host_loop_version_on_adversarial_detec
         for j in range(i + 1, 40):
             if first[i] == first[j]:
                 assert mat2[i, j - first[i]] == (int((m[i] & m[j]).sum()) if lab[i] == lab[j] else 0)
+
+
+def test_ensemble_three_wait_tile_batch_equals_the_host_loop_version(gpu_device):
+    """The ENSEMBLE tile batch (a10 + a14 per class, reference inference.py:1464-1598) on the three-wait path -- tables of both
+    models' forwards in one copy, the class passes of all classes fetched in one wait (one permuting gather into (class, tile,
+    model) order, one contour trace, one pair matrix over (class, tile) runs, ``demia_host_dedup_smart`` per class), the shared
+    cross-class stage -- against ``process_tile_batch_hostloops`` (Python loops, ~15 waits) on two "models" whose detections
+    duplicate each other with jitter: weighted f64 scores, min-size and compactness drops, score ties across models, an empty
+    tile for one model, both classes.  Identical masks, scores, classes and contour records; two waits after the forwards."""
+    import types
+    from deepemia_amd.functions.inference import InferencePipeline, _Detections
+
+    dev = torch.device(gpu_device)
+    fake = types.SimpleNamespace(engine=types.SimpleNamespace(device=dev))
+    pipe = InferencePipeline([fake, fake], "t", {}, {})
+    ops = pipe.ops
+    size = 256
+    ops.set_frame_width(size)
+    g = np.random.default_rng(33)
+    yy, xx = np.mgrid[0:size, 0:size]
+
+    def blob(cx, cy, a, b, th):
+        u = (xx - cx) * np.cos(th) + (yy - cy) * np.sin(th)
+        v = -(xx - cx) * np.sin(th) + (yy - cy) * np.cos(th)
+        return (u / a) ** 2 + (v / b) ** 2 <= 1.0
+
+    T = 4
+    per_model = [[], []]
+    for t in range(T):
+        n = int(g.integers(12, 30))
+        base = [(g.uniform(25, size - 25), g.uniform(25, size - 25), g.uniform(3, 24), g.uniform(3, 18), g.uniform(0, np.pi)) for _ in range(n)]
+        cls = g.integers(0, 2, n)
+        for m in range(2):
+            masks, sc, cl = [], [], []
+            for i, (cx, cy, a, b, th) in enumerate(base):
+                if g.uniform() < 0.15:
+                    continue                                             # this model misses the object
+                j = g.uniform(-2.5, 2.5, 2)
+                mk = blob(cx + j[0], cy + j[1], a * g.uniform(0.9, 1.1), b * g.uniform(0.9, 1.1), th)
+                if i % 7 == 3:
+                    mk = mk & ((xx + yy) % 3 == 0)                       # a sieve: low compactness -> dropped by the 0.15 rule
+                if i % 9 == 4:
+                    mk = mk & ~blob(cx, cy, a * 0.4, b * 0.4, th)        # a hole: filled by the stage program
+                masks.append(mk)
+                sc.append(np.round(g.uniform(0.31, 0.99), 1 if i % 4 == 0 else 3))     # ties across models
+                cl.append(cls[i])
+            if t == 2 and m == 1:
+                masks, sc, cl = [], [], []                               # model 1 finds nothing on tile 2
+            per_model[m].append((np.stack(masks) if masks else np.zeros((0, size, size), dtype=bool),
+                                 np.asarray(sc, dtype=np.float32), np.asarray(cl, dtype=np.int64)))
+
+    def dets(m):
+        return [_Detections(ops.from_dense(mk) if len(mk) else torch.zeros((0, size, size // 32), dtype=torch.int32, device=dev), s_, c_, (size, size))
+                for mk, s_, c_ in per_model[m]]
+
+    x = torch.zeros((T, size, size, 3), dtype=torch.uint8, device=dev)
+    spatial = {"enabled": True, "containment_rules": {}, "overlap_rules": {0: {"allow_overlap": False, "max_iou_threshold": 0.3}}}
+    for k, (thr, sp) in enumerate((({0: (0.3, 0.7), 1: (0.3, 0.5)}, None), ({0: (0.4, 0.3), 1: (0.3, 0.4)}, spatial))):
+        pipe._cache[(0, f"a{k}")], pipe._cache[(1, f"a{k}")] = dets(0), dets(1)
+        pipe._cache[(0, f"b{k}")], pipe._cache[(1, f"b{k}")] = dets(0), dets(1)
+        w0 = pipe.d2h_waits
+        a = pipe.process_tile_batch(f"a{k}", x, {1}, thr, spatial_cfg=sp, um_pix=0.5, model_ids=(0, 1))
+        assert pipe.d2h_waits - w0 == 2                  # class passes of both classes, cross-class stage (+ the forwards' one = three)
+        b = pipe.process_tile_batch_hostloops(f"b{k}", x, {1}, thr, spatial_cfg=sp, um_pix=0.5, model_ids=(0, 1))
+        n_tot = 0
+        for t, ((pa, sa, ca, ra), (pb, sb, cb, rb)) in enumerate(zip(a, b)):
+            assert (pa is None) == (pb is None), t
+            assert [float(v) for v in sa] == [float(v) for v in sb] and list(ca) == list(cb), (t, sa, sb)
+            assert all(isinstance(v, float) for v in sa)                 # ensemble scores stay f64 products
+            if pa is None:
+                continue
+            assert torch.equal(pa, pb), t
+            n_tot += int(pa.shape[0])
+            for ia, ib in zip(ra, rb):
+                assert len(ia) == len(ib)
+                for u, v in zip(ia, ib):
+                    assert np.array_equal(u["points"], v["points"]) and u["area"] == v["area"] and np.array_equal(u["values"], v["values"])
+        assert n_tot > 25, n_tot
