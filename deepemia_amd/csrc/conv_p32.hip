@@ -70,6 +70,7 @@ struct ConvQ {
     int N, H, W, Cin, Ho, Wo, Cout, CoutPad, KH, KW, stride, pad;
     int act, res_mode, out_f32, out_ld;
     int M, HoWo, ntn, nwg, ksteps, taps;
+    int kloop;              // K-steps the kernel walks: ksteps, or ksteps / 2 in the h-only single-plane kernel (HK, 64 k per step)
     unsigned in_bytes, w_bytes;
     unsigned out_bytes, res_bytes;   // planes epilogue (EPI_PLANES): sizes of the output / residual buffers incl. their headers
     const float* head_w;    // fused 1x1 head (head_n > 0): [head_n][256] f32 weights applied to every 256-channel block of the
@@ -78,6 +79,7 @@ struct ConvQ {
     int head_n, head_ld, head_act;
     int groups, group_rows, row0;   // scale groups (images): in_meta / res_meta / out_meta are [groups][2]; output row m of this
                                     // call belongs to group (m + row0) / group_rows
+    int no_hk;              // single-plane build only (A/B switch DEMIA_P32_NO_HK=1): the plain K-step of 32 with both planes moved
     int zero_low;           // single-plane build only: write the output's low plane as zeros (demia_conv_p32_desc.single == 2)
     int stagger_ticks;      // > 0: the second half of the first resident set of workgroups starts this many 10-ns ticks late
     int resident;           // workgroups resident at once (256 CUs x workgroups per CU) -- for the stagger
@@ -643,9 +645,17 @@ __device__ __forceinline__ void p32_epilogue_head_direct(const ConvQ& p, const G
 
 constexpr int EPI_GENERIC = 0, EPI_PLANES = 1, EPI_HEAD = 2;
 
-template <int WM, int WN, int TM, int TN, bool M16 = true, int EPI = EPI_PLANES, int NST = 2>
+// HK (single-plane build only, Cin % 64 == 0): the K-step is 64 channels of ONE plane.  A single-plane product reads the high
+// planes only, and with the plain K-step half of every DMA'd line (the low halves) is dead weight: at one MFMA per product the
+// kernel is bound by the L2 -> LDS operand stream (10 TB/s over the chip at 666 TFLOP/s), not by the matrix pipe.  Here a
+// lane fetches the HIGH half of channel group g (chunks 0..3 of the LDS line) or of group g + 1 (chunks 4..7) -- 64 bytes out
+// of each of two adjacent 128-byte lines -- for A, and the high halves of weight K-steps (g, tap) and (g + 1, tap) for B: the
+// same MFMAs and fragment reads per product, HALF the DMA bytes and half the barriers.  The fragment addresses are the ones
+// the two-plane kernel uses for its planes (chunk = half * 4 + (lane >> 4)), so a stage is consumed as two K sub-steps.
+template <int WM, int WN, int TM, int TN, bool M16 = true, int EPI = EPI_PLANES, int NST = 2, bool HK = false>
 __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 2 : 1) void conv_p32_kernel(const ConvQ p) {
     static_assert(NST == 2 || NST == 3, "two or three LDS stages");
+    static_assert(!HK || (P32_SINGLE && M16 && NST == 2), "HK is a variant of the single-plane 16x16x32 kernel");
     // eight waves (two per SIMD, <= 256 registers each), or FOUR waves of a larger wave tile (one per SIMD, the whole
     // register file): a third less fragment traffic out of the LDS per output and half the barrier participants
     static_assert(WM * WN == 8 || (WM * WN == 4 && EPI == EPI_PLANES), "eight waves, or four (planes epilogue only)");
@@ -695,7 +705,8 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 2 : 1) void conv_p32_k
         const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
         const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
         const long pix = ((long)n * p.H + hi0) * p.W + wi0;
-        a_off[q] = (unsigned)(128 + pix * (long)(p.Cin * 4) + csw * 16);
+        // HK: source chunk c = high half of channel group g (c < 4) or g + 1 (c >= 4): 16 (c & 3) bytes into line g + (c >> 2)
+        a_off[q] = (unsigned)(128 + pix * (long)(p.Cin * 4) + (HK ? (csw >> 2) * 128 + (csw & 3) * 16 : csw * 16));
         unsigned mk = 0;
         for (int t = 0, th = 0, tw = 0; t < p.taps; ++t) {
             if (vm && (unsigned)(hi0 + th) < (unsigned)p.H && (unsigned)(wi0 + tw) < (unsigned)p.W) mk |= 1u << t;
@@ -708,7 +719,8 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 2 : 1) void conv_p32_k
         const int row = (wave + NW * q) * 8 + (lane >> 3);
         const int csw = (lane & 7) ^ ((row >> 1) & 7);
         const int co = n0 + row;
-        b_off[q] = (unsigned)(((co >> 6) * p.ksteps) * 8192 + (co & 63) * 128 + csw * 16);
+        // HK: the high half of weight K-step (g, tap) (c < 4) or (g + 1, tap) (c >= 4), `taps` K-steps further on
+        b_off[q] = (unsigned)(((co >> 6) * p.ksteps) * 8192 + (co & 63) * 128 + (HK ? (csw >> 2) * (p.taps * 8192) + (csw & 3) * 16 : csw * 16));
     }
     // K-step being REQUESTED: tap index, A byte offset of (tap, channel group), B byte offset -- all scalar
     int tap = 0, kw = 0, tstep = 0;
@@ -731,10 +743,11 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 2 : 1) void conv_p32_k
         }
     };
     const unsigned pixb = (unsigned)(p.Cin * 4), rowb = (unsigned)(p.W * p.Cin * 4);
+    // (tstep = the weight K-step being requested: HK walks channel groups in pairs, so it skips the second group's `taps` steps)
 #define P32_ADVANCE()                                                                   \
     do {                                                                                \
         ++tstep;                                                                        \
-        if (++tap == p.taps) { tap = 0; kw = 0; srow = 0; sgrp += 128u; sdelta = sgrp; } \
+        if (++tap == p.taps) { tap = 0; kw = 0; srow = 0; sgrp += HK ? 256u : 128u; sdelta = sgrp; if (HK) tstep += p.taps; } \
         else if (++kw == p.KW) { kw = 0; srow += rowb; sdelta = srow + sgrp; }          \
         else sdelta += pixb;                                                            \
     } while (0)
@@ -810,7 +823,30 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 2 : 1) void conv_p32_k
         }
         if (BARRIER_IN_COMPUTE) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
+    // HK: both halves of a stage line are high-plane K (k 0..31, 32..63): two MFMAs per tile, one per half
+    auto compute_hk = [&](int st) {
+        const char* sb = smem + st * STAGE;
+        f16x8 b0[2 * TN], b1[2 * TN];
+#pragma unroll
+        for (int j = 0; j < 2 * TN; ++j) {
+            b0[j] = *reinterpret_cast<const f16x8*>(sb + fb16[0] + j * 2048);
+            b1[j] = *reinterpret_cast<const f16x8*>(sb + fb16[1] + j * 2048);
+        }
+#pragma unroll
+        for (int i = 0; i < 2 * TM; ++i) {
+            const f16x8 a0 = *reinterpret_cast<const f16x8*>(sb + fa16[0] + i * 2048);
+            const f16x8 a1 = *reinterpret_cast<const f16x8*>(sb + fa16[1] + i * 2048);
+#pragma unroll
+            for (int j = 0; j < 2 * TN; ++j) {
+                f32x4 c = acc16[i][j];
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0[j], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1[j], c, 0, 0, 0);
+                acc16[i][j] = c;
+            }
+        }
+    };
     auto compute = [&](int st) {
+        if constexpr (HK) { compute_hk(st); return; }
         if constexpr (P32_SINGLE != 0) { compute1(st); return; }
         const char* sb = smem + st * STAGE;
         if constexpr (M16) {
@@ -972,7 +1008,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 2 : 1) void conv_p32_k
     issue(0, tap, sdelta, 0u);
     P32_ADVANCE();
     bool two_ahead = false;
-    if (NST == 3 && p.ksteps > 1 && !(P32_ABLATE & 128)) {
+    if (NST == 3 && p.kloop > 1 && !(P32_ABLATE & 128)) {
         issue(1, tap, sdelta, (unsigned)tstep * 8192u);
         P32_ADVANCE();
         two_ahead = true;
@@ -983,9 +1019,9 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 2 : 1) void conv_p32_k
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     int st = 0;
-    for (int t = 0; t < ((P32_ABLATE & 128) ? 1 : p.ksteps); ++t) {
+    for (int t = 0; t < ((P32_ABLATE & 128) ? 1 : p.kloop); ++t) {
         const int st_issue = NST == 2 ? (st ^ 1) : (st == 0 ? 2 : st - 1);      // (t + NST - 1) % NST
-        const bool more = t + NST - 1 < p.ksteps;
+        const bool more = t + NST - 1 < p.kloop;
         if (more) {                               // that stage was last read before the previous barrier
             issue(st_issue, tap, sdelta, (unsigned)tstep * 8192u);
             P32_ADVANCE();
@@ -1244,8 +1280,8 @@ int launch_pp(ConvQ p, hipStream_t st) {
 
 #endif  // P32_DEV_TILES
 
-template <int WM, int WN, int TM, int TN, bool M16 = true, int EPI = EPI_PLANES, int NST = 2>
-int launch_q(ConvQ p, hipStream_t st) {
+template <int WM, int WN, int TM, int TN, bool M16 = true, int EPI = EPI_PLANES, int NST = 2, bool HK = false>
+int launch_q_(ConvQ p, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     // LDS: the K-loop stages, overlaid in the epilogue by the accumulator image (planes epilogue: one 32-row block per wave)
     constexpr int stages = NST * (BM + BN) * 128, image = EPI == EPI_PLANES ? WM * WN * 32 * (TN * 128 + 16) : WM * 32 * (BN * 4 + 16);
@@ -1254,7 +1290,8 @@ int launch_q(ConvQ p, hipStream_t st) {
     p.ntn = p.CoutPad / BN;
     p.nwg = p.ntn * cdiv(p.M, BM);
     p.resident = 256 * (160 * 1024 / smem >= 2 ? 2 : 1);
-    auto k = conv_p32_kernel<WM, WN, TM, TN, M16, EPI, NST>;
+    p.kloop = HK ? p.ksteps / 2 : p.ksteps;
+    auto k = conv_p32_kernel<WM, WN, TM, TN, M16, EPI, NST, HK>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -1263,6 +1300,16 @@ int launch_q(ConvQ p, hipStream_t st) {
     hipLaunchKernelGGL(k, dim3(p.nwg), dim3(WM * WN * 64), smem, st, p);
     DEMIA_CHECK_LAUNCH("conv_p32_kernel");
     return DEMIA_OK;
+}
+// (single-plane build: layers whose channel count is a multiple of 64 take the h-only K-step of 64 -- half the operand stream)
+template <int WM, int WN, int TM, int TN, bool M16 = true, int EPI = EPI_PLANES, int NST = 2>
+int launch_q(ConvQ p, hipStream_t st) {
+#if P32_SINGLE
+    if constexpr (M16 && NST == 2) {
+        if (p.Cin % 64 == 0 && !p.no_hk) return launch_q_<WM, WN, TM, TN, M16, EPI, NST, true>(p, st);
+    }
+#endif
+    return launch_q_<WM, WN, TM, TN, M16, EPI, NST, false>(p, st);
 }
 
 // Tile choice: predicted launch time of every instantiated tile, from a four-parameter model fitted to a sweep of the
@@ -1335,6 +1382,11 @@ extern "C" int demia_conv2d_p32(const demia_conv_p32_desc* d, void* stream) {
     p.in_bytes = (unsigned)in_bytes; p.w_bytes = (unsigned)w_bytes;
     p.ntn = p.nwg = 0;
     p.zero_low = d->single == 2;
+    {
+        static const char* env = getenv("DEMIA_P32_NO_HK");
+        p.no_hk = (env && env[0] == '1') ? 1 : 0;
+    }
+    p.kloop = 0;
     p.resident = 256;
     p.groups = d->groups > 1 ? d->groups : 1;
     p.group_rows = p.groups > 1 ? d->group_rows : (1 << 29);

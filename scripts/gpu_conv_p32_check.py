@@ -237,6 +237,8 @@ def key_layers(hint=1, which='mfma'):
     out = []
     layers = {'mfma': [((16, 200, 200), 256, 256, 3, 0), ((16, 50, 50), 256, 256, 3, 0), ((1, 1, 16000), 12544, 1024, 1, 0),
                        ((16, 50, 50), 1024, 256, 1, 0)],
+              # the res4 bottleneck tail at the bench's 48 tiles: conv2 (3x3) and conv3 (1x1 + residual) -- the pair a fused kernel would replace
+              'res4': [((48, 50, 50), 256, 256, 3, 0), ((48, 50, 50), 256, 1024, 1, 1), ((48, 50, 50), 1024, 256, 1, 0)],
               'hbm': [((16, 50, 50), 256, 1024, 1, 1), ((16, 200, 200), 64, 256, 1, 1), ((16, 200, 200), 256, 256, 1, 1),
                       ((16, 100, 100), 128, 512, 1, 1)]}[which]
     for (n, h, w), cin, cout, k, rs in layers:

@@ -24,7 +24,7 @@ b = t(lambda: _lib.check(eng.lib.demia_stem_conv_mfma(_lib.ptr(xin), _lib.ptr(en
 from deepemia_amd import p32
 xp = p32.alloc((B, ph // 4, pw // 4, 64), 'cuda:0', groups=B)
 s_out = p32.plane_scale(eng.stem_bound)
-c = t(lambda: _lib.check(eng.lib.demia_maxpool3x3s2_p32(_lib.ptr(out), _lib.ptr(xp.buf), _lib.ptr(xp.meta), s_out, B, ph // 2, pw // 2, 64, B, st), 'c'))
-d = t(lambda: _lib.check(eng.lib.demia_stem_pool_mfma(_lib.ptr(xin), _lib.ptr(eng.stem_planes), _lib.ptr(eng.stem_scale_mfma), _lib.ptr(eng.stem_bias), _lib.ptr(xp.buf), _lib.ptr(xp.meta), B, ph, pw, eng.stem_s_in, s_out, B, st), 'd'))
+c = t(lambda: _lib.check(eng.lib.demia_maxpool3x3s2_p32(_lib.ptr(out), _lib.ptr(xp.buf), _lib.ptr(xp.meta), s_out, B, ph // 2, pw // 2, 64, B, 0, st), 'c'))
+d = t(lambda: _lib.check(eng.lib.demia_stem_pool_mfma(_lib.ptr(xin), _lib.ptr(eng.stem_planes), _lib.ptr(eng.stem_scale_mfma), _lib.ptr(eng.stem_bias), _lib.ptr(xp.buf), _lib.ptr(xp.meta), B, ph, pw, eng.stem_s_in, s_out, B, 0, st), 'd'))
 print(f'max pool (f32 -> P32) {c*1e3:.0f} us; fused stem + pool {d*1e3:.0f} us')
 print(f'B={B}: VALU stem {a*1e3:.0f} us, MFMA stem {b*1e3:.0f} us ({out.numel()*4/1e9:.2f} GB written)')

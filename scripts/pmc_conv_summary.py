@@ -48,7 +48,7 @@ assert len(fetch) == len(write) == len(sq) > 0, (len(fetch), len(write), len(sq)
 n = len(fetch)
 F = sum(d["FETCH_SIZE"] for d in fetch.values())
 W = sum(d["WRITE_SIZE"] for d in write.values())
-cmd = "python3 bench.py --forward-only --eager --steps 2 --warmup 1 --no-cpu-baseline --repeat-tiles"
+cmd = "python3 bench.py --forward-only --eager --steps 2 --warmup 1 --no-cpu-baseline --no-h2d-leg --tiles-cache /tmp/deepemia_tiles_cache (the bench's own two distinct 48-tile batches; generated tiles cached by an unprofiled run)"
 traffic = {"kernel": kernel, "head": head, "launches": n, "FETCH_SIZE_KiB_sum": F, "WRITE_SIZE_KiB_sum": W,
            "command": f"rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- {cmd}  ({prec}, B={batch}, R101, 2048^2)",
            "correction": "gfx950: FETCH_SIZE x2 for 16-B/lane reads (MI355X_MICROARCH.md, HBM); WRITE_SIZE exact; KiB -> bytes x1024",

@@ -108,9 +108,9 @@ def test_stem_on_the_matrix_pipe_equals_the_f32_stem(env, hw):
         s_out = p32.plane_scale(eng.stem_bound)
         two = p32.alloc((2, ph // 4, pw // 4, 64), env["dev"], groups=groups)
         fused = p32.alloc((2, ph // 4, pw // 4, 64), env["dev"], groups=groups)
-        _lib.check(eng.lib.demia_maxpool3x3s2_p32(_lib.ptr(b), _lib.ptr(two.buf), _lib.ptr(two.meta), s_out, 2, ph // 2, pw // 2, 64, groups, st), "pool")
+        _lib.check(eng.lib.demia_maxpool3x3s2_p32(_lib.ptr(b), _lib.ptr(two.buf), _lib.ptr(two.meta), s_out, 2, ph // 2, pw // 2, 64, groups, 0, st), "pool")
         _lib.check(eng.lib.demia_stem_pool_mfma(_lib.ptr(xin), _lib.ptr(eng.stem_planes), _lib.ptr(eng.stem_scale_mfma), _lib.ptr(eng.stem_bias),
-                                                _lib.ptr(fused.buf), _lib.ptr(fused.meta), 2, ph, pw, eng.stem_s_in, s_out, groups, st), "fused")
+                                                _lib.ptr(fused.buf), _lib.ptr(fused.meta), 2, ph, pw, eng.stem_s_in, s_out, groups, 0, st), "fused")
         assert torch.equal(fused.buf, two.buf) and torch.equal(fused.meta, two.meta), groups
         assert float(fused.meta[:, 0].min()) > 0.0
 
@@ -873,3 +873,51 @@ def test_rpn_two_pass_selection_equals_the_radix_passes_incl_ties(env, monkeypat
         assert torch.equal(a[2], b[2]) and int(a[2].min()) > 0, kind
         assert torch.equal(a[1], b[1]), kind
         assert torch.equal(a[0], b[0]), kind
+
+
+@pytest.mark.parametrize("case", [(256, 256, 3, 1, 1, 14, 14, 9, True), (256, 1024, 1, 1, 0, 1, 1, 700, True), (128, 64, 3, 2, 1, 33, 31, 2, False),
+                                  (64, 256, 1, 1, 0, 40, 40, 2, True), (96, 64, 3, 1, 1, 20, 20, 1, True)])
+def test_single_plane_conv_is_the_high_plane_product(env, case, monkeypatch):
+    """``demia_conv_p32_desc.single = 1`` (the mask head's default, engine.DEFAULT_SINGLE_STAGES): ONE fp16 MFMA per product on
+    the HIGH planes of both operands, f32 accumulation, output still split into both planes.  Checked against an f64
+    convolution of exactly those operands (half(x s) / s and half(w 2^e) / 2^e) -- the only error left is the f32 accumulation
+    order (<= 3e-6 of max |out|) -- for the h-only K-step of 64 (Cin % 64 == 0: half the operand stream) and for the plain
+    K-step of 32 (Cin = 96, or DEMIA_P32_NO_HK=1 in a subprocess-free way: a channel count that is no multiple of 64)."""
+    import torch.nn.functional as F
+    from deepemia_amd import engine as E, p32
+    from deepemia_amd._lib import ACT_RELU
+
+    cin, cout, k, stride, pad, h, w, n, relu = case
+    dev = env["dev"]
+    g = torch.Generator().manual_seed(7 * cin + cout + k)
+    x = (torch.randn((n, h, w, cin), generator=g) * 2.0).to(dev)
+    x[..., :5] *= 1e-3
+    wt = torch.randn((cout, cin, k, k), generator=g) / (cin * k * k) ** 0.5
+    scale = torch.rand((cout,), generator=g) + 0.5
+    bias = torch.randn((cout,), generator=g) * 0.1
+    eng = env["f16x2"]
+    cout_pad = (cout + 63) // 64 * 64
+    wp = torch.zeros((cout_pad, k, k, cin))
+    wp[:cout] = wt.permute(0, 2, 3, 1)
+    planes, sw = E.split2_f16_scaled(wp.to(dev))
+    L = E.ConvLayer(None, scale.to(dev), bias.to(dev), cin, cout, cout_pad, k, k, stride, pad, E.tile_weight_planes_p32(planes),
+                    (scale.to(dev) / sw[:cout]).contiguous(), float((scale.abs() * wt.abs().flatten(1).sum(1)).max()), float(bias.abs().max()), single=1)
+    xp = p32.from_f32(x)
+    out = eng.conv_p32(xp, L, act=ACT_RELU if relu else 0)
+    torch.cuda.synchronize()
+    got = p32.to_f32(out).double()
+    # the operands the kernel multiplies: high planes only
+    xh = xp.buf[p32.HEADER_HALFS:].view(-1, cin // 32, 2, 32)[:, :, 0, :].reshape(n, h, w, cin).double() / float(xp.meta[0, 1])
+    wh = (planes[0].double() / sw.double().view(-1, 1, 1, 1))[:cout].permute(0, 3, 1, 2)
+    ref = F.conv2d(xh.permute(0, 3, 1, 2), wh, None, stride, pad).permute(0, 2, 3, 1) * scale.double().to(dev) + bias.double().to(dev)
+    if relu:
+        ref = ref.clamp(min=0)
+    err = float((got - ref).abs().max() / ref.abs().max())
+    assert err < 3e-6, err
+    # and the single-plane product really is an 11-bit one: it differs from the two-plane result at the 1e-4 .. 1e-3 level
+    L3 = E.ConvLayer(**{**L.__dict__, "single": 0})
+    full = p32.to_f32(eng.conv_p32(xp, L3, act=ACT_RELU if relu else 0)).double()
+    d = float((got - full).abs().max() / full.abs().max())
+    assert 1e-5 < d < 5e-3, d
+    # the measured |out| bound the next layer scales with is exact
+    assert abs(float(out.meta[0, 0]) - float(got.abs().max())) <= 1e-5 * float(got.abs().max())
