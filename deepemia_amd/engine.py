@@ -921,14 +921,35 @@ class MaskRCNNEngine:
                             out = self.forward(static_in)
                     finally:
                         self._paste_static = None
+                    out._slot = (key, len(st["graphs"]))      # lets release_outputs find the slot these outputs live in
                     st["graphs"].append((g, static_in, out, planes, prev))
+            st["released"] = [None] * len(st["graphs"])
             cur.wait_stream(side)
             self._graphs[key] = st
-        g, static_in, out = st["graphs"][st["next"]][:3]
-        st["next"] = (st["next"] + 1) % len(st["graphs"])
+        slot = st["next"]
+        g, static_in, out = st["graphs"][slot][:3]
+        st["next"] = (slot + 1) % len(st["graphs"])
+        ev = st["released"][slot]
+        if ev is not None:
+            # the consumer of this slot's previous outputs said (release_outputs) after which point of ITS stream nothing reads
+            # them any more: the replay that overwrites them waits for that point, whatever the host did in between
+            cur.wait_event(ev)
+            st["released"][slot] = None
         static_in.copy_(images, non_blocking=True)
         g.replay()
         return out
+
+    def release_outputs(self, raw: RawDetections) -> None:
+        """Called by the consumer of a replayed forward's outputs, on the stream that reads them, once its LAST read of them is
+        enqueued: the next replay into the same slot waits for this point.  (No-op for eager results.)"""
+        slot = getattr(raw, "_slot", None)
+        if slot is None:
+            return
+        st = self._graphs.get(slot[0])
+        if st is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            st["released"][slot[1]] = ev
 
     def unpack(self, packed: torch.Tensor, h: int, w: int) -> torch.Tensor:
         """bit-packed [M, H, W/32] -> Detectron2's (M, H, W) bool."""

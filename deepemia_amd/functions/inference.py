@@ -240,6 +240,7 @@ class _Detections:
         self.base: Optional[torch.Tensor] = None
         self.base_bbox: Optional[torch.Tensor] = None
         self.base_idx: Optional[np.ndarray] = None
+        self.owner = None     # (engine, RawDetections) when `base` are a replayed forward's own planes read in place
 
 
 class _PassTables:
@@ -346,6 +347,11 @@ class InferencePipeline:
                         packed = r.packed.clone()
                     r = type(r)(r.boxes.clone(), r.scores.clone(), r.classes.clone(), r.valid.clone(), r.count.clone(), packed,
                                 r.height, r.width, None if r.bbox is None else r.bbox.clone())
+                elif getattr(r, "_slot", None) is not None:
+                    # the graph's own planes, read in place: consumers may only READ them (they stay zero outside the boxes the
+                    # next replay knows about), and they tell the engine when their last read is enqueued (release_outputs)
+                    self.ops.protect(r.packed)
+                    r._engine = pred.engine
                 raws.append(r)
             else:
                 raws.append(pred.engine.forward(chunk))
@@ -403,6 +409,8 @@ class InferencePipeline:
                     if base is not None:
                         det.base, det.base_bbox = base, base_bbox
                         det.base_idx = (b * int(raw.packed.shape[1]) + sel).astype(np.int64)
+                    if getattr(raw, "_engine", None) is not None:
+                        det.owner = (raw._engine, raw)
                     out.append(det)
             outs.append(out)
         return outs
@@ -415,6 +423,16 @@ class InferencePipeline:
             for m, d in zip(todo, self.finish_forwards([self.forward_async(m, images) for m in todo])):
                 self._cache[(m, key)] = d
         return [self._cache[(m, key)] for m in model_ids]
+
+    @staticmethod
+    def _release_forward_outputs(dets: Sequence[_Detections]) -> None:
+        """Every read of the forwards' own output planes behind ``dets`` is enqueued on the current stream: the replays that
+        overwrite those planes may run once this point of the stream is reached (``MaskRCNNEngine.release_outputs``)."""
+        seen = set()
+        for det in dets:
+            if det.owner is not None and id(det.owner[1]) not in seen:
+                seen.add(id(det.owner[1]))
+                det.owner[0].release_outputs(det.owner[1])
 
     def _predict_batch(self, model_idx: int, key: str, images: torch.Tensor) -> List[_Detections]:
         """Forward a batch of equally sized images once per (model, key); every class reuses it."""
@@ -1132,6 +1150,7 @@ class InferencePipeline:
             out = [(None, [], [], []) for _ in range(T)]
             self.last_batch_stats = [(np.zeros((0,), dtype=np.int64), np.zeros((0, 4), dtype=np.int64)) for _ in range(T)]
             h = self._ensemble_passes_launch(dets_per_model, class_thresholds, small_classes)
+            self._release_forward_outputs([d_ for dm in dets_per_model for d_ in dm])     # the gathers above were the last reads
             if h is None:
                 return out
             passes = self._ensemble_passes_finish(h, class_thresholds, small_classes)
@@ -1143,6 +1162,7 @@ class InferencePipeline:
             self.last_batch_stats = [(np.zeros((0,), dtype=np.int64), np.zeros((0, 4), dtype=np.int64)) for _ in range(T)]
             # ---- class passes: enqueue all, wait once ---------------------------------------------------------------
             handles = [self._single_class_pass_launch(dets, cls, small_classes, conf) for cls, (conf, _) in class_thresholds.items()]
+            self._release_forward_outputs(dets)       # the gathers of the class passes were the last reads of the forward's planes
             live = [h for h in handles if h is not None]
             if not live:
                 return out

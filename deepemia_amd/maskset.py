@@ -44,6 +44,22 @@ class MaskOps:
         self.lib = _lib.load()
         self.device = torch.device(device)
         self._frame_w = 0
+        self._points_hint = 0             # contour points the previous trace used (+ slack): sizes ContourSet.fetch(with_points=True)
+        self._protected = []              # (first byte, last byte) of planes the in-place ops must never touch (see protect)
+
+    def protect(self, planes: torch.Tensor) -> None:
+        """Register planes that consumers may only READ: a captured forward's own output planes stay zero outside the boxes its
+        next replay knows about (incremental paste), so an in-place stage on them would leave bits no replay ever clears."""
+        lo = int(planes.data_ptr())
+        rng = (lo, lo + planes.numel() * planes.element_size())
+        if rng not in self._protected:
+            self._protected.append(rng)
+
+    def _writable(self, packed: torch.Tensor, what: str) -> None:
+        p = int(packed.data_ptr())
+        for lo, hi in self._protected:
+            if lo <= p < hi:
+                raise RuntimeError(f"{what}: in-place stage on the read-only output planes of a captured forward -- gather a copy first")
 
     def set_frame_width(self, W: int) -> None:
         """True pixel width of the full-frame masks in flight.  Packed rows hold ceil(W / 32) words; kernels need
@@ -210,6 +226,7 @@ class MaskOps:
     def overlap_prefix_(self, packed: torch.Tensor, seg: Optional[torch.Tensor] = None,
                         bbox: Optional[torch.Tensor] = None) -> torch.Tensor:
         M, H, wpr = packed.shape
+        self._writable(packed, "overlap_prefix_")
         _lib.check(self.lib.demia_mask_overlap_prefix(_lib.ptr(packed), _lib.ptr(seg), _lib.ptr(bbox), M, H, self._w(packed),
                                                       self._stream()), "demia_mask_overlap_prefix")
         return packed

@@ -40,7 +40,7 @@ class Layer:
         self.bbound = float(self.bias.abs().max())
 
 
-def conv_p32(x: p32.P32, L: Layer, stride=1, pad=0, act=ACT_NONE, res=None, res_mode=RES_NONE, out_f32=False, out_ld=0, hint=0):
+def conv_p32(x: p32.P32, L: Layer, stride=1, pad=0, act=ACT_NONE, res=None, res_mode=RES_NONE, out_f32=False, out_ld=0, hint=0, single=0):
     n, h, w, cin = x.shape
     ho = (h + 2 * pad - L.kh) // stride + 1
     wo = (w + 2 * pad - L.kw) // stride + 1
@@ -55,6 +55,7 @@ def conv_p32(x: p32.P32, L: Layer, stride=1, pad=0, act=ACT_NONE, res=None, res_
                          _lib.ptr(res.buf) if res is not None else 0, _lib.ptr(res.meta) if res is not None else 0, optr, ometa,
                          L.wbound, L.bbound, n, h, w, cin, ho, wo, L.cout, L.cout_pad, L.kh, L.kw, stride, pad, act, res_mode,
                          1 if out_f32 else 0, out_ld, hint)
+    d.single = single
     _lib.check(lib.demia_conv2d_p32(C.byref(d), st()), 'demia_conv2d_p32')
     return out
 
@@ -252,7 +253,28 @@ def key_layers(hint=1, which='mfma'):
     print(os.environ.get('AB_LIB', 'default'), f'hint {hint} |', ' | '.join(out), flush=True)
 
 
+def single_sweep(B=48):
+    """The single-plane layers (mask head) at B tiles over every tile this build instantiates: which tile suits ONE MFMA per product."""
+    for name, (n, h, w), cin, cout, k in (('mask_fcn 3x3', (100 * B, 14, 14), 256, 256, 3), ('deconv 1x1', (1, 1, 19600 * B), 256, 1024, 1)):
+        L = Layer(cout, cin, k, k, seed=1)
+        xp = p32.from_f32(torch.randn(n, h, w, cin, device=dev))
+        fl = 2.0 * n * h * w * cout * cin * k * k
+        row = []
+        for hint in [0, 1, 2, 4, 6, 7, 9, 11, 12, 13] + ([3, 5, 8, 14, 42, 52, 49] if _lib.is_dev_build() else []):
+            for single in (1,):
+                try:
+                    t = min(timeit(lambda: conv_p32(xp, L, 1, k // 2, ACT_RELU, hint=hint, single=single), reps=4) for _ in range(2))
+                    row.append(f'{HINTS.get(hint, "auto")}={t*1e3:.0f}us/{fl/t/1e9:.0f}TF')
+                except Exception as e:
+                    row.append(f'{HINTS.get(hint, "auto")}=ERR')
+        t3 = min(timeit(lambda: conv_p32(xp, L, 1, k // 2, ACT_RELU, hint=0, single=0), reps=4) for _ in range(2))
+        print(f'{name} M={n*h*w} K={cin*k*k} N={cout}: three-MFMA auto {t3*1e3:.0f}us | single: ' + ' '.join(row), flush=True)
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'single':
+        single_sweep(int(sys.argv[2]) if len(sys.argv) > 2 else 48)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'key':
         key_layers(int(sys.argv[2]) if len(sys.argv) > 2 else 1, sys.argv[3] if len(sys.argv) > 3 else 'mfma')
         sys.exit(0)
