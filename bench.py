@@ -122,6 +122,9 @@ def main() -> None:
                     "several rounds per launch; 26 GiB of activations)")
     ap.add_argument("--precision", choices=["f32", "f32x3", "f16x2", "f16", "f16x2r", "bf16x2", "bf16"], default="f16x2",
                     help="f16x2 (default, parity); f16 = flagged NON-parity single-plane fp16 operands (the reference's autocast arithmetic)")
+    ap.add_argument("--single-stages", default="", help="(flagged NON-parity opt-in) comma list of stages of the f16x2 forward on ONE MFMA per "
+                    "product, e.g. mask_fcn,deconv: holds the eight-tile headline parity record, fails a soft-mask CLI parity case "
+                    "(DESIGN.md section 7)")
     ap.add_argument("--depth", type=int, default=101)
     ap.add_argument("--size", type=int, default=2048)
     ap.add_argument("--threshold", type=float, default=0.3)
@@ -198,7 +201,8 @@ def main() -> None:
     for li in range(args.lanes):
         # a lane = one software pipeline (forward of batch i + L under the post-processing of batch i): its own engine, i.e. its
         # own intermediates arena and hipGraphs (the weights are duplicated: 0.5 GB), its own plane pools, streams and host thread
-        e_ = MaskRCNNEngine(sd, args.depth, 2, args.threshold, dev, args.precision, args.min_size_test, args.max_size_test)
+        e_ = MaskRCNNEngine(sd, args.depth, 2, args.threshold, dev, args.precision, args.min_size_test, args.max_size_test,
+                            single_stages=tuple(t for t in args.single_stages.split(",") if t) if args.single_stages else None)
         p_ = InferencePipeline([Predictor(e_)], f"bench{li}", {}, {})
         p_.use_graphs = bool(args.graph)
         p_.graph_after = 1
@@ -498,8 +502,8 @@ def main() -> None:
         all_conv_ms = sum(e[0].elapsed_time(e[1]) for e in events)
         # the dominant kernel = the conv kernel of the run's precision (f32x3: conv_igemm_split_kernel; the few layers
         # whose shape it does not take -- 15 / 11 / 2 output channels -- run on the exact-f32 kernel and are left out)
-        # (f16x2: the launches of the stages that run single-plane by default -- the mask head, engine.DEFAULT_SINGLE_STAGES --
-        # are the same kernel with one MFMA per product; they carry the kind "f16" and are priced against the native fp16 peak)
+        # (f16x2 with --single-stages: the launches of the opted-in stages are the same kernel with one MFMA per product; they
+        # carry the kind "f16" and are priced against the native fp16 peak)
         kinds = {args.precision} | ({"f16"} if args.precision == "f16x2" else set())
         dom = [e for e in events if e[3] in kinds]
         conv_ms = sum(e[0].elapsed_time(e[1]) for e in dom)
@@ -539,6 +543,7 @@ def main() -> None:
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": ("NON-PARITY single-plane fp16 arithmetic (flagged mode, parity bar not met -- see parity): " if args.precision == "f16" else "") +
+                                   (f"FLAGGED opt-in, not the product default: stages {sorted(eng.single_stages)} on one MFMA per product: " if eng.single_stages else "") +
                                    ("NON-PARITY native-resolution mode, not configs[1]: " if native else
                                     (f"configs[4] (a job of {args.total_tiles} distinct tiles per GPU, {args.steps} steps): " if args.total_tiles else
                                      f"configs[1] ({len(xs)} distinct resident batches taken in turn): ")) +
@@ -561,7 +566,7 @@ def main() -> None:
                                                      "per product; peak = bf16 dense peak / 6)" if args.precision == "f32x3" else
                                                      "conv_p32_kernel (implicit-GEMM conv, both operands as 2 pre-scaled fp16 planes moved by LDS-DMA, "
                                                      "3 fp16 MFMAs per product: roof = fp16 dense peak / 3" +
-                                                     (f"; {single_launches} of the {launches} timed launches -- the mask head -- run ONE MFMA per product on the "
+                                                     (f"; {single_launches} of the {launches} timed launches (--single-stages) run ONE MFMA per product on the "
                                                       "high planes: roof = fp16 dense peak; `peak` = the FLOP-weighted roof of the mix)" if single_launches else ")")
                                                      if args.precision == "f16x2" else
                                                      "conv_p32_kernel in its flagged single-plane mode (fp16 operands, ONE fp16 MFMA per product, zero low "

@@ -50,6 +50,15 @@
 #define P32_DEV_TILES 0   // 1: also instantiate the experimental tiles / schedules reachable through tile hints only (ping-pong
                           // kernel, three LDS stages, 32x32x16 MFMAs, alternative wave grids): dev builds for same-box A/B
 #endif
+#ifndef P32_ST_AUX
+#define P32_ST_AUX 0      // cache policy of the epilogue's plane stores (raw buffer `aux`: 2 = nt, streaming) -- A/B builds
+#endif
+#ifndef P32_RES_AUX
+#define P32_RES_AUX 0     // ... of its residual loads
+#endif
+#ifndef P32_A_NT
+#define P32_A_NT 0        // 1: the A-operand LDS-DMA of 1x1 layers carries `nt` (every line is read once per column tile)
+#endif
 #ifndef P32_FRAG_PIPE
 #define P32_FRAG_PIPE 0   // 1: A fragments double-buffered in registers, reads of tile-row i + 1 pinned in front of the MFMAs of row i
 #endif
@@ -112,6 +121,11 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void dma16(const i32x4 rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void dma16_nt(const i32x4 rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen nt lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
 __device__ __forceinline__ i32x4 make_rsrc(const void* base, unsigned bytes) {
@@ -474,8 +488,8 @@ __device__ __forceinline__ void p32_epilogue_planes(const ConvQ& p, const GroupS
         for (int k = 0; k < ITEMS; ++k) {
             const int mp = row_of(i, k) - rs;                // row r of the pair
             if (P32_ABLATE & 32) { rh[k] = u32x4{0, 0, 0, 0}; rl[k] = rh[k]; continue; }
-            rh[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, res_off(mp), 0, 0);
-            rl[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, res_off(mp + 1), 0, 0);
+            rh[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, res_off(mp), 0, P32_RES_AUX);
+            rl[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, res_off(mp + 1), 0, P32_RES_AUX);
         }
     };
     float vmax0 = 0.f, vmax1 = 0.f, vmax2 = 0.f;
@@ -550,8 +564,8 @@ __device__ __forceinline__ void p32_epilogue_planes(const ConvQ& p, const GroupS
             if (P32_ABLATE & 64) {
                 asm volatile("" :: "v"(d0), "v"(d1), "v"(off));
             } else {
-                __builtin_amdgcn_raw_buffer_store_b128(d0, rs_out, off, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(d1, rs_out, off + cbytes, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(d0, rs_out, off, 0, P32_ST_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(d1, rs_out, off + cbytes, 0, P32_ST_AUX);
             }
         }
     }
@@ -725,6 +739,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 2 : 1) void conv_p32_k
     // K-step being REQUESTED: tap index, A byte offset of (tap, channel group), B byte offset -- all scalar
     int tap = 0, kw = 0, tstep = 0;
     unsigned sdelta = 0, srow = 0, sgrp = 0;
+    const bool a_nt = P32_A_NT && p.taps == 1 && p.ntn == 1;      // (block-uniform)
     auto issue = [&](int st, int tp, unsigned sd, unsigned bd) {
         const unsigned sbase = __builtin_amdgcn_readfirstlane(lds0 + st * STAGE + wave * 1024);
         const bool first = bd < 2 * 8192u;
@@ -734,7 +749,8 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 2 : 1) void conv_p32_k
             if (!A_EVEN && q == QA - 1 && wave + NW * q >= NIA) break;
             const bool ok = (a_msk[q] >> tp) & 1u;
             const unsigned vo = ok ? a_off[q] + sd : (a_off[q] & 0x70u);     // padding taps / rows beyond M: the zero header
-            dma16(rsrc_a, sbase + q * (NW * 1024), vo, 0u);
+            if (P32_A_NT && a_nt) dma16_nt(rsrc_a, sbase + q * (NW * 1024), vo, 0u);
+            else dma16(rsrc_a, sbase + q * (NW * 1024), vo, 0u);
         }
 #pragma unroll
         for (int q = 0; q < QB; ++q) {
@@ -1333,6 +1349,11 @@ inline double predict_us(const TileCfg& c, long M, int cout_pad, int ksteps, boo
 }
 
 inline int choose_tile(long M, int cout_pad, int ksteps, bool residual, bool need256 = false) {
+#if P32_SINGLE
+    // one MFMA per product: the launch is bound by the operand stream, which the 256 x 256 tile uses best (mask-head 3x3 at 48
+    // tiles: 1236 us against 1256-2022 us for the other shapes, gpu_conv_p32_check.py single) -- wherever it fills the chip twice
+    if (cout_pad % 256 == 0 && (long)cdiv(M, 256) * (cout_pad / 256) >= 512) return 1;
+#endif
     int best = 0;
     double best_t = 1e30;
     for (const TileCfg& c : kTiles) {

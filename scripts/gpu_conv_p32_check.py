@@ -240,6 +240,7 @@ def key_layers(hint=1, which='mfma'):
                        ((16, 50, 50), 1024, 256, 1, 0)],
               # the res4 bottleneck tail at the bench's 48 tiles: conv2 (3x3) and conv3 (1x1 + residual) -- the pair a fused kernel would replace
               'res4': [((48, 50, 50), 256, 256, 3, 0), ((48, 50, 50), 256, 1024, 1, 1), ((48, 50, 50), 1024, 256, 1, 0)],
+              'hbm48': [((48, 200, 200), 64, 256, 1, 1), ((48, 100, 100), 128, 512, 1, 1), ((48, 200, 200), 256, 64, 1, 0), ((48, 25, 25), 512, 2048, 1, 1)],
               'hbm': [((16, 50, 50), 256, 1024, 1, 1), ((16, 200, 200), 64, 256, 1, 1), ((16, 200, 200), 256, 256, 1, 1),
                       ((16, 100, 100), 128, 512, 1, 1)]}[which]
     for (n, h, w), cin, cout, k, rs in layers:
