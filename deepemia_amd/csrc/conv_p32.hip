@@ -88,7 +88,6 @@ struct ConvQ {
     int head_n, head_ld, head_act;
     int groups, group_rows, row0;   // scale groups (images): in_meta / res_meta / out_meta are [groups][2]; output row m of this
                                     // call belongs to group (m + row0) / group_rows
-    int nt_epi;             // planes epilogue with the streaming cache policy (see p32_epilogue_planes NT)
     int no_hk;              // single-plane build only (A/B switch DEMIA_P32_NO_HK=1): the plain K-step of 32 with both planes moved
     int zero_low;           // single-plane build only: write the output's low plane as zeros (demia_conv_p32_desc.single == 2)
     int stagger_ticks;      // > 0: the second half of the first resident set of workgroups starts this many 10-ns ticks late
@@ -409,14 +408,9 @@ __device__ __forceinline__ void p32_epilogue(const ConvQ& p, const GroupScales& 
 // memory instructions and the waits are counted: a pass waits for ITS residual lines only, not -- as with stores inside
 // `if (m < M)` branches, where the count is unknown and the wait becomes vmcnt(0) -- for the previous pass's stores to be
 // acknowledged by the L2.  That acknowledgement was the longest stall of every short-K (HBM-bound) layer.
-// NT: residual loads and plane stores carry the streaming cache policy (`nt`).  Chosen by the host for residual layers whose
-// output is larger than the 256 MiB Infinity Cache: both tensors are touched once per launch, and without `nt` their lines evict
-// the A rows that the other column tiles of the same rows are about to read (res4 conv3 at 48 tiles 333 -> 309 us, res3 conv3
-// 489 -> 448 us, same box; no effect on K = 64, none wanted where the next layer finds the output in the cache).
-template <int WM, int WN, int TM, int TN, bool NT, typename WriteRow>
+template <int WM, int WN, int TM, int TN, typename WriteRow>
 __device__ __forceinline__ void p32_epilogue_planes(const ConvQ& p, const GroupScales& gs, char* smem, WriteRow&& write_tile_row, int wm, int wn,
                                                     int m0, int n0) {
-    constexpr int ST_AUX = NT ? 2 : P32_ST_AUX, RES_AUX = NT ? 2 : P32_RES_AUX;
     constexpr int BM_ = WM * TM * 32;
     const int tid = threadIdx.x, lane = tid & 63;
     // WAVE-LOCAL passes: a wave takes the 32 x (TN * 32) block of ITS OWN accumulators through ITS OWN piece of LDS and
@@ -494,8 +488,8 @@ __device__ __forceinline__ void p32_epilogue_planes(const ConvQ& p, const GroupS
         for (int k = 0; k < ITEMS; ++k) {
             const int mp = row_of(i, k) - rs;                // row r of the pair
             if (P32_ABLATE & 32) { rh[k] = u32x4{0, 0, 0, 0}; rl[k] = rh[k]; continue; }
-            rh[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, res_off(mp), 0, RES_AUX);
-            rl[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, res_off(mp + 1), 0, RES_AUX);
+            rh[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, res_off(mp), 0, P32_RES_AUX);
+            rl[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, res_off(mp + 1), 0, P32_RES_AUX);
         }
     };
     float vmax0 = 0.f, vmax1 = 0.f, vmax2 = 0.f;
@@ -570,8 +564,8 @@ __device__ __forceinline__ void p32_epilogue_planes(const ConvQ& p, const GroupS
             if (P32_ABLATE & 64) {
                 asm volatile("" :: "v"(d0), "v"(d1), "v"(off));
             } else {
-                __builtin_amdgcn_raw_buffer_store_b128(d0, rs_out, off, 0, ST_AUX);
-                __builtin_amdgcn_raw_buffer_store_b128(d1, rs_out, off + cbytes, 0, ST_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(d0, rs_out, off, 0, P32_ST_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(d1, rs_out, off + cbytes, 0, P32_ST_AUX);
             }
         }
     }
@@ -672,9 +666,8 @@ constexpr int EPI_GENERIC = 0, EPI_PLANES = 1, EPI_HEAD = 2;
 // of each of two adjacent 128-byte lines -- for A, and the high halves of weight K-steps (g, tap) and (g + 1, tap) for B: the
 // same MFMAs and fragment reads per product, HALF the DMA bytes and half the barriers.  The fragment addresses are the ones
 // the two-plane kernel uses for its planes (chunk = half * 4 + (lane >> 4)), so a stage is consumed as two K sub-steps.
-template <int WM, int WN, int TM, int TN, bool M16 = true, int EPI = EPI_PLANES, int NST = 2, bool HK = false, bool NT = false>
+template <int WM, int WN, int TM, int TN, bool M16 = true, int EPI = EPI_PLANES, int NST = 2, bool HK = false>
 __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 2 : 1) void conv_p32_kernel(const ConvQ p) {
-    static_assert(!NT || EPI == EPI_PLANES, "the streaming policy belongs to the planes epilogue");
     static_assert(NST == 2 || NST == 3, "two or three LDS stages");
     static_assert(!HK || (P32_SINGLE && M16 && NST == 2), "HK is a variant of the single-plane 16x16x32 kernel");
     // eight waves (two per SIMD, <= 256 registers each), or FOUR waves of a larger wave tile (one per SIMD, the whole
@@ -1065,9 +1058,9 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 2 : 1) void conv_p32_k
 
     if constexpr (EPI == EPI_PLANES) {
         if constexpr (M16) {
-            p32_epilogue_planes<WM, WN, TM, TN, NT>(p, gs, smem, [&](int i, float* e) { write_acc16<TN, TN * 32 + 4>(acc16[2 * i], acc16[2 * i + 1], e, lane); }, wm, wn, m0, n0);
+            p32_epilogue_planes<WM, WN, TM, TN>(p, gs, smem, [&](int i, float* e) { write_acc16<TN, TN * 32 + 4>(acc16[2 * i], acc16[2 * i + 1], e, lane); }, wm, wn, m0, n0);
         } else {
-            p32_epilogue_planes<WM, WN, TM, TN, NT>(p, gs, smem, [&](int i, float* e) { write_acc32<TN, TN * 32 + 4>(acc[i], e, lane); }, wm, wn, m0, n0);
+            p32_epilogue_planes<WM, WN, TM, TN>(p, gs, smem, [&](int i, float* e) { write_acc32<TN, TN * 32 + 4>(acc[i], e, lane); }, wm, wn, m0, n0);
         }
     } else if constexpr (M16 && HEAD && P32_HEAD_DIRECT) {
         // (block-uniform) the layer's own activation is ReLU / none and the head has at most 2 rows (K = 2 classes): straight from
@@ -1303,7 +1296,7 @@ int launch_pp(ConvQ p, hipStream_t st) {
 
 #endif  // P32_DEV_TILES
 
-template <int WM, int WN, int TM, int TN, bool M16 = true, int EPI = EPI_PLANES, int NST = 2, bool HK = false, bool NT = false>
+template <int WM, int WN, int TM, int TN, bool M16 = true, int EPI = EPI_PLANES, int NST = 2, bool HK = false>
 int launch_q_(ConvQ p, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     // LDS: the K-loop stages, overlaid in the epilogue by the accumulator image (planes epilogue: one 32-row block per wave)
@@ -1314,7 +1307,7 @@ int launch_q_(ConvQ p, hipStream_t st) {
     p.nwg = p.ntn * cdiv(p.M, BM);
     p.resident = 256 * (160 * 1024 / smem >= 2 ? 2 : 1);
     p.kloop = HK ? p.ksteps / 2 : p.ksteps;
-    auto k = conv_p32_kernel<WM, WN, TM, TN, M16, EPI, NST, HK, NT>;
+    auto k = conv_p32_kernel<WM, WN, TM, TN, M16, EPI, NST, HK>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -1330,10 +1323,6 @@ int launch_q(ConvQ p, hipStream_t st) {
 #if P32_SINGLE
     if constexpr (M16 && NST == 2) {
         if (p.Cin % 64 == 0 && !p.no_hk) return launch_q_<WM, WN, TM, TN, M16, EPI, NST, true>(p, st);
-    }
-#else
-    if constexpr (EPI == EPI_PLANES && M16 && NST == 2) {
-        if (p.nt_epi) return launch_q_<WM, WN, TM, TN, M16, EPI, NST, false, true>(p, st);
     }
 #endif
     return launch_q_<WM, WN, TM, TN, M16, EPI, NST, false>(p, st);
@@ -1414,7 +1403,6 @@ extern "C" int demia_conv2d_p32(const demia_conv_p32_desc* d, void* stream) {
     p.in_bytes = (unsigned)in_bytes; p.w_bytes = (unsigned)w_bytes;
     p.ntn = p.nwg = 0;
     p.zero_low = d->single == 2;
-    p.nt_epi = 0;
     {
         static const char* env = getenv("DEMIA_P32_NO_HK");
         p.no_hk = (env && env[0] == '1') ? 1 : 0;
@@ -1461,11 +1449,6 @@ extern "C" int demia_conv2d_p32(const demia_conv_p32_desc* d, void* stream) {
     const bool planes = !d->out_f32 && d->Cout % tile_bn == 0 && out_bytes < (1L << 32) - 512 && res_bytes < (1L << 32) - 512 &&
                         (long)(p.M + 256) * d->Cout * 4 + 256 < (1L << 32);
     p.out_bytes = (unsigned)out_bytes; p.res_bytes = (unsigned)res_bytes;
-    {
-        static const char* env = getenv("DEMIA_P32_NT");             // A/B switch: 0 = never, 1 = every residual layer
-        const bool big = out_bytes > (256L << 20);
-        p.nt_epi = d->res_mode == DEMIA_RES_SAME && (env ? env[0] == '1' : big) ? 1 : 0;
-    }
     if (!planes) {
         if (tile != 7 && tile != 9 && tile != 10 && tile != 11 && tile != 21 && tile != 22 && tile != 26) tile = n128 ? 7 : 11;
         switch (tile) {
