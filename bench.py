@@ -89,12 +89,59 @@ def cpu_baseline(depth: int, size: int, thr: float, sd, tiles: int = 3):  # noqa
 
 
 def resolve_lanes(lanes: int, world: int, overlap: bool, graph: bool) -> int:
-    """Pipelines in flight per GPU.  Forced to ONE whenever WORLD_SIZE > 1: every lane's host thread issues its step's
-    all-gather, and nothing orders the lanes' collectives alike on every rank -- two ranks x two lanes hung in mismatched
-    all-gathers until the lease ended (round 3, gpurun_out/two_rank_lanes.err).  Also one without overlap / hipGraph replay."""
-    if world > 1 or not overlap or not graph:
+    """Pipelines in flight per GPU (1..4; one without overlap / hipGraph replay).  With WORLD_SIZE > 1 the lanes' host threads
+    must NOT issue their steps' all-gathers themselves -- nothing orders them alike on every rank, and two ranks x two lanes hung
+    in mismatched all-gathers until the lease ended (round 3, gpurun_out/two_rank_lanes.err): the steps' exchanges then go through
+    :class:`OrderedExchange`, ONE thread per rank that issues them in step order."""
+    if not overlap or not graph:
         return 1
     return max(1, min(int(lanes), 4))
+
+
+class OrderedExchange:
+    """WORLD_SIZE > 1 with several lanes: every rank has to issue the steps' all-gathers in the SAME order, but the lanes' host
+    threads finish their steps in any order.  The lanes hand their step's table (and the event after which it is complete) to this
+    object; its one thread issues the exchanges in step order 0, 1, 2, ... on a stream of its own -- from the collective library's
+    point of view a single thread issuing one all-gather after the other, exactly as with one lane.  (The bench does not use the
+    gathered table, so a lane does not wait for its exchange; ``finish`` -- inside the timed region -- does.)"""
+
+    def __init__(self, dev_index: int, n_steps: int, exchange):
+        import threading
+        self.cv = threading.Condition()
+        self.items, self.err, self.abort = {}, None, False
+        self.thread = threading.Thread(target=self._run, args=(dev_index, n_steps, exchange), daemon=True)
+        self.thread.start()
+
+    def submit(self, i: int, hdr, pay, event) -> None:
+        with self.cv:
+            self.items[i] = (hdr, pay, event)
+            self.cv.notify_all()
+
+    def _run(self, dev_index, n_steps, exchange) -> None:
+        try:
+            torch.cuda.set_device(dev_index)
+            stream = torch.cuda.Stream(device=f"cuda:{dev_index}")
+            with torch.cuda.stream(stream):
+                for i in range(n_steps):
+                    with self.cv:
+                        while i not in self.items and not self.abort:
+                            self.cv.wait(timeout=1.0)
+                        if self.abort:
+                            return
+                        hdr, pay, event = self.items.pop(i)
+                    stream.wait_event(event)
+                    exchange(hdr, pay)
+        except BaseException as e:          # re-raised by finish()
+            self.err = e
+
+    def finish(self, failed: bool = False) -> None:
+        if failed:
+            with self.cv:
+                self.abort = True
+                self.cv.notify_all()
+        self.thread.join()
+        if self.err is not None:
+            raise self.err
 
 
 def load_or_make_device_tiles(first: int, n: int, size: int, dev, cache_dir):
@@ -149,11 +196,11 @@ def main() -> None:
                     "host memory on a copy stream (reported as `h2d`, never as `value`)")
     ap.add_argument("--no-plane-pools", action="store_true", help="(A/B) gather mask sets into fresh zero-filled planes instead of the plane pools")
     ap.add_argument("--no-csv-text", action="store_true", help="leave the CSV text (a19) of every step out of the timed region")
-    ap.add_argument("--lanes", type=int, default=1, help="(experiment, default 1) independent pipelines in flight on the GPU, each with its own "
+    ap.add_argument("--lanes", type=int, default=2, help="independent software pipelines in flight on the GPU (default 2), each with its own "
                     "engine arena, hipGraphs, streams and host thread; steps are dealt out round robin.  A second forward fills the CUs "
-                    "the first leaves idle at the end of every launch and in its HBM-bound layers: predictor only +6.5 %%, whole path "
-                    "+4-6.5 %% at K >= 40 timed steps, but 0-4 %% and unstable at K = 20 (with two forwards in flight one lane's "
-                    "post-processing stretches from 22 to 80-110 ms; DESIGN.md section 8)")
+                    "the first leaves idle in the partly filled last round of every launch and in its HBM-bound layers: whole path +4.2 %% / "
+                    "+6.1 %% on two boxes at the default K = 20, five of five runs (round 4); three lanes are slower than one.  With N > 1 "
+                    "the steps' exchanges are issued in step order by one thread per rank (OrderedExchange)")
     ap.add_argument("--no-overlap", action="store_true", help="do not overlap batch i+1's network with batch i's post-processing")
     ap.add_argument("--forward-only", action="store_true", help="time predictor(tile) only, without the per-tile post-processing")
     ap.add_argument("--post-priority", choices=["default", "high", "low"], default="default", help="(experiment) priority of the post-processing stream")
@@ -259,7 +306,7 @@ def main() -> None:
     last = lanes[0].last
     import threading
     post_lock = threading.Lock()
-    xchg = {}          # (lanes > 1) the start offset between lanes, set after the warm-up
+    xchg = {}          # (lanes > 1) the start offset between lanes, set after the warm-up; N > 1: the ordered exchange of the running leg
 
     TRACE = [] if os.environ.get("DEEPEMIA_BENCH_TRACE") else None      # (diagnostic) host timestamps of every lane's steps
 
@@ -336,7 +383,13 @@ def main() -> None:
             else:
                 hdr = torch.zeros((0, parallel.HDR), dtype=torch.int32, device=dev)
                 pay = torch.zeros((0,), dtype=torch.int32, device=dev)
-            parallel.all_gather_instance_tables(hdr, pay)
+            ox = xchg.get("ordered") if i >= 0 else None
+            if ox is not None:           # several lanes: this step's exchange is issued in step order by the rank's exchange thread
+                ev_ = torch.cuda.Event()
+                ev_.record(torch.cuda.current_stream(dev))
+                ox.submit(i, hdr, pay, ev_)
+            else:
+                parallel.all_gather_instance_tables(hdr, pay)
         return n_inst, n_rows
 
     def run_lane(ln, idxs, out, launcher=launch):
@@ -368,12 +421,17 @@ def main() -> None:
         if len(lanes) == 1:
             run_lane(lanes[0], list(range(n_steps)), outs[0], launcher)
         else:
+            if dist is not None and not args.forward_only:
+                xchg["ordered"] = OrderedExchange(dev_index, n_steps, parallel.all_gather_instance_tables)
             ths = [threading.Thread(target=run_lane, args=(ln, list(range(li, n_steps, len(lanes))), outs[li], launcher))
                    for li, ln in enumerate(lanes)]
             for t_ in ths:
                 t_.start()
             for t_ in ths:
                 t_.join()
+            ox = xchg.pop("ordered", None)
+            if ox is not None:
+                ox.finish(failed=any(o[1] is not None for o in outs))      # the steps' exchanges belong to the timed region
         for o in outs:
             if o[1] is not None:
                 raise o[1]

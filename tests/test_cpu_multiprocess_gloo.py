@@ -168,21 +168,66 @@ def test_agreed_capacity_exchange_is_exact_and_needs_one_host_wait_in_steady_sta
     assert out[0][1] == out[1][1]
 
 
-def test_bench_runs_one_lane_whenever_world_size_exceeds_one():
-    """Two ranks x two lanes hung in round 3 (mismatched all-gathers: nothing orders the lanes' collectives alike on every
-    rank): ``bench.py`` forces one lane per rank for N > 1, whatever ``--lanes`` says."""
+def test_bench_lanes_and_the_ordered_exchange():
+    """Two ranks x two lanes hung in round 3: the lanes' host threads issued their steps' all-gathers in any order.  ``bench.py``
+    now hands the exchanges of a multi-lane run to ``OrderedExchange`` -- one thread per rank that issues them in STEP order,
+    whatever order the lanes finish in.  Checked here without a GPU-side collective: steps submitted out of order (by two
+    threads) come out in order 0..n-1, each after its own event; an aborted run ends the thread."""
     import importlib.util
+    import threading
+    import time
     from pathlib import Path
 
     spec = importlib.util.spec_from_file_location("bench_mod", Path(__file__).resolve().parent.parent / "bench.py")
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    for lanes in (1, 2, 4, 9):
-        for world in (2, 4, 8):
-            assert bench.resolve_lanes(lanes, world, overlap=True, graph=True) == 1
-    assert bench.resolve_lanes(2, 1, overlap=True, graph=True) == 2
-    assert bench.resolve_lanes(9, 1, overlap=True, graph=True) == 4
-    assert bench.resolve_lanes(2, 1, overlap=False, graph=True) == 1 and bench.resolve_lanes(2, 1, overlap=True, graph=False) == 1
+    assert bench.resolve_lanes(2, 8, overlap=True, graph=True) == 2 and bench.resolve_lanes(9, 1, overlap=True, graph=True) == 4
+    assert bench.resolve_lanes(2, 1, overlap=False, graph=True) == 1 and bench.resolve_lanes(2, 8, overlap=True, graph=False) == 1
+
+    class FakeEvent:
+        pass
+
+    class FakeStream:
+        def __init__(self, *a, **k):
+            self.waited = []
+
+        def wait_event(self, e):
+            self.waited.append(e)
+
+    class FakeCtx:
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+    order = []
+    real = bench.torch.cuda
+    fake_cuda = type("C", (), {"set_device": staticmethod(lambda i: None), "Stream": FakeStream, "stream": staticmethod(lambda s: FakeCtx())})
+    bench.torch.cuda = fake_cuda
+    try:
+        n = 12
+        ox = bench.OrderedExchange(0, n, lambda h, p: order.append((h, p)))
+
+        def lane(idxs, delay):
+            for i in idxs:
+                time.sleep(delay)
+                ox.submit(i, i, -i, FakeEvent())
+
+        ths = [threading.Thread(target=lane, args=(list(range(1, n, 2)), 0.001)), threading.Thread(target=lane, args=(list(range(0, n, 2)), 0.004))]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        ox.finish()
+        assert order == [(i, -i) for i in range(n)]
+        ox2 = bench.OrderedExchange(0, 5, lambda h, p: order.append("x"))
+        ox2.submit(0, 0, 0, FakeEvent())
+        time.sleep(0.05)
+        ox2.finish(failed=True)                      # a lane died: the exchange thread must not wait for step 1 for ever
+        assert not ox2.thread.is_alive()
+    finally:
+        bench.torch.cuda = real
 
 
 def _worker_status(rank, world, port, h, w, out):

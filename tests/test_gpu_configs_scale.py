@@ -5,7 +5,8 @@ GPU, plus the N > 1 launch path of ``bench.py`` rehearsed on the one-GPU box.
   ``main.py --task inference``: finishes, is deterministic, every instance lies inside the frame, RLE rows == instances,
   CSV rows >= instances; the same pipeline is compared with the oracle at 512^2 in ``test_gpu_pipeline_e2e.py``.
 * ``bench.py --gpus 2`` under ``torch.distributed.run`` (both ranks on cuda:0, gloo for the exchange because RCCL refuses
-  two ranks on one device): one JSON line, n_gpus 2, weak scaling, a positive whole-job rate.  No RCCL run has happened
+  two ranks on one device), with the default TWO lanes per rank -- the configuration that hung in round 3 until the steps'
+  exchanges were issued in step order by one thread per rank: one JSON line, n_gpus 2, weak scaling, a positive whole-job rate.  No RCCL run has happened
   anywhere in this repository's records -- the 8-GPU scaling run is the driver's.
 * configs[4] shape: ``bench.py --total-tiles 32`` walks distinct tiles and still passes its own parity check."""
 import csv
@@ -92,14 +93,15 @@ def test_config2_one_8192_image_through_the_cli(tmp_path, monkeypatch, gpu_devic
 def test_bench_two_ranks_on_one_device_and_total_tiles_mode(gpu_device, tmp_path):
     env = dict(os.environ, DEEPEMIA_BENCH_ONE_DEVICE="1", DEEPEMIA_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4",
-           "--no-cpu-baseline"]
+           "--master-port", str(_free_port()), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "1", "--batch", "4",
+           "--no-cpu-baseline"]          # default --lanes 2: two ranks x two lanes, the configuration that hung in round 3
     r = subprocess.run(cmd, cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["steps"] == 2 and line["value"] > 0
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["steps"] == 6 and line["value"] > 0
+    assert line["config"]["lanes"] == 2          # the steps' exchanges went through OrderedExchange, in step order on both ranks
     assert "all-gather of instance tables" in line["config"]["workload"]
     assert line["roofline"]["bound"] == "mfma" and 0 < line["roofline"]["frac"] < 1
 
