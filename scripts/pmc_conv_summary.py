@@ -104,5 +104,18 @@ for path in (SRC / "stats").rglob("*kernel_stats.csv"):
 line = [l for l in (SRC / "bench_under_rocprofv3.json").read_text().splitlines() if l.startswith("{")]
 if line:
     (DST / f"{tag}_bench_{prec}_b{batch}_whole_path_under_rocprofv3.json").write_text(line[-1] + "\n")
+# the same command with ONE lane (the figure roofline.avg_launch_us has to agree with)
+for path in (SRC / "stats_l1").rglob("*kernel_stats.csv"):
+    shutil.copy(path, DST / f"{tag}_bench_{prec}_b{batch}_one_lane_kernel_stats.csv")
+    rows = [r for r in csv.DictReader(open(path)) if kernel in r["Name"]]
+    calls = sum(int(r["Calls"]) for r in rows)
+    tot = sum(float(r["TotalDurationNs"]) for r in rows)
+    print(f"one lane: {calls} {kernel} launches, {tot / 1e6:.2f} ms, {tot / max(calls, 1) / 1e3:.1f} us per launch")
+p1 = SRC / "bench_l1_under_rocprofv3.json"
+if p1.exists():
+    line = [l for l in p1.read_text().splitlines() if l.startswith("{")]
+    if line:
+        (DST / f"{tag}_bench_{prec}_b{batch}_one_lane_under_rocprofv3.json").write_text(line[-1] + "\n")
+        print("HIP events of that run:", json.loads(line[-1])["roofline"]["avg_launch_us"], "us per launch")
 print(json.dumps(traffic, indent=1))
 print(json.dumps(rec, indent=1))
