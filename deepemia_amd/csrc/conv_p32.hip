@@ -35,7 +35,8 @@
 #ifndef P32_ABLATE
 #define P32_ABLATE 0      // timing-only dev builds: 1 = no A DMA after the first two steps, 2 = no B DMA, 4 = no MFMAs,
                           // 32 = no residual loads, 64 = no global stores in the epilogue, 128 = one K-step only,
-                          // 256 = sigmoid / nearest-2x paths compiled out (instruction counting), 512 = no epilogue passes,
+                          // 256 = sigmoid / nearest-2x paths compiled out (instruction counting), 512 = no epilogue passes (the MFMAs die with them),
+                          // 2048 = no epilogue, accumulators kept alive (K loop + prologue only),
                           // 1024 = no fragment reads (scripts/build_variant.sh, scripts/gpu_ablate.sh)
 #endif
 
@@ -1056,6 +1057,13 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 2 : 1) void conv_p32_k
     }
 #undef P32_ADVANCE
 
+    if constexpr ((P32_ABLATE & 2048) != 0 && M16) {      // timing-only: prologue + K loop with its MFMAs, no epilogue at all
+#pragma unroll
+        for (int i = 0; i < 2 * TM; ++i)
+#pragma unroll
+            for (int j = 0; j < 2 * TN; ++j) asm volatile("" :: "v"(acc16[i][j]));
+        return;
+    }
     if constexpr (EPI == EPI_PLANES) {
         if constexpr (M16) {
             p32_epilogue_planes<WM, WN, TM, TN>(p, gs, smem, [&](int i, float* e) { write_acc16<TN, TN * 32 + 4>(acc16[2 * i], acc16[2 * i + 1], e, lane); }, wm, wn, m0, n0);

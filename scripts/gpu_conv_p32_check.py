@@ -272,7 +272,23 @@ def single_sweep(B=48):
         print(f'{name} M={n*h*w} K={cin*k*k} N={cout}: three-MFMA auto {t3*1e3:.0f}us | single: ' + ' '.join(row), flush=True)
 
 
+def occupancy_probe():
+    """res4 conv3 (1x1, 256 -> 1024, + residual, 256 x 256 tiles) on 64 / 128 / 256 / 512 / 1024 tiles: is a tile's time set by its own
+    CU (same time whatever the number of busy CUs) or by what the whole chip asks of HBM at once (faster when fewer CUs run)?"""
+    L = Layer(1024, 256, 1, 1, seed=1)
+    for tiles in (64, 128, 256, 512, 1024, 1876):
+        rows = tiles // 4 * 256
+        xp = p32.from_f32(torch.randn(1, 1, rows, 256, device=dev))
+        res = p32.from_f32(torch.randn(1, 1, rows, 1024, device=dev))
+        t = min(timeit(lambda: conv_p32(xp, L, 1, 0, ACT_RELU, res, RES_SAME, hint=1), reps=10) for _ in range(3))
+        t0 = min(timeit(lambda: conv_p32(xp, L, 1, 0, ACT_RELU, None, RES_NONE, hint=1), reps=10) for _ in range(3))
+        print(f'{os.environ.get("AB_LIB", "default")} tiles {tiles:5d} ({tiles / 256:.2f} rounds): with residual {t*1e3:7.1f} us, without {t0*1e3:7.1f} us', flush=True)
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'occupancy':
+        occupancy_probe()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'single':
         single_sweep(int(sys.argv[2]) if len(sys.argv) > 2 else 48)
         sys.exit(0)
