@@ -409,9 +409,12 @@ __device__ __forceinline__ void p32_epilogue(const ConvQ& p, const GroupScales& 
 // memory instructions and the waits are counted: a pass waits for ITS residual lines only, not -- as with stores inside
 // `if (m < M)` branches, where the count is unknown and the wait becomes vmcnt(0) -- for the previous pass's stores to be
 // acknowledged by the L2.  That acknowledgement was the longest stall of every short-K (HBM-bound) layer.
-template <int WM, int WN, int TM, int TN, typename WriteRow>
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+// (`leader`: the one thread that publishes the scale of a group whose first row lies in this tile; `hook`: called after every
+//  item -- the ping-pong kernel below puts its barriers there; the plain kernel passes nothing)
+template <int WM, int WN, int TM, int TN, typename WriteRow, typename Hook = NoHook>
 __device__ __forceinline__ void p32_epilogue_planes(const ConvQ& p, const GroupScales& gs, char* smem, WriteRow&& write_tile_row, int wm, int wn,
-                                                    int m0, int n0) {
+                                                    int m0, int n0, bool leader = (threadIdx.x == 0), Hook&& hook = NoHook()) {
     constexpr int BM_ = WM * TM * 32;
     const int tid = threadIdx.x, lane = tid & 63;
     // WAVE-LOCAL passes: a wave takes the 32 x (TN * 32) block of ITS OWN accumulators through ITS OWN piece of LDS and
@@ -426,7 +429,7 @@ __device__ __forceinline__ void p32_epilogue_planes(const ConvQ& p, const GroupS
     const float post0 = uniform(gs.post0), post1 = uniform(gs.post1), post2 = uniform(gs.post2);
     const float resi0 = uniform(gs.resi0), resi1 = uniform(gs.resi1), resi2 = uniform(gs.resi2);
     const float sout0 = uniform(gs.sout0), sout1 = uniform(gs.sout1), sout2 = uniform(gs.sout2);
-    if (n0 == 0 && tid == 0) {
+    if (n0 == 0 && leader) {
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             const int first = d == 0 ? g0 * p.group_rows - p.row0 : (d == 1 ? b1 : b2);
@@ -568,6 +571,7 @@ __device__ __forceinline__ void p32_epilogue_planes(const ConvQ& p, const GroupS
                 __builtin_amdgcn_raw_buffer_store_b128(d0, rs_out, off, 0, P32_ST_AUX);
                 __builtin_amdgcn_raw_buffer_store_b128(d1, rs_out, off + cbytes, 0, P32_ST_AUX);
             }
+            hook();
         }
     }
 #pragma unroll
@@ -1086,6 +1090,222 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 2 : 1) void conv_p32_k
 
 #if P32_DEV_TILES   // experiments that did not pay, kept for same-box A/B through tile hints (scripts/build_variant.sh -DP32_DEV_TILES=1)
 // ---------------------------------------------------------------------------------------------------------------------
+// Pointwise (1x1, stride 1) layers as a PING-PONG of two four-wave groups inside one persistent workgroup.
+//
+// The plain kernel above keeps one workgroup per CU, so a tile's phases take turns: the K loop (matrix pipe, LDS), then the
+// epilogue (vector ALU) which is also the tile's memory phase (residual lines in, planes out).  On the short-K layers of the
+// bottlenecks the three cost about the same -- res4 conv3 at 48 tiles: 20 us K loop, 7 us epilogue arithmetic, 14 us waiting
+// for memory per 256 x 256 tile -- and every CU reaches its memory phase at the same moment, so HBM is asked for twice what it
+// delivers while the K loops leave it idle.  Here the eight waves are two GROUPS of four (a 2 x 2 grid of
+// 64 x 128 wave tiles over a 128 x 256 tile each).  In every phase one group runs the K loop of its tile while the other runs
+// the epilogue of the tile it finished one phase earlier; then they swap.  The K-loop group owns the two LDS stages; the
+// epilogue group works out of registers (its accumulators) and a small per-wave LDS image.  The matrix pipe always has a
+// group feeding it, and memory traffic is spread over the whole phase instead of a burst at its end.
+//
+// gfx950 has one barrier per workgroup, so BOTH groups execute the same barriers: a phase is `ksteps` steps, each ending in
+// `s_barrier`; the K group does one K-step per step, the epilogue group `ips = ceil(16 / ksteps)` of its 16 items (a hook
+// inside p32_epilogue_planes) and then empty steps.  Barrier counts are equal BY CONSTRUCTION: every wave runs the same phase
+// loop and the same step loop; validity flags skip work, never a barrier.
+// The DMA for a phase's first K-step is issued by the PREVIOUS phase's K group during its last step (the stage it would have
+// filled for itself is free then), so a phase starts computing at once.
+// Results are bit-identical to the plain kernel: the same three MFMAs per accumulator and K-step in the same order, the same
+// epilogue code.
+// OUTCOME (round 4, dev build, tile hint 60): correct on the first run and never hung -- and 0.6-0.95 x the plain kernel's speed
+// (res4 conv3 at 48 tiles 392 vs 348 us, res4 conv1 300 vs 190, res2 conv3 841 vs 796).  With no operand traffic and no epilogue
+// its K-step still takes 0.9-1.0 us for the 0.37 us of MFMAs in it: ONE K-loop wave per SIMD has nothing to cover its fragment
+// reads (64 KiB out of LDS per step, all four waves at once right behind the barrier) and the barrier itself, and the group tile
+// that fits the registers beside the epilogue's working set (128 x 128: 64 accumulator registers; 128 x 256 spilled 45) has half
+// the MFMAs per barrier of the plain tile.  The overlap works as designed -- the epilogue costs nothing extra -- but it is bought
+// with a K loop 2.4 x slower per MFMA.  Kept as a dev tile for the record.
+__global__ __launch_bounds__(512, 1) void conv_p32_pp1x1_kernel(const ConvQ p) {
+    constexpr int HM = 128, BN = 128;                     // a group's tile (wave tiles of 64 x 64: 64 accumulator registers, so
+                                                          // that K-loop operands and the epilogue's working set fit beside them)
+    constexpr int STAGE = (HM + BN) * 128;                // 32 KiB: one K-step of A (128 rows) and B (128 rows)
+    constexpr int EIMG = 32 * (2 * 32 + 4) * 4;           // the epilogue's per-wave image at TN = 2 (32 x 64 floats + padding)
+    constexpr int NITEMS = 8;                             // epilogue items per wave tile (2 passes of 32 rows x 4 items)
+    constexpr int NSTG = 3;                               // LDS stages: a K-step's operands are requested TWO steps ahead (a step of
+                                                          // a 128 x 128 tile is shorter than an L2 round trip)
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // [3 stages][4 images]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = wave >> 2, q = wave & 3, wmh = q >> 1, wnh = q & 1;
+    const int S = p.ksteps, T = p.nwg, G = (int)gridDim.x;
+    const int nIter = (T + 2 * G - 1) / (2 * G);
+    const int bl = xcd_remap(blockIdx.x, G);              // tiles that share their rows land on one XCD
+    const i32x4 rsrc_a = make_rsrc(p.in, p.in_bytes), rsrc_b = make_rsrc(p.w, p.w_bytes);
+    const unsigned lds0 = (unsigned)(__SIZE_TYPE__)((lds_void*)smem);
+    const unsigned pixb = (unsigned)(p.Cin * 4);
+
+    auto tile_of = [&](int iter, int h) { return (iter * G + bl) * 2 + h; };
+    // K-step `s_` of tile `t` -> stage `st`: this wave's 4 of the 16 A pieces and 4 of the 16 B pieces (a piece = 8 rows = 1 KiB),
+    // in two halves so that the K loop can put them BETWEEN its MFMA groups (a K-loop wave is alone on its SIMD: whatever it
+    // issues in front of its MFMAs is time the matrix pipe idles)
+    auto issue_a = [&](int st, int t, int s_) {
+        const int tm = t / p.ntn;
+        const int m0_ = tm * HM;
+        const unsigned sbase = __builtin_amdgcn_readfirstlane(lds0 + st * STAGE);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int piece = q + 4 * j;
+            const int row = piece * 8 + (lane >> 3);
+            const int csw = (lane & 7) ^ ((row >> 1) & 7);
+            const int m = m0_ + row;
+            const unsigned vo = m < p.M ? 128u + (unsigned)m * pixb + (unsigned)(csw * 16) + (unsigned)s_ * 128u : (unsigned)(csw * 16);
+            dma16(rsrc_a, sbase + piece * 1024, vo, 0u);
+        }
+    };
+    auto issue_b = [&](int st, int t, int s_) {
+        const int tm = t / p.ntn, tn = t - tm * p.ntn;
+        const int n0_ = tn * BN;
+        const unsigned sbase = __builtin_amdgcn_readfirstlane(lds0 + st * STAGE);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int piece = q + 4 * j;
+            const int row = piece * 8 + (lane >> 3);
+            const int csw = (lane & 7) ^ ((row >> 1) & 7);
+            const int co = n0_ + row;
+            const unsigned vo = (unsigned)(((co >> 6) * S) * 8192 + (co & 63) * 128 + csw * 16);
+            dma16(rsrc_b, sbase + HM * 128 + piece * 1024, vo, (unsigned)s_ * 8192u);
+        }
+    };
+    f32x4 acc[4][4];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    // fragment addresses (see the plain kernel): row r of a region at r * 128, logical 16-byte chunk c at (c ^ ((r >> 1) & 7)) * 16
+    // One K-step: fragments of stage `st`, then the three MFMA terms with the DMA of global step `gi` (tile `ti`, K-step `si`, if
+    // `do_issue`) between them.
+    auto kstep = [&](bool do_compute, int st, bool do_issue, int gi, int ti, int si) {
+        if (!do_compute) {
+            if (do_issue) { issue_a(gi % NSTG, ti, si); issue_b(gi % NSTG, ti, si); }
+            return;
+        }
+        const int swz = ((lane & 15) >> 1) & 7, kq = lane >> 4;
+        const char* sa = smem + st * STAGE + (wmh * 64 + (lane & 15)) * 128;
+        const char* sbp = smem + st * STAGE + HM * 128 + (wnh * 64 + (lane & 15)) * 128;
+        const int c0 = (kq ^ swz) * 16, c1 = ((4 + kq) ^ swz) * 16;
+        f16x8 ah[4], al[4], bh[4], blo[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ah[i] = *reinterpret_cast<const f16x8*>(sa + c0 + i * 2048);
+            blo[i] = *reinterpret_cast<const f16x8*>(sbp + c1 + i * 2048);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            al[i] = *reinterpret_cast<const f16x8*>(sa + c1 + i * 2048);
+            bh[i] = *reinterpret_cast<const f16x8*>(sbp + c0 + i * 2048);
+        }
+        // The three terms of a product go into an accumulator in the plain kernel's order (smallest first), but term by term over
+        // ALL sixteen accumulators: three back-to-back MFMAs on one accumulator would each wait for the one before.
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], blo[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (do_issue) issue_a(gi % NSTG, ti, si);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (do_issue) issue_b(gi % NSTG, ti, si);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+    };
+    auto step_barrier = [&]() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+    // Global step g belongs to phase g / S (K group (g / S) & 1, tile iteration (g / S) >> 1) and is K-step g % S of that tile; its
+    // operands live in stage g % 3 and are requested at global step g - 2 by whichever group runs the K loop then.
+    // which (tile, K-step) global step g is, and whether it exists
+    auto global_step = [&](int g, int& t2, int& s2) -> bool {
+        const int ph2 = g / S;
+        s2 = g - ph2 * S;
+        t2 = tile_of(ph2 >> 1, ph2 & 1);
+        if (ph2 >= 2 * nIter || t2 >= T) return false;
+        return !((P32_ABLATE & 3) && g >= NSTG);             // (timing-only: no operand traffic after the first steps)
+    };
+    // prologue: global steps 0 and 1
+    if (half == 0) {
+        int t2, s2;
+        if (global_step(0, t2, s2)) { issue_a(0, t2, s2); issue_b(0, t2, s2); }
+        if (global_step(1, t2, s2)) { issue_a(1, t2, s2); issue_b(1, t2, s2); }
+    }
+    step_barrier();
+    zero_acc();
+    int gstep = 0;                                        // barrier-steps done
+    const int ips = (NITEMS + S - 1) / S;                 // epilogue items per step
+    char* const eimg = smem + NSTG * STAGE - (wave - q) * EIMG;     // p32_epilogue_planes adds (tid >> 6) * EIMG: image q of the four
+
+    for (int ph = 0; ph <= 2 * nIter; ++ph) {
+        const int hk = ph & 1;                            // the group in its K loop
+        if (half == hk) {
+            const int t = tile_of(ph >> 1, hk);
+            const bool valid = ph < 2 * nIter && t < T;
+            for (int s_ = 0; s_ < S; ++s_) {
+                int t2, s2;
+                const bool issued = global_step(gstep + 2, t2, s2);
+                kstep(valid, gstep % NSTG, issued, gstep + 2, t2, s2);
+                // the operands of step g + 1 (requested a step ago) have to be there, the request just made may stay in flight --
+                // except at the phase's last step: the other group takes over the K loop and waits for nothing it did not issue
+                if (issued && s_ + 1 < S) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                else step_barrier();
+                ++gstep;
+            }
+        } else {
+            const int t = ph >= 1 ? tile_of((ph - 1) >> 1, half) : T;
+            int done = 0, cnt = 0;
+            // (a bare barrier: the epilogue's loads and stores stay in flight across it -- that is the point)
+            auto hook = [&]() {
+                if (++cnt == ips) {
+                    cnt = 0;
+                    if (done < S) { asm volatile("s_barrier" ::: "memory"); ++done; }
+                }
+            };
+            if (ph >= 1 && t < T && (P32_ABLATE & 2048)) {       // timing-only: no epilogue, accumulators kept alive
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(acc[i][j]));
+                zero_acc();
+            } else if (ph >= 1 && t < T) {
+                const int tm = t / p.ntn, tn = t - tm * p.ntn;
+                const int m0 = tm * HM, n0 = tn * BN;
+                const GroupScales gs = load_group_scales(p, m0, true);
+                p32_epilogue_planes<2, 2, 2, 2>(p, gs, eimg, [&](int i, float* e) { write_acc16<2, 2 * 32 + 4>(acc[2 * i], acc[2 * i + 1], e, lane); },
+                                                wmh, wnh, m0, n0, q == 0 && lane == 0, hook);
+                zero_acc();
+            }
+            while (done < S) { asm volatile("s_barrier" ::: "memory"); ++done; }
+            gstep += S;
+        }
+    }
+}
+
+int launch_pp1x1(ConvQ p, hipStream_t st) {
+    constexpr int smem = 3 * (128 + 128) * 128 + 4 * 32 * (2 * 32 + 4) * 4;      // 133 120 bytes
+    p.ntn = p.CoutPad / 128;
+    p.nwg = cdiv(p.M, 128) * p.ntn;                        // 128 x 128 tiles
+    const int grid = p.nwg / 2 < 256 ? (p.nwg + 1) / 2 : 256;
+    auto k = conv_p32_pp1x1_kernel;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(512), smem, st, p);
+    DEMIA_CHECK_LAUNCH("conv_p32_pp1x1_kernel");
+    return DEMIA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // The same tile as a PING-PONG of two wave groups (waves 0-3 = the upper half of the rows, waves 4-7 = the lower half;
 // wave w and wave w + 4 share a SIMD).  The plain kernel above runs all eight waves in lockstep -- fragment reads, MFMAs
 // and the barrier hit both waves of a SIMD at the same moment, and timing-only builds show its matrix pipe waiting for
@@ -1457,6 +1677,15 @@ extern "C" int demia_conv2d_p32(const demia_conv_p32_desc* d, void* stream) {
     const bool planes = !d->out_f32 && d->Cout % tile_bn == 0 && out_bytes < (1L << 32) - 512 && res_bytes < (1L << 32) - 512 &&
                         (long)(p.M + 256) * d->Cout * 4 + 256 < (1L << 32);
     p.out_bytes = (unsigned)out_bytes; p.res_bytes = (unsigned)res_bytes;
+#if !P32_SINGLE && P32_DEV_TILES
+    if (tile == 60) {
+        DEMIA_REQUIRE(!d->out_f32 && n128 && d->Cout % 128 == 0 && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 &&
+                      d->res_mode != DEMIA_RES_UP2 && out_bytes < (1L << 32) - 512 && res_bytes < (1L << 32) - 512 &&
+                      (long)(p.M + 256) * d->Cout * 4 + 256 < (1L << 32),
+                      "tile 60 (ping-pong) takes 1x1 stride-1 planes layers with Cout % 128 == 0, no nearest-2x residual, buffers below 4 GiB");
+        return launch_pp1x1(p, st);
+    }
+#endif
     if (!planes) {
         if (tile != 7 && tile != 9 && tile != 10 && tile != 11 && tile != 21 && tile != 22 && tile != 26) tile = n128 ? 7 : 11;
         switch (tile) {

@@ -285,7 +285,62 @@ def occupancy_probe():
         print(f'{os.environ.get("AB_LIB", "default")} tiles {tiles:5d} ({tiles / 256:.2f} rounds): with residual {t*1e3:7.1f} us, without {t0*1e3:7.1f} us', flush=True)
 
 
+def pingpong_check(time_too=True):
+    """Tile hint 60 (the ping-pong kernel for 1x1 layers) against the plain kernel: bit-identical planes and metas on shapes
+    with / without residual, ragged M, one and many K-steps, several scale groups; then its time beside the plain kernel's."""
+    shapes = [  # n, h, w, cin, cout, residual, groups
+        (2, 25, 25, 256, 1024, 1, 1), (3, 31, 17, 64, 256, 1, 1), (1, 40, 40, 1024, 256, 0, 1), (2, 20, 20, 32, 128, 0, 1),
+        (4, 50, 50, 256, 1024, 1, 4), (1, 1, 777, 512, 128, 0, 1), (1, 9, 9, 96, 256, 1, 1), (6, 16, 16, 128, 512, 1, 2),
+    ]
+    for ci, (n, h, w, cin, cout, rs, groups) in enumerate(shapes):
+        g = torch.Generator().manual_seed(500 + ci)
+        x = (torch.randn(n, h, w, cin, generator=g) * 2.0).to(dev)
+        L = Layer(cout, cin, 1, 1, seed=ci)
+        xp = p32.from_f32(x, groups=groups)
+        res = p32.from_f32((torch.randn(n, h, w, cout, generator=g) * 1.5).to(dev), groups=groups) if rs else None
+        outs = []
+        for hint in (0, 60):
+            out = p32.alloc((n, h, w, cout), dev, groups=groups)
+            d = _lib.ConvP32Desc(_lib.ptr(xp.buf), _lib.ptr(xp.meta), _lib.ptr(L.w_p32), _lib.ptr(L.scale3), _lib.ptr(L.bias_d),
+                                 _lib.ptr(res.buf) if rs else 0, _lib.ptr(res.meta) if rs else 0, _lib.ptr(out.buf), _lib.ptr(out.meta),
+                                 L.wbound, L.bbound, n, h, w, cin, h, w, cout, L.cout_pad, 1, 1, 1, 0, ACT_RELU, RES_SAME if rs else RES_NONE, 0, 0, hint,
+                                 0, 0, 0, 0, 0, 0, groups, (n * h * w) // groups, 0)
+            _lib.check(lib.demia_conv2d_p32(C.byref(d), st()), 'demia_conv2d_p32')
+            torch.cuda.synchronize()
+            outs.append(out)
+        same = torch.equal(outs[0].buf, outs[1].buf) and torch.equal(outs[0].meta, outs[1].meta)
+        err = float((p32.to_f32(outs[0]) - p32.to_f32(outs[1])).abs().max())
+        print(f'pingpong case {ci}: M={n*h*w} K={cin} N={cout} res{rs} groups{groups}: identical={same} max abs diff {err:.3e}', flush=True)
+        assert same, ci
+    if not time_too:
+        return
+    for name, (n, h, w), cin, cout, rs in (('res4 conv3', (48, 50, 50), 256, 1024, 1), ('res4 conv1', (48, 50, 50), 1024, 256, 0),
+                                            ('res3 conv3', (48, 100, 100), 128, 512, 1), ('res3 conv1', (48, 100, 100), 512, 128, 0),
+                                            ('res2 conv3', (48, 200, 200), 64, 256, 1), ('res2 conv1', (48, 200, 200), 256, 64, 0),
+                                            ('res5 conv3', (48, 25, 25), 512, 2048, 1), ('res5 conv1', (48, 25, 25), 2048, 512, 0)):
+        if cout % 128:
+            continue
+        L = Layer(cout, cin, 1, 1, seed=1)
+        xp = p32.from_f32(torch.randn(n, h, w, cin, device=dev))
+        res = p32.from_f32(torch.randn(n, h, w, cout, device=dev)) if rs else None
+        tt = {}
+        for hint in (0, 60):
+            tt[hint] = min(timeit(lambda: conv_p32(xp, L, 1, 0, ACT_RELU, res, RES_SAME if rs else RES_NONE, hint=hint), reps=8) for _ in range(3))
+        print(f'{name}: M={n*h*w} K={cin} N={cout} res{rs}: plain {tt[0]*1e3:7.1f} us, ping-pong {tt[60]*1e3:7.1f} us ({tt[0]/tt[60]:.2f}x)', flush=True)
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'pingpong':
+        pingpong_check(len(sys.argv) < 3 or sys.argv[2] != 'notime')
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'pptime':         # timing-only variants (AB_LIB=...): hint 60 on the res4 pointwise layers
+        for name, (n, h, w), cin, cout, rs in (('res4 conv3', (48, 50, 50), 256, 1024, 1), ('res4 conv1', (48, 50, 50), 1024, 256, 0)):
+            L = Layer(cout, cin, 1, 1, seed=1)
+            xp = p32.from_f32(torch.randn(n, h, w, cin, device=dev))
+            res = p32.from_f32(torch.randn(n, h, w, cout, device=dev)) if rs else None
+            t = min(timeit(lambda: conv_p32(xp, L, 1, 0, ACT_RELU, res, RES_SAME if rs else RES_NONE, hint=60), reps=8) for _ in range(3))
+            print(f'{os.environ.get("AB_LIB", "default")} {name}: ping-pong {t*1e3:7.1f} us', flush=True)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'occupancy':
         occupancy_probe()
         sys.exit(0)

@@ -921,3 +921,37 @@ def test_single_plane_conv_is_the_high_plane_product(env, case, monkeypatch):
     assert 1e-5 < d < 5e-3, d
     # the measured |out| bound the next layer scales with is exact
     assert abs(float(out.meta[0, 0]) - float(got.abs().max())) <= 1e-5 * float(got.abs().max())
+
+
+@pytest.mark.parametrize("case", [(256, 1024, 25, 25, 2, True, 1), (64, 256, 31, 17, 3, True, 1), (1024, 256, 40, 40, 1, False, 1),
+                                  (32, 128, 20, 20, 2, False, 1), (256, 1024, 50, 50, 4, True, 4), (96, 256, 9, 9, 1, True, 1)])
+def test_pingpong_pointwise_kernel_is_bit_identical_to_the_plain_kernel(env, case):
+    """Dev build only (tile hint 60): 1x1 layers as a ping-pong of two four-wave groups inside one persistent workgroup -- one group in
+    its K loop while the other runs the epilogue of the tile it finished a phase earlier, both executing the same barriers.  Same
+    MFMAs per accumulator in the same order, same epilogue code: planes and metas equal the plain kernel's bit for bit, on ragged M,
+    one to 32 K-steps, with and without residual, one and several scale groups.  (It is 0.6-0.95 x the plain kernel's speed and
+    therefore not used by the product: DESIGN.md section 4.)"""
+    from conftest import needs_dev_build
+    needs_dev_build("")
+    from deepemia_amd import engine as E, p32
+    from deepemia_amd._lib import ACT_RELU, RES_NONE, RES_SAME
+
+    cin, cout, h, w, n, res, groups = case
+    dev = env["dev"]
+    g = torch.Generator().manual_seed(cin + cout + h)
+    x = (torch.randn((n, h, w, cin), generator=g) * 2.0).to(dev)
+    wt = torch.randn((cout, cin, 1, 1), generator=g) / cin ** 0.5
+    scale = torch.rand((cout,), generator=g) + 0.5
+    bias = torch.randn((cout,), generator=g) * 0.1
+    wp = torch.zeros((cout, 1, 1, cin))
+    wp[:] = wt.permute(0, 2, 3, 1)
+    planes, sw = E.split2_f16_scaled(wp.to(dev))
+    L = E.ConvLayer(None, scale.to(dev), bias.to(dev), cin, cout, cout, 1, 1, 1, 0, E.tile_weight_planes_p32(planes),
+                    (scale.to(dev) / sw[:cout]).contiguous(), float((scale.abs() * wt.abs().flatten(1).sum(1)).max()), float(bias.abs().max()))
+    eng = env["f16x2"]
+    xp = p32.from_f32(x, groups=groups)
+    rp = p32.from_f32((torch.randn((n, h, w, cout), generator=g) * 1.5).to(dev), groups=groups) if res else None
+    outs = [eng.conv_p32(xp, L, act=ACT_RELU, residual=rp, res_mode=RES_SAME if res else RES_NONE, tile_hint=hint) for hint in (0, 60)]
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0].buf, outs[1].buf) and torch.equal(outs[0].meta, outs[1].meta)
+    assert float(outs[0].meta[:, 0].min()) > 0.0
