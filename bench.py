@@ -61,7 +61,11 @@ def cpu_baseline(depth: int, size: int, thr: float, sd, tiles: int = 3):  # noqa
         ncpu = os.cpu_count() or 1
     nthr = max(1, min(16, ncpu))            # the GPU box gives one GPU a 16-core share
     torch.set_num_threads(nthr)
-    refs = [TP.reference_tile(synth.em_tile(i, size), sd, depth, thr, CLASS_THRESHOLDS, SMALL_CLASSES) for i in range(tiles)]
+    refs = []
+    for i in range(tiles):
+        refs.append(TP.reference_tile(synth.em_tile(i, size), sd, depth, thr, CLASS_THRESHOLDS, SMALL_CLASSES))
+        # (a progress line per tile: a long sample -- BASELINE.md's 20 tiles take nine minutes -- must not look like a hung run)
+        print(f"[cpu_baseline] tile {i + 1}/{tiles}: {refs[-1]['seconds']['total']:.1f} s", file=sys.stderr, flush=True)
     secs = {k: float(np.median([r["seconds"][k] for r in refs])) for k in refs[0]["seconds"]}
     tot = sorted(r["seconds"]["total"] for r in refs)
     torch.set_num_threads(1)
