@@ -143,7 +143,7 @@ def check():
     print(f'check ok, worst {worst:.2e}')
 
 
-HINTS = {14: '192x256', 42: '128x256s3', 52: '160x256ns3', 49: '256x64s3', 12: '160x256n', 13: '224x256n', 31: '256x256m32', 34: '192x256m32', 21: '256x256pp', 22: '128x256pp', 26: '256x128pp', 1: '256x256', 2: '128x256', 3: '256x256n', 4: '192x256n', 5: '128x256n', 6: '256x128', 7: '128x128', 8: '128x128n',
+HINTS = {60: 'pingpong', 14: '192x256', 42: '128x256s3', 52: '160x256ns3', 49: '256x64s3', 12: '160x256n', 13: '224x256n', 31: '256x256m32', 34: '192x256m32', 21: '256x256pp', 22: '128x256pp', 26: '256x128pp', 1: '256x256', 2: '128x256', 3: '256x256n', 4: '192x256n', 5: '128x256n', 6: '256x128', 7: '128x128', 8: '128x128n',
          9: '256x64', 10: '256x64b', 11: '128x64'}
 
 R101_B16 = [
@@ -240,6 +240,8 @@ def key_layers(hint=1, which='mfma'):
                        ((16, 50, 50), 1024, 256, 1, 0)],
               # the res4 bottleneck tail at the bench's 48 tiles: conv2 (3x3) and conv3 (1x1 + residual) -- the pair a fused kernel would replace
               'res4': [((48, 50, 50), 256, 256, 3, 0), ((48, 50, 50), 256, 1024, 1, 1), ((48, 50, 50), 1024, 256, 1, 0)],
+              'mfma48': [((48, 200, 200), 256, 256, 3, 0), ((4800, 14, 14), 256, 256, 3, 0), ((48, 50, 50), 256, 256, 3, 0), ((1, 1, 48000), 12544, 1024, 1, 0),
+                         ((48, 50, 50), 1024, 256, 1, 0), ((48, 50, 50), 256, 1024, 1, 1)],
               'hbm48': [((48, 200, 200), 64, 256, 1, 1), ((48, 100, 100), 128, 512, 1, 1), ((48, 200, 200), 256, 64, 1, 0), ((48, 25, 25), 512, 2048, 1, 1)],
               'hbm': [((16, 50, 50), 256, 1024, 1, 1), ((16, 200, 200), 64, 256, 1, 1), ((16, 200, 200), 256, 256, 1, 1),
                       ((16, 100, 100), 128, 512, 1, 1)]}[which]
