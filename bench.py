@@ -641,7 +641,8 @@ def main() -> None:
                          "avg_launch_us": conv_ms * 1e3 / max(launches, 1),
                          "algorithmic_gflop_per_launch": conv_flops / max(launches, 1) / 1e9,
                          "algorithmic_bytes_per_launch": conv_bytes / max(launches, 1),
-                         # conv time per step (from the instrumented passes) over the TIMED step; the eager figure beside it
+                         # conv time per step (from the instrumented single-lane passes) over the TIMED step (with two lanes in flight two
+                         # passes overlap, so this can pass 1); the eager figure beside it
                          "share_of_step_time": (conv_ms / (n_instr if instrumented_s else args.steps)) / (dt / args.steps * 1e3),
                          "all_conv_share_of_step_time": (all_conv_ms / (n_instr if instrumented_s else args.steps)) / (dt / args.steps * 1e3),
                          "share_of_eager_instrumented_step_time": conv_ms * 1e-3 / (instrumented_s or dt),

@@ -106,6 +106,30 @@ def test_bench_two_ranks_on_one_device_and_total_tiles_mode(gpu_device, tmp_path
     assert line["roofline"]["bound"] == "mfma" and 0 < line["roofline"]["frac"] < 1
 
 
+def test_bench_default_line_carries_its_contract(gpu_device):
+    """The default bench command at a small batch: one JSON line with the driver's fields, two lanes, two distinct resident batches,
+    the input hashes (tile 0 is byte-reproducible: numpy PCG64), the side figure of the repeated batch, the upload leg, and the
+    parity leg on tile 0 of the last timed step over batch 0."""
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "6", "--warmup", "1", "--batch", "8", "--parity-only"],
+                       cwd=str(ROOT), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:] + r.stdout[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                "roofline", "parity", "h2d", "same_batch_every_step", "inputs"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["steps"] == 6 and line["dtype"] == "f16x2" and line["vs_baseline"] is None and line["value"] > 0
+    assert line["config"]["lanes"] == 2 and "2 distinct resident batches" in line["config"]["workload"]
+    assert line["inputs"]["distinct_resident_batches"] == 2
+    assert line["inputs"]["sha256_tile0"] == "f9c43b982cea3c5afa2d7573af7540bda988ebd59f9f5c099760f70176a33d87"
+    assert len(line["inputs"]["sha256_weights"]) == 64
+    assert line["parity"]["ok"] and line["parity"]["eager_equals_replay"] and "timed step 4" in line["parity"]["checked"]
+    rf = line["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and rf["single_plane_launches"] == 0
+    assert line["config"]["post_d2h_waits_per_step"] <= 3.5        # three per step; the first batch of a lane copies its contour points separately
+
+
 def test_config4_job_of_256_distinct_tiles_at_size(gpu_device):
     """BASELINE configs[4] at its stated size on one GPU: a job of 256 DISTINCT 2048^2 tiles (16 steps of 16; step 0 holds
     the numpy tiles, the rest are generated on the device), the whole per-tile path on every tile, the parity leg on tile 0
@@ -121,7 +145,8 @@ def test_config4_job_of_256_distinct_tiles_at_size(gpu_device):
     assert par["csv_max_rel_err"] <= 1e-4 and par["csv_max_rel_err_own_mask"] <= 1e-4
     assert "hipGraph replay" in par["checked"]
     assert line["h2d"]["value_with_upload"] > 0 and line["h2d"]["h2d_ms_per_step"] > 0
-    assert 0 < line["roofline"]["share_of_step_time"] <= 1.0
+    # (conv time of ONE pass run alone over the timed step: with two lanes in flight two passes overlap, so it may pass 1)
+    assert 0 < line["roofline"]["share_of_step_time"] < 2.0
 
 
 _RCCL_SCRIPT = r"""
