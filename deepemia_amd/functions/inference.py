@@ -295,9 +295,9 @@ class InferencePipeline:
         if self.multiscale_enabled:
             system_logger.warning("multiscale_settings.enabled -- NON-PARITY mode: the reference never reaches its multi-scale code")
         self._cache: Dict[Tuple[int, str], List[_Detections]] = {}
-        # images per batched forward: l4_performance_optimizations.forward_batch_size / DEEPEMIA_FORWARD_BATCH (default 16:
+        # images per batched forward: l4_performance_optimizations.forward_batch_size / DEEPEMIA_FORWARD_BATCH (default 48: the res3-res5 layers fill the 256 CUs for several rounds, 26 GiB of activations; 16:
         # fills 256 CUs on the 50^2 feature maps, 8.6 GiB of activations per 2048^2-tile batch)
-        self.forward_batch = max(1, int(os.environ.get("DEEPEMIA_FORWARD_BATCH", l4.get("forward_batch_size", 16))))
+        self.forward_batch = max(1, int(os.environ.get("DEEPEMIA_FORWARD_BATCH", l4.get("forward_batch_size", 48))))
         self.use_graphs = os.environ.get("DEEPEMIA_GRAPHS", "1") == "1"     # hipGraph replay of repeated forward shapes
         self.graph_after = 2                                                   # ... from their second occurrence on
         self._shape_seen: Dict[tuple, int] = {}
@@ -548,6 +548,86 @@ class InferencePipeline:
             tiles[i, : ye - y, : xe - x] = image_dev[y:ye, x:xe]
         return tiles, offs
 
+    @staticmethod
+    def _tile_offsets(h: int, w: int, tile_size: int, overlap_ratio: float):
+        stride = int(tile_size * (1 - overlap_ratio))
+        return [(x, y) for y in range(0, h, stride) for x in range(0, w, stride)]
+
+    def _tiles_key(self, image_key: str, tile_size, overlap_ratio, upscale_factor) -> str:
+        return f"{image_key}|tiles{tile_size}/{overlap_ratio}/{upscale_factor}/{self.rank}of{self.world}"
+
+    def _my_tiles(self, image_dev: torch.Tensor, tile_size: int, overlap_ratio: float, upscale_factor: float) -> Optional[torch.Tensor]:
+        """THIS rank's tiles of an image (a1, tile ``t % world == rank``), upscaled (a2) -- the input of the tile forward."""
+        tiles, offs = self._make_tiles(image_dev, tile_size, overlap_ratio)
+        mine = parallel.shard_indices(len(offs), self.rank, self.world)
+        if not mine:
+            return None
+        my_tiles = tiles if len(mine) == len(offs) else tiles[torch.tensor(mine, dtype=torch.long, device=self.dev)]
+        uh = uw = int(tile_size * upscale_factor)
+        if (uh, uw) != (tile_size, tile_size):
+            my_tiles = self.predictors[0].engine.resize_linear_u8(my_tiles, uh, uw)
+        return my_tiles
+
+    # ------------------------------------------------------------------ forwards batched ACROSS images (the CLI loop)
+    def prefetch_images(self, items: Sequence[Tuple[str, torch.Tensor]], model_ids: Sequence[int], tile_size: int, overlap_ratio: float,
+                        upscale_factor: float):
+        """Enqueue, on the CURRENT stream, the standard forwards of a GROUP of images -- every image's full-image pass
+        (rank 0; ``inference.py:789``) and this rank's tiles (``inference.py:2365-2449``) -- batched ACROSS the images: the
+        full frames of equally sized images go through the network as one batch, and so do all their tiles (a folder of 2048^2
+        micrographs with nine tiles each: 45 tiles per forward instead of nine; the res3-res5 layers fill the 256 CUs for several
+        rounds only from ~32 tiles up).  Returns a handle for :meth:`finish_prefetch`, which files the results in the cache
+        under exactly the keys the per-image passes ask for -- they then run unchanged and find every forward done.  Nothing
+        is waited for here: the caller enqueues the NEXT group before it post-processes the current one.
+        Results are bit-identical to image-by-image forwards: every stage of the network is batch-invariant (per-image scale
+        groups; ``test_f16x2_forward_is_batch_invariant``)."""
+        plan = []            # (model, [(cache key, images in the batch)], handle)
+        by_shape: Dict[tuple, list] = {}
+        for name, img in items:
+            by_shape.setdefault(tuple(int(d) for d in img.shape[:2]), []).append((name, img))
+        for (h, w), group in by_shape.items():
+            full_keys = [(name + "|full", 1) for name, _ in group] if self.rank == 0 else []
+            full = torch.stack([img for _, img in group]) if full_keys else None
+            tkeys, tparts = [], []
+            for name, img in group:
+                t = self._my_tiles(img, tile_size, overlap_ratio, upscale_factor)
+                if t is not None:
+                    tkeys.append((self._tiles_key(name, tile_size, overlap_ratio, upscale_factor), int(t.shape[0])))
+                    tparts.append(t)
+            tiles = (tparts[0] if len(tparts) == 1 else torch.cat(tparts)) if tparts else None
+            for m in model_ids:
+                for keys, batch in ((full_keys, full), (tkeys, tiles)):
+                    todo = [(k, n) for k, n in keys if (m, k) not in self._cache]
+                    if batch is None or not todo:
+                        continue
+                    if len(todo) != len(keys):      # (some already cached: forward the missing ones only)
+                        pos, sel = 0, []
+                        for k, n in keys:
+                            if (m, k) not in self._cache:
+                                sel.extend(range(pos, pos + n))
+                            pos += n
+                        batch_m = batch[torch.tensor(sel, dtype=torch.long, device=self.dev)]
+                    else:
+                        batch_m = batch
+                    plan.append((m, todo, self.forward_async(m, batch_m)))
+        return plan
+
+    def finish_prefetch(self, plan) -> None:
+        """ONE device-to-host wait for the tables of all forwards of a :meth:`prefetch_images` group; the per-image detection
+        lists go into the cache."""
+        if not plan:
+            return
+        for (m, keys, _), dets in zip(plan, self.finish_forwards([h for _, _, h in plan])):
+            pos = 0
+            for k, n in keys:
+                self._cache[(m, k)] = dets[pos:pos + n]
+                pos += n
+
+    def drop_cached(self, image_key: str) -> None:
+        """Forget the cached forwards of ONE image (the CLI loop calls it when the image is done; forwards of the images
+        ahead stay)."""
+        for ck in [ck for ck in self._cache if ck[1] == image_key or ck[1].startswith(image_key + "|")]:
+            del self._cache[ck]
+
     # ------------------------------------------------------------------ a13 + the tile pipeline
     def _tile_pipeline_local(self, model_ids: Sequence[int], image_key: str, image_dev: torch.Tensor, target_class,
                              small_classes, confidence_threshold, tile_size=512, overlap_ratio=0.1, upscale_factor=2.0,
@@ -566,7 +646,7 @@ class InferencePipeline:
             return self._single_model_class_pass(dets_per_model[0], target_class, small_classes, confidence_threshold, iou_threshold)
 
         rank, world = self.rank, self.world
-        tiles, offs = self._make_tiles(image_dev, tile_size, overlap_ratio)
+        offs = self._tile_offsets(h, w, tile_size, overlap_ratio)
         uh, uw = int(tile_size * upscale_factor), int(tile_size * upscale_factor)
         # unit 0 = the full-image pass (rank 0), unit 1 + t = tile t (rank t % world): SURVEY.md section 8(e)
         mine = parallel.shard_indices(len(offs), rank, world)
@@ -581,11 +661,11 @@ class InferencePipeline:
                 full_masks, full_scores, full_classes = class_pass(full)
         tile_masks, tile_scores, tile_classes, tile_units = [], [], [], []
         if mine:
-            my_tiles = tiles[torch.tensor(mine, dtype=torch.long, device=self.dev)]
-            if (uh, uw) != (tile_size, tile_size):
-                my_tiles = self.predictors[0].engine.resize_linear_u8(my_tiles, uh, uw)
-            tile_dets = [self._predict_batch(m, f"{image_key}|tiles{tile_size}/{overlap_ratio}/{upscale_factor}/{rank}of{world}", my_tiles)
-                         for m in model_ids]
+            tkey = self._tiles_key(image_key, tile_size, overlap_ratio, upscale_factor)
+            # (the tiles are cut only if some model's forward over them is not in the cache yet: `prefetch_images` has usually
+            # run them already, batched with the tiles of the neighbouring images)
+            my_tiles = None if all((m, tkey) in self._cache for m in model_ids) else self._my_tiles(image_dev, tile_size, overlap_ratio, upscale_factor)
+            tile_dets = [self._predict_batch(m, tkey, my_tiles) for m in model_ids]
         edge = int(tile_size * overlap_ratio / 2)
         if mine:
             # a6 + a9..a12 (or a10 + a14) for ALL of this rank's tiles with one launch per kernel, then a13 likewise: one
@@ -752,6 +832,8 @@ class InferencePipeline:
                                        self.soft_nms_sigma, self.soft_nms_score_threshold)
         return self.deduplicate_masks_smart(packed, list(full_scores) + list(tile_scores), list(full_classes) + list(tile_classes), 0.4)
 
+    _encode_table = staticmethod(parallel.encode_instance_table)      # (a seam: the failure-agreement test makes it raise on one rank)
+
     def gather_and_merge(self, locals_by_class: Dict[int, tuple], hw: Tuple[int, int], ensemble_by_class: Dict[int, bool], status: int = 0):
         """The ONE exchange of the multi-GPU path, once per IMAGE: every rank contributes the class-tagged instance tables
         of all its local class passes (full-image pass on rank 0, its tiles), every rank receives the global table ordered
@@ -765,26 +847,34 @@ class InferencePipeline:
         image is skipped by all ranks together and the next image's exchange finds every rank at the same collective."""
         h, w = hw
         hdrs, pays = [], []
-        for cls, (fm, fs, fc, tm, ts, tc, tu) in locals_by_class.items():
-            empty_full = isinstance(fm, str)
-            parts = ([fm] if (fm is not None and not empty_full and fm.shape[0]) else []) + list(tm)
-            sc = ([] if (fm is None or empty_full) else list(fs)) + list(ts)
-            cl = [cls] * len(sc)
-            un = [0] * (len(sc) - len(ts)) + list(tu)
-            if self.rank == 0 and empty_full:   # N4 marker travels too: unit -1 row of this class, no payload
-                mark = torch.zeros((1, parallel.HDR), dtype=torch.int32, device=self.dev)
-                mark[0, 0] = -1
-                mark[0, 1] = cls
-                mark[0, 4:8] = -1
-                hdrs.append(mark)
-            if parts:
-                local = torch.cat(parts, dim=0)
-                a, b = self.ops.area_bbox(local)
-                hdr, pay = parallel.encode_instance_table(local, sc, cl, un, b.cpu().numpy(), a.cpu().numpy())
-                hdrs.append(hdr)
-                pays.append(pay)
-        hdr = torch.cat(hdrs, dim=0) if hdrs else torch.zeros((0, parallel.HDR), dtype=torch.int32, device=self.dev)
-        pay = torch.cat(pays, dim=0) if pays else torch.zeros((0,), dtype=torch.int32, device=self.dev)
+        try:
+            # (building this rank's table allocates -- the concatenated full-frame masks, the crop -- and can fail like the
+            # local passes can: it must not keep the rank out of the collective either)
+            for cls, (fm, fs, fc, tm, ts, tc, tu) in (locals_by_class.items() if status == 0 else ()):
+                empty_full = isinstance(fm, str)
+                parts = ([fm] if (fm is not None and not empty_full and fm.shape[0]) else []) + list(tm)
+                sc = ([] if (fm is None or empty_full) else list(fs)) + list(ts)
+                cl = [cls] * len(sc)
+                un = [0] * (len(sc) - len(ts)) + list(tu)
+                if self.rank == 0 and empty_full:   # N4 marker travels too: unit -1 row of this class, no payload
+                    mark = torch.zeros((1, parallel.HDR), dtype=torch.int32, device=self.dev)
+                    mark[0, 0] = -1
+                    mark[0, 1] = cls
+                    mark[0, 4:8] = -1
+                    hdrs.append(mark)
+                if parts:
+                    local = torch.cat(parts, dim=0)
+                    a, b = self.ops.area_bbox(local)
+                    hdr, pay = self._encode_table(local, sc, cl, un, b.cpu().numpy(), a.cpu().numpy())
+                    hdrs.append(hdr)
+                    pays.append(pay)
+            hdr = torch.cat(hdrs, dim=0) if hdrs else torch.zeros((0, parallel.HDR), dtype=torch.int32, device=self.dev)
+            pay = torch.cat(pays, dim=0) if pays else torch.zeros((0,), dtype=torch.int32, device=self.dev)
+        except Exception as e:
+            system_logger.error(f"Rank {self.rank}: building the instance table of an image failed: {e}", exc_info=True)
+            status = 1
+            hdr = torch.zeros((0, parallel.HDR), dtype=torch.int32, device=self.dev)
+            pay = torch.zeros((0,), dtype=torch.int32, device=self.dev)
         gt = parallel.all_gather_instance_tables(hdr, pay, status=status, state=self.exchange)
         if bool((gt.status != 0).any()):
             raise PeerImageFailure(f"local passes failed on rank(s) {np.nonzero(gt.status)[0].tolist()}: every rank skips this image")
@@ -1625,22 +1715,96 @@ def run_inference(dataset_name, output_dir, visualize=True, threshold=0.65, draw
         if t is not None:
             sample.append((name, t))
     sample_dev = dict(sample)          # the first images are already on the device: no second decode
-    small_classes = determine_small_classes(pipe.calculate_average_mask_sizes(sample), 50)
-    system_logger.info(f"Small classes: {sorted(small_classes)}")
 
     Img_ID, EncodedPixels = [], []
     dedup_results: Dict[str, dict] = {}
     processed = set()
+    # The forwards of a GROUP of images are batched across the images and enqueued one group AHEAD of the post-processing
+    # (`prefetch_images`): while the host walks the class loops, dedups and writers of group g, the network of group g + 1
+    # runs on a stream of its own.  The reference goes image by image (inference.py:713-942); the per-image semantics (an
+    # image that fails is logged and skipped) are kept -- a group only shares its forwards.
+    tiles_per_image = 1
+    if sample:
+        tiles_per_image = max(1, len(pipe._tile_offsets(int(sample[0][1].shape[0]), int(sample[0][1].shape[1]), tile_size, overlap_ratio)))
+    group_size = max(1, min(int(os.environ.get("DEEPEMIA_IMAGE_GROUP", pipe.forward_batch // tiles_per_image)), 16))
+    groups = [images_name[i:i + group_size] for i in range(0, len(images_name), group_size)]
+    net_stream = torch.cuda.Stream(device=dev)
+
+    def enqueue_forwards(ok, model_ids):
+        up = torch.cuda.Event()
+        up.record(torch.cuda.current_stream(dev))
+        try:
+            with torch.cuda.stream(net_stream):
+                net_stream.wait_event(up)
+                return pipe.prefetch_images(ok, model_ids, tile_size, overlap_ratio, upscale_factor)
+        except Exception as e:      # e.g. out of memory on the batched forward: the per-image passes run their own forwards
+            system_logger.warning(f"Batched forwards of images {[nm for nm, _ in ok]} failed ({e}); falling back to per-image forwards")
+            return None
+
+    def launch_group(gnames, model_ids):
+        """Decode / upload the group's images (the decode of the group after it is already running on the helper threads) and
+        enqueue its forwards on the network stream.  Returns ({name: device image or None}, prefetch plan)."""
+        items = {}
+        for nm in gnames:
+            items[nm] = sample_dev.pop(nm) if nm in sample_dev else load(nm)
+        ok = [(nm, t) for nm, t in items.items() if t is not None]
+        return items, (enqueue_forwards(ok, model_ids) if ok else None)
+
+    def finish_group(plan, g):
+        try:
+            pipe.finish_prefetch(plan)          # the wait for the group's forwards
+        except Exception as e:
+            system_logger.warning(f"Batched forwards of group {g} failed ({e}); falling back to per-image forwards")
+
+    # group 0 goes through the first model before the small-class statistics: they read its full-image passes (inference.py:1626-1706)
+    ahead = launch_group(groups[0], [0]) if groups else None
+    if ahead is not None:
+        finish_group(ahead[1], 0)
+    if pipe.world > 1:
+        # every rank must walk the class loop with the SAME small classes: rank 0 (the one that runs the full-image passes the
+        # statistics read) decides, the others take its answer -- a rank that could not read one of the first images would
+        # otherwise compute its own
+        import torch.distributed as dist
+        box = [sorted(determine_small_classes(pipe.calculate_average_mask_sizes(sample), 50))] if pipe.rank == 0 else [None]
+        dist.broadcast_object_list(box, src=0)
+        small_classes = set(box[0])
+    else:
+        small_classes = determine_small_classes(pipe.calculate_average_mask_sizes(sample), 50)
+    system_logger.info(f"Small classes: {sorted(small_classes)}")
     t_all = time.perf_counter()
-    for gi, name in enumerate(images_name):
+    targets_all = list(range(num_classes) if classes_to_infer is None else [c for c in classes_to_infer if c < num_classes])
+    any_ens = len(predictors) > 1 and any(ensemble_enabled and (not ensemble_small_only or c in small_classes) for c in targets_all)
+    models_needed = list(range(len(predictors))) if any_ens else [0]
+    if ahead is not None:
+        ok0 = [(nm, t) for nm, t in ahead[0].items() if t is not None]
+        ahead = (ahead[0], enqueue_forwards(ok0, models_needed) if (ok0 and len(models_needed) > 1) else None)
+
+    def prefetch_group(gnames):
+        for nm in gnames:
+            if nm not in sample_dev:
+                prefetch(nm)
+
+    flat = [(g, nm) for g, gn in enumerate(groups) for nm in gn]
+    cur_group, cur_items = -1, {}
+    for gi, (g, name) in enumerate(flat):
         t0 = time.perf_counter()
         log_memory_usage(f"Before image {gi + 1}/{len(images_name)}: {name}")
-        for nxt in images_name[gi + 1: gi + 3]:
-            if nxt not in sample_dev:
-                prefetch(nxt)
-        image_dev = sample_dev.pop(name) if name in sample_dev else load(name)
+        if g != cur_group:
+            cur_group = g
+            cur_items, plan = ahead
+            finish_group(plan, g)
+            if g + 2 < len(groups):
+                prefetch_group(groups[g + 2])       # decode two groups ahead on the helper threads
+            ahead = launch_group(groups[g + 1], models_needed) if g + 1 < len(groups) else None
+        image_dev = cur_items.pop(name, None)
         if image_dev is None:
             system_logger.warning(f"Could not load image: {name}")
+            if pipe.world > 1:
+                # the other ranks may have loaded it: take part in the image's exchange with status 1, so that every rank skips it
+                try:
+                    pipe.gather_and_merge({}, (0, 0), {}, status=1)
+                except PeerImageFailure as e:
+                    system_logger.error(f"Error processing image {name}: {e}")
             continue
         try:
             image_host = None
@@ -1711,8 +1875,9 @@ def run_inference(dataset_name, output_dir, visualize=True, threshold=0.65, draw
         except Exception as e:  # reference semantics: log, skip the image, continue (inference.py:928-931)
             system_logger.error(f"Error processing image {name}: {e}", exc_info=True)
         finally:
-            pipe.clear_cache()
+            pipe.drop_cached(name)
             log_memory_usage(f"After image {gi + 1}/{len(images_name)}: {name}")
+    pipe.clear_cache()
     decoder.shutdown(wait=False)
     total = time.perf_counter() - t_all
     system_logger.info(f"Inference complete: {len(processed)}/{len(images_name)} images, avg "

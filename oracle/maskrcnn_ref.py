@@ -129,8 +129,60 @@ def _frozen_bn(x: torch.Tensor, sd, prefix: str) -> torch.Tensor:
     return x * scale.reshape(1, -1, 1, 1) + bias.reshape(1, -1, 1, 1)
 
 
+# Study switch ("Winograd decision"): which stages evaluate their 3x3 stride-1 convolutions by fp32
+# Winograd F(2x2, 3x3) instead of the direct sum -- a set out of {"backbone", "fpn", "rpn", "mask"}; EMPTY (the oracle of
+# record) unless ``oracle/winograd_probe.py`` sets it.  Nothing else reads it.
+WINOGRAD_STAGES: set = set()
+WINOGRAD_F16X2 = False      # ... with the transformed operands U, V carried as two power-of-two-scaled fp16 planes and the product taken
+                            # as a_h b_l + a_l b_h + a_h b_h in fp32 (the product path's arithmetic) instead of fp32
+
+_WG = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]])
+_WBT = torch.tensor([[1.0, 0.0, -1.0, 0.0], [0.0, 1.0, 1.0, 0.0], [0.0, -1.0, 1.0, 0.0], [0.0, 1.0, 0.0, -1.0]])
+_WAT = torch.tensor([[1.0, 1.0, 1.0, 0.0], [0.0, 1.0, -1.0, -1.0]])
+
+
+def conv3x3_winograd(x: torch.Tensor, w: torch.Tensor, b=None) -> torch.Tensor:
+    """``F.conv2d(x, w, b, padding=1)`` for a 3x3 stride-1 kernel by Winograd F(2x2, 3x3) (Lavin & Gray 2015), everything in
+    fp32: U = G g G^T per (co, ci), V = B^T d B per 4x4 input tile (stride 2), the 16 element-wise positions as 16 GEMMs
+    over the channels, Y = A^T M A.  2.25 x fewer multiplications in the contraction; the transforms add and subtract
+    neighbouring inputs, so the rounding differs from the direct sum by a few fp32 ulps of the LARGEST term."""
+    n, c, h, wd = x.shape
+    th, tw = (h + 1) // 2, (wd + 1) // 2
+    xp = F.pad(x, (1, 2 * tw - wd + 1, 1, 2 * th - h + 1))
+    d = xp.unfold(2, 4, 2).unfold(3, 4, 2)                         # [n, c, th, tw, 4, 4]
+    v = torch.einsum("ai,nctuij,bj->abnctu", _WBT, d, _WBT)        # [4, 4, n, c, th, tw]
+    u = torch.einsum("ai,ocij,bj->aboc", _WG, w, _WG)              # [4, 4, co, ci]
+    u, v = u.reshape(16, 1, w.shape[0], c), v.reshape(16, n, c, th * tw)
+    if WINOGRAD_F16X2:
+        def planes(t, dims):
+            # one exact power-of-two scale per output channel (U) / per image (V) bringing max |t| under 2^15, then h = half(t s),
+            # l = half(t s - h): 22 significand bits; elements far below the maximum keep an absolute error (fp16 denormals)
+            amax = t.abs().amax(dim=dims, keepdim=True).clamp(min=1e-30)
+            sc = torch.exp2(14 - torch.floor(torch.log2(amax)))
+            hi = (t * sc).half().float()
+            lo = (t * sc - hi).half().float()
+            return hi, lo, sc
+        uh, ul, us = planes(u, (0, 1, 3))          # per output channel
+        vh, vl, vs = planes(v, (0, 2, 3))          # per image
+        m = (torch.matmul(uh, vl) + torch.matmul(ul, vh) + torch.matmul(uh, vh)) / (us * vs)
+    else:
+        m = torch.matmul(u, v)                                                                # [16, n, co, th * tw]
+    m = m.reshape(4, 4, n, w.shape[0], th, tw)
+    y = torch.einsum("ia,abnotu,jb->notiuj", _WAT, m, _WAT).reshape(n, w.shape[0], 2 * th, 2 * tw)[:, :, :h, :wd]
+    return y if b is None else y + b.reshape(1, -1, 1, 1)
+
+
+def _conv3x3(x, w, b, stage: str):
+    if stage in WINOGRAD_STAGES:
+        return conv3x3_winograd(x, w, b)
+    return F.conv2d(x, w, b, padding=1)
+
+
 def _conv_bn(x, sd, prefix, stride=1, padding=0, relu=False):
-    y = F.conv2d(x, sd[prefix + ".weight"], None, stride=stride, padding=padding)
+    if padding == 1 and stride == 1 and "backbone" in WINOGRAD_STAGES and tuple(sd[prefix + ".weight"].shape[2:]) == (3, 3):
+        y = conv3x3_winograd(x, sd[prefix + ".weight"])
+    else:
+        y = F.conv2d(x, sd[prefix + ".weight"], None, stride=stride, padding=padding)
     y = _frozen_bn(y, sd, prefix + ".norm")
     return F.relu(y) if relu else y
 
@@ -160,7 +212,7 @@ def backbone_fpn(x: torch.Tensor, sd, depth: int) -> Dict[str, torch.Tensor]:
         if prev is not None:
             lat = lat + F.interpolate(prev, scale_factor=2.0, mode="nearest")
         prev = lat
-        results[f"p{lvl}"] = F.conv2d(lat, sd[f"backbone.fpn_output{lvl}.weight"], sd[f"backbone.fpn_output{lvl}.bias"], padding=1)
+        results[f"p{lvl}"] = _conv3x3(lat, sd[f"backbone.fpn_output{lvl}.weight"], sd[f"backbone.fpn_output{lvl}.bias"], "fpn")
     results["p6"] = F.max_pool2d(results["p5"], kernel_size=1, stride=2, padding=0)
     results.update(feats)
     return results
@@ -271,7 +323,7 @@ def rpn_forward(feats: Dict[str, torch.Tensor], sd, image_size: Tuple[int, int],
     per_level = []
     for li, name in enumerate(("p2", "p3", "p4", "p5", "p6")):
         x = feats[name]
-        t = F.relu(F.conv2d(x, sd[rp + "conv.weight"], sd[rp + "conv.bias"], padding=1))
+        t = F.relu(_conv3x3(x, sd[rp + "conv.weight"], sd[rp + "conv.bias"], "rpn"))
         logits = F.conv2d(t, sd[rp + "objectness_logits.weight"], sd[rp + "objectness_logits.bias"])
         deltas = F.conv2d(t, sd[rp + "anchor_deltas.weight"], sd[rp + "anchor_deltas.bias"])
         n, a, h, w = logits.shape
@@ -427,7 +479,7 @@ def mask_head(pooled: torch.Tensor, classes: torch.Tensor, sd) -> torch.Tensor:
     mh = "roi_heads.mask_head."
     x = pooled
     for i in range(1, 5):
-        x = F.relu(F.conv2d(x, sd[f"{mh}mask_fcn{i}.weight"], sd[f"{mh}mask_fcn{i}.bias"], padding=1))
+        x = F.relu(_conv3x3(x, sd[f"{mh}mask_fcn{i}.weight"], sd[f"{mh}mask_fcn{i}.bias"], "mask"))
     x = F.relu(F.conv_transpose2d(x, sd[mh + "deconv.weight"], sd[mh + "deconv.bias"], stride=2))
     x = F.conv2d(x, sd[mh + "predictor.weight"], sd[mh + "predictor.bias"])
     n = x.shape[0]

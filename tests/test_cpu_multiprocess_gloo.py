@@ -1,6 +1,7 @@
 """CPU, world_size 2, gloo: the N > 1 path -- unit sharding and the all-gather of per-tile instance
 tables -- gives every rank the same global table, in (unit id, detector order) order, bit-exact."""
 import os
+from pathlib import Path
 import socket
 
 import numpy as np
@@ -168,6 +169,28 @@ def test_agreed_capacity_exchange_is_exact_and_needs_one_host_wait_in_steady_sta
     assert out[0][1] == out[1][1]
 
 
+def test_bench_gpus_n_starts_its_ranks_itself_and_refuses_a_wrong_world_size():
+    """``python bench.py --gpus N`` is the form of the driver's command: with N > 1 and no WORLD_SIZE the process becomes a launcher
+    (a child ``torch.distributed.run`` with N ranks, its stdout = rank 0's one JSON line, never a GPU call of its own); a WORLD_SIZE
+    that differs from --gpus is refused with exit code 2 instead of being reported as N.  ``--rendezvous-only`` stops the ranks
+    after their rendezvous (gloo), so the role logic runs on a CPU box."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--rendezvous-only"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and json.loads(lines[0]) == {"n_gpus": 2, "rendezvous_only": True}, r.stdout
+    bad = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "8", "--rendezvous-only"], env=dict(env, WORLD_SIZE="1", RANK="0"),
+                         capture_output=True, text=True, timeout=120)
+    assert bad.returncode == 2 and "refusing" in bad.stderr and not bad.stdout.strip()
+    one = subprocess.run([sys.executable, str(root / "bench.py"), "--rendezvous-only"], env=env, capture_output=True, text=True, timeout=120)
+    assert one.returncode == 0 and json.loads(one.stdout.strip()) == {"n_gpus": 1, "rendezvous_only": True}
+
+
 def test_bench_lanes_and_the_ordered_exchange():
     """Two ranks x two lanes hung in round 3: the lanes' host threads issued their steps' all-gathers in any order.  ``bench.py``
     now hands the exchanges of a multi-lane run to ``OrderedExchange`` -- one thread per rank that issues them in STEP order,
@@ -183,6 +206,9 @@ def test_bench_lanes_and_the_ordered_exchange():
     spec.loader.exec_module(bench)
     assert bench.resolve_lanes(2, 8, overlap=True, graph=True) == 2 and bench.resolve_lanes(9, 1, overlap=True, graph=True) == 4
     assert bench.resolve_lanes(2, 1, overlap=False, graph=True) == 1 and bench.resolve_lanes(2, 8, overlap=True, graph=False) == 1
+    # the parity step is one that lane 0 (the rank process) runs over batch 0
+    assert bench.parity_step_of(20, 2, 2, 0) == 18 and bench.parity_step_of(6, 2, 2, 0) == 4 and bench.parity_step_of(20, 2, 3, 0) == 18
+    assert bench.parity_step_of(20, 2, 1, 0) == 18 and bench.parity_step_of(20, 1, 2, 0) == 18 and bench.parity_step_of(16, 16, 2, 256) == 0
 
     class FakeEvent:
         pass

@@ -4,10 +4,12 @@ GPU, plus the N > 1 launch path of ``bench.py`` rehearsed on the one-GPU box.
 * configs[2]: ONE 8192 x 8192 image -> full-image pass + 16 tiles of 2048^2 (tile_size 2048, overlap 0, upscale 1) through
   ``main.py --task inference``: finishes, is deterministic, every instance lies inside the frame, RLE rows == instances,
   CSV rows >= instances; the same pipeline is compared with the oracle at 512^2 in ``test_gpu_pipeline_e2e.py``.
-* ``bench.py --gpus 2`` under ``torch.distributed.run`` (both ranks on cuda:0, gloo for the exchange because RCCL refuses
-  two ranks on one device), with the default TWO lanes per rank -- the configuration that hung in round 3 until the steps'
-  exchanges were issued in step order by one thread per rank: one JSON line, n_gpus 2, weak scaling, a positive whole-job rate.  No RCCL run has happened
-  anywhere in this repository's records -- the 8-GPU scaling run is the driver's.
+* plain ``python bench.py --gpus 2`` -- the form of the driver's command -- starts its two ranks ITSELF (a child
+  ``torch.distributed.run``; both ranks on cuda:0, gloo for the exchange because RCCL refuses two ranks on one device), with the
+  default TWO lanes per rank, lanes 1.. being child processes of the rank whose exchanges run in a process group per lane: one JSON
+  line, n_gpus 2, weak scaling, a positive whole-job rate; the same under round 4's thread lanes (``--lane-mode threads``: the
+  configuration that hung in round 3 until the steps' exchanges were issued in step order by one thread per rank).  No RCCL run has
+  happened anywhere in this repository's records -- the 8-GPU scaling run is the driver's.
 * configs[4] shape: ``bench.py --total-tiles 32`` walks distinct tiles and still passes its own parity check."""
 import csv
 import json
@@ -90,20 +92,28 @@ def test_config2_one_8192_image_through_the_cli(tmp_path, monkeypatch, gpu_devic
         assert v and min(v[0::2]) >= 1 and max(a + b - 1 for a, b in zip(v[0::2], v[1::2])) <= 8192 * 8192
 
 
-def test_bench_two_ranks_on_one_device_and_total_tiles_mode(gpu_device, tmp_path):
-    env = dict(os.environ, DEEPEMIA_BENCH_ONE_DEVICE="1", DEEPEMIA_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "1", "--batch", "4",
-           "--no-cpu-baseline"]          # default --lanes 2: two ranks x two lanes, the configuration that hung in round 3
-    r = subprocess.run(cmd, cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=600)
+@pytest.mark.parametrize("lane_mode", ["processes", "threads"])
+def test_bench_two_ranks_on_one_device_and_total_tiles_mode(gpu_device, tmp_path, lane_mode):
+    env = dict(os.environ, DEEPEMIA_BENCH_ONE_DEVICE="1", DEEPEMIA_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    # no torch.distributed.run here: `--gpus 2` makes bench.py start its ranks itself (default --lanes 2: two ranks x two lanes)
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "1", "--batch", "4",
+           "--no-cpu-baseline", "--lane-mode", lane_mode]
+    r = subprocess.run(cmd, cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]          # stdout of the launcher = the one JSON line
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["steps"] == 6 and line["value"] > 0
-    assert line["config"]["lanes"] == 2          # the steps' exchanges went through OrderedExchange, in step order on both ranks
+    assert line["config"]["lanes"] == 2 and line["config"]["lane_mode"] == lane_mode
     assert "all-gather of instance tables" in line["config"]["workload"]
     assert line["roofline"]["bound"] == "mfma" and 0 < line["roofline"]["frac"] < 1
+    assert line["one_lane"]["value"] > 0 and abs(line["value_over_one_lane"] - line["value"] / line["one_lane"]["value"]) < 1e-9
+    # a rank count that is not the one running is refused, not reported
+    bad = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--no-cpu-baseline"], cwd=str(ROOT),
+                         env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=120)
+    assert bad.returncode == 2 and "refusing" in bad.stderr and not bad.stdout.strip()
 
 
 def test_bench_default_line_carries_its_contract(gpu_device):
@@ -117,17 +127,21 @@ def test_bench_default_line_carries_its_contract(gpu_device):
     assert len(lines) == 1
     line = json.loads(lines[0])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
-                "roofline", "parity", "h2d", "same_batch_every_step", "inputs"):
+                "roofline", "parity", "h2d", "same_batch_every_step", "inputs", "one_lane", "value_over_one_lane"):
         assert key in line, key
     assert line["n_gpus"] == 1 and line["steps"] == 6 and line["dtype"] == "f16x2" and line["vs_baseline"] is None and line["value"] > 0
-    assert line["config"]["lanes"] == 2 and "2 distinct resident batches" in line["config"]["workload"]
+    assert line["config"]["lanes"] == 2 and line["config"]["lane_mode"] == "processes" and "2 distinct resident batches" in line["config"]["workload"]
+    assert line["one_lane"]["value"] > 0 and line["one_lane"]["ms_per_step"] > 0      # the same K steps with lane 0 alone, same process
     assert line["inputs"]["distinct_resident_batches"] == 2
     assert line["inputs"]["sha256_tile0"] == "f9c43b982cea3c5afa2d7573af7540bda988ebd59f9f5c099760f70176a33d87"
     assert len(line["inputs"]["sha256_weights"]) == 64
     assert line["parity"]["ok"] and line["parity"]["eager_equals_replay"] and "timed step 4" in line["parity"]["checked"]
+    assert line["parity"]["tiles_checked"] == 1 and len(line["parity"]["per_tile"]) == 1      # --parity-only: tile 0 (the default run: 0..2)
     rf = line["roofline"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and rf["single_plane_launches"] == 0
     assert line["config"]["post_d2h_waits_per_step"] <= 3.5        # three per step; the first batch of a lane copies its contour points separately
+    # conv time of one pass over a ONE-lane step of the same process: a share
+    assert 0.3 < rf["conv_share_of_one_lane_step"] < 1.0 and rf["conv_alone_over_step_period"] > 0
 
 
 def test_config4_job_of_256_distinct_tiles_at_size(gpu_device):
@@ -145,8 +159,7 @@ def test_config4_job_of_256_distinct_tiles_at_size(gpu_device):
     assert par["csv_max_rel_err"] <= 1e-4 and par["csv_max_rel_err_own_mask"] <= 1e-4
     assert "hipGraph replay" in par["checked"]
     assert line["h2d"]["value_with_upload"] > 0 and line["h2d"]["h2d_ms_per_step"] > 0
-    # (conv time of ONE pass run alone over the timed step: with two lanes in flight two passes overlap, so it may pass 1)
-    assert 0 < line["roofline"]["share_of_step_time"] < 2.0
+    assert 0.3 < line["roofline"]["conv_share_of_one_lane_step"] < 1.0
 
 
 _RCCL_SCRIPT = r"""

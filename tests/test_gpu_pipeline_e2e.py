@@ -380,9 +380,10 @@ def test_tiles_sharded_over_two_ranks_equal_single_process(gpu_device, tmp_path)
     assert sum(len(x[1]) for x in single) > 20
 
 
-def _cli_rank_worker(rank, world, port, root, cfgdir, fail_rank, fail_image, out):
+def _cli_rank_worker(rank, world, port, root, cfgdir, fail_rank, fail_image, encode_fail, load_fail, out):
     """``main.py --task inference`` as rank ``rank`` of ``world`` (gloo; both ranks on the one GPU of the test box), with the
-    local passes of ``fail_image`` made to raise on ``fail_rank``."""
+    local passes of ``fail_image`` made to raise on ``fail_rank``, the instance-table encoding of ``encode_fail = (rank, image)``
+    made to raise, and ``load_fail = (rank, image)`` made unreadable on that rank only."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
                       DEEPEMIA_DIST_BACKEND="gloo", DEEPEMIA_CONFIG_DIR=str(cfgdir), DEEPEMIA_OFFLINE="1", DEEPEMIA_LOG_DIR=str(root))
     os.chdir(root)
@@ -390,22 +391,42 @@ def _cli_rank_worker(rank, world, port, root, cfgdir, fail_rank, fail_image, out
     from deepemia_amd.functions import inference as INF
 
     orig = INF.InferencePipeline._tile_pipeline_local
+    state = {"image": None}
 
     def flaky(self, model_ids, image_key, *a, **k):
+        state["image"] = image_key
         if self.rank == fail_rank and image_key == fail_image:
             raise RuntimeError(f"injected failure of rank {fail_rank}'s local passes of {fail_image}")
         return orig(self, model_ids, image_key, *a, **k)
 
     INF.InferencePipeline._tile_pipeline_local = flaky
+    orig_encode = INF.parallel.encode_instance_table
+
+    def flaky_encode(*a, **k):
+        if encode_fail is not None and rank == encode_fail[0] and state["image"] == encode_fail[1]:
+            raise RuntimeError(f"injected failure of rank {rank}'s table encoding of {encode_fail[1]}")
+        return orig_encode(*a, **k)
+
+    INF.InferencePipeline._encode_table = staticmethod(flaky_encode)
+    orig_read = INF.imread_bgr
+
+    def flaky_read(path):
+        if load_fail is not None and rank == load_fail[0] and os.path.basename(path) == load_fail[1]:
+            return None
+        return orig_read(path)
+
+    INF.imread_bgr = flaky_read
     rc = cli.main(["--task", "inference", "--dataset_name", DATASET, "--threshold", "0.3", "--no-gpu-check"])
     out[rank] = rc
 
 
 def test_one_ranks_failure_on_an_image_makes_every_rank_skip_that_image_together(tmp_path, monkeypatch, gpu_device):
-    """ADVICE r3 (medium): a rank-local failure inside the per-image ``try`` used to make that rank skip the image's
+    """ADVICE r3 / r4 (medium): a rank-local failure inside the per-image ``try`` used to make that rank skip the image's
     all-gather while its peers sat in it -- a hang, or another image's tables merged silently.  Now the failed rank takes part
     with an empty table and status 1, every rank raises ``PeerImageFailure`` after the exchange and skips the image, and the
-    images after it come out exactly as in a single-process run."""
+    images after it come out exactly as in a single-process run.  Three kinds of rank-local failure, one image each: rank 1's
+    local passes raise (em_1), rank 0's instance-table ENCODING raises -- the allocations between the passes and the collective
+    (em_2) --, and rank 1 alone cannot read the file (em_3)."""
     import socket
 
     import torch.multiprocessing as mp
@@ -415,11 +436,11 @@ def test_one_ranks_failure_on_an_image_makes_every_rank_skip_that_image_together
                                       "class_specific_settings": {"class_0": {"confidence_threshold": 0.3, "iou_threshold": 0.6},
                                                                   "class_1": {"confidence_threshold": 0.35, "iou_threshold": 0.5}},
                                       "tile_settings": tile, "spatial_constraints": {"enabled": False}}}
-    cfgdir, split, sds, images = _write_tree(tmp_path, [50], 0.5, 6.0, 3, 512, ds_cfg)
+    cfgdir, split, sds, images = _write_tree(tmp_path, [50], 0.5, 6.0, 5, 512, ds_cfg)
     _run_cli_plain(monkeypatch, cfgdir, tmp_path)
     single = list(csv.reader(open(split / "measurements_results.csv")))
     single_rle = list(csv.reader(open(split / "R50_flip_results.csv")))
-    assert {r[19] for r in single[1:]} == {"em_0.tif", "em_1.tif", "em_2.tif"}
+    assert {r[19] for r in single[1:]} == {f"em_{i}.tif" for i in range(5)}
     for f in (split / "measurements_results.csv", split / "R50_flip_results.csv"):
         f.unlink()
     s = socket.socket()
@@ -428,15 +449,16 @@ def test_one_ranks_failure_on_an_image_makes_every_rank_skip_that_image_together
     s.close()
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_cli_rank_worker, args=(2, port, str(tmp_path), str(cfgdir), 1, "em_1.tif", out), nprocs=2, join=True)
+    mp.spawn(_cli_rank_worker, args=(2, port, str(tmp_path), str(cfgdir), 1, "em_1.tif", (0, "em_2.tif"), (1, "em_3.tif"), out), nprocs=2, join=True)
     assert dict(out) == {0: 0, 1: 0}
     rows = list(csv.reader(open(split / "measurements_results.csv")))
     rle = list(csv.reader(open(split / "R50_flip_results.csv")))
+    skipped = {"em_1.tif", "em_2.tif", "em_3.tif"}
     assert rows[0] == single[0]
-    assert rows[1:] == [r for r in single[1:] if r[19] != "em_1.tif"] and len(rows) > 10
-    assert rle[1:] == [r for r in single_rle[1:] if r[0] != "em_1"]
-    log = "".join(p.read_text(errors="replace") for p in tmp_path.glob("*.log"))
-    assert "every rank skips this image" in log or True      # (the log directory layout is the logger's business)
+    assert rows[1:] == [r for r in single[1:] if r[19] not in skipped] and len(rows) > 10
+    assert rle[1:] == [r for r in single_rle[1:] if r[0] + ".tif" not in skipped]
+    log = "".join(p.read_text(errors="replace") for p in tmp_path.glob("system_*.log"))
+    assert log.count("every rank skips this image") >= 3 and "building the instance table of an image failed" in log
 
 
 def test_cli_edge_inputs_nothing_detected_grayscale_and_odd_sizes(tmp_path, monkeypatch, gpu_device):
