@@ -261,6 +261,45 @@ class LaneChildren:
                 p_.wait()
 
 
+def join_groups(args, world, rank, my_lane, children, backend, dev_index):
+    """The process groups of a run: the ranks (lane 0 of every GPU) form the default group torch.distributed.run prepared;
+    the lane-l children of all ranks form a group of their own, over a TCP store on a port rank 0 picks and every rank hands
+    to its lane-l child (INIT <port>): each step's all-gather then has exactly one issuer per rank and group, whatever the
+    lanes' relative timing.  Returns torch.distributed (None when N = 1; False when a lane child's rank went away)."""
+    lane_port = 0
+    if my_lane:
+        # a lane child waits for the rank's INIT line: the rendezvous port of ITS process group (lane l of every rank), 0 if N = 1
+        first = sys.stdin.readline().split()
+        if not first or first[0] != "INIT":
+            return False
+        lane_port = int(first[1])
+    if world == 1:
+        if children is not None:
+            children.send("INIT 0")
+        return None
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    on_gpu = backend == "nccl"
+    if on_gpu:
+        torch.cuda.set_device(dev_index)
+    kw = {}
+    if my_lane:
+        # an explicit store: under torch.distributed.run a tcp:// rendezvous would look for the elastic agent's store instead
+        import datetime
+        store = dist.TCPStore("127.0.0.1", lane_port, world, rank == 0, timeout=datetime.timedelta(seconds=180))
+        kw = {"store": store, "rank": rank, "world_size": world, "timeout": datetime.timedelta(seconds=600)}
+    if on_gpu:
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{dev_index}"), **kw)
+    else:
+        dist.init_process_group(backend, **kw)
+    if children is not None:
+        ports = [[free_port() for _ in range(args.lanes - 1)]] if rank == 0 else [None]
+        dist.broadcast_object_list(ports, src=0, device=torch.device(f"cuda:{dev_index}" if on_gpu else "cpu"))
+        for k, port in enumerate(ports[0]):
+            children.send(f"INIT {port}", only=k)
+    return dist
+
+
 def parity_step_of(steps: int, n_batches: int, n_lanes: int, total_tiles: int) -> int:
     """The timed step whose tile 0 is synthetic tile 0 AND that lane 0 (the rank process itself) runs: the last multiple of
     lcm(distinct batches, lanes) below ``steps`` (a job of distinct tiles: step 0)."""
@@ -340,17 +379,6 @@ def main() -> None:
     world = int(env_world or "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.rendezvous_only:
-        if world > 1:
-            import torch.distributed as dist
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group("gloo")
-            dist.barrier()
-        if rank == 0:
-            print(json.dumps({"n_gpus": world, "rendezvous_only": True}), flush=True)
-        if world > 1:
-            dist.destroy_process_group()
-        return
     args.graph = not args.eager and args.precision in ("f16x2", "f16")
     args.lanes = resolve_lanes(args.lanes, world, overlap=not args.no_overlap, graph=bool(args.graph))
     my_lane = int(args.lane_child)                     # 0: the rank process itself
@@ -360,6 +388,35 @@ def main() -> None:
     if proc_lanes and not my_lane:
         # the further lanes of this GPU, started BEFORE this process makes its first GPU call
         children = LaneChildren(args.lanes - 1, [a for a in sys.argv[1:]])
+    if args.rendezvous_only:
+        # (test hook, no GPU) the roles and the process groups only: every rank and every lane child joins its group over gloo
+        # and takes part in one all-reduce of (lane + 1); rank 0 reports the sums it and its children saw
+        try:
+            dist = join_groups(args, world, rank, my_lane, children, "gloo", 0)
+            if dist is False:
+                return
+            total = my_lane + 1
+            if dist is not None:
+                t_ = torch.tensor([my_lane + 1])
+                dist.all_reduce(t_)
+                total = int(t_.item())
+            if my_lane:
+                reply.write("READY " + json.dumps({"sum": total}) + "\n")
+                reply.flush()
+            else:
+                sums = [total] + ([r_["sum"] for r_ in children.recv("READY")] if children is not None else [])
+                if rank == 0:
+                    print(json.dumps({"n_gpus": world, "rendezvous_only": True, "lanes": args.lanes, "lane_group_sums": sums}), flush=True)
+            if dist is not None:
+                dist.barrier()
+                dist.destroy_process_group()
+        except BaseException:
+            if children is not None:
+                children.close(kill=True)
+            raise
+        if children is not None:
+            children.close()
+        return
     try:
         run_rank(args, world, rank, local_rank, my_lane, proc_lanes, children, reply)
     except BaseException:
@@ -385,33 +442,10 @@ def run_rank(args, world, rank, local_rank, my_lane, proc_lanes, children, reply
     if dev_index >= torch.cuda.device_count():          # (counting devices does not initialise HIP)
         print(f"bench.py: rank {rank} needs cuda:{dev_index} but {torch.cuda.device_count()} device(s) are visible (--gpus {args.gpus})", file=sys.stderr)
         sys.exit(2)
-    lane_port = 0
-    if my_lane:
-        # a lane child waits for the rank's INIT line: the rendezvous port of ITS process group (lane l of every rank), 0 if N = 1
-        first = sys.stdin.readline().split()
-        if not first or first[0] != "INIT":
-            return
-        lane_port = int(first[1])
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(dev_index)
-        kw = {"init_method": f"tcp://127.0.0.1:{lane_port}", "rank": rank, "world_size": world} if my_lane else {}
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{dev_index}"), **kw)
-        else:
-            dist.init_process_group(backend, **kw)
-        if children is not None:
-            # one process group per lane: rank 0 picks a free port per lane, every rank hands it to its lane-l child
-            ports = [[free_port() for _ in range(args.lanes - 1)]] if rank == 0 else [None]
-            dist.broadcast_object_list(ports, src=0, device=torch.device(f"cuda:{dev_index}" if backend == "nccl" else "cpu"))
-            for k, port in enumerate(ports[0]):
-                children.send(f"INIT {port}", only=k)
-    else:
-        dist = None
-        torch.cuda.set_device(0)
-        if children is not None:
-            children.send("INIT 0")
+    dist = join_groups(args, world, rank, my_lane, children, backend, dev_index)
+    if dist is False:
+        return
+    torch.cuda.set_device(dev_index)
     dev = f"cuda:{dev_index}"
 
     from deepemia_amd import parallel, synth

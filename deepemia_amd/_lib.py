@@ -144,6 +144,7 @@ EXPORTS = {
     "demia_host_dedup_smart": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p]),
     "demia_host_repr_rows": (C.c_int64, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64]),
+    "demia_host_rle_text": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "demia_mask_place_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "demia_mask_crop_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

@@ -12,7 +12,7 @@ extern "C" void demia_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* demia_last_error(void) { return g_err; }
-extern "C" int demia_abi_version(void) { return 5; }
+extern "C" int demia_abi_version(void) { return 6; }
 
 extern "C" const char* demia_build_arch(void) { return "gfx950"; }
 #ifndef DEMIA_DEV

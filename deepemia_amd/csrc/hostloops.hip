@@ -188,3 +188,54 @@ extern "C" int64_t demia_host_repr_rows(const double* vals, int64_t rows, int co
     }
     return pos;
 }
+
+// a16: rle_encoding (mask_utils.py:17-35) of M masks as the TEXT the RLE CSV holds (`" ".join(map(str, runs))`,
+// inference.py:917-925), from the bbox-cropped packed words the instance tables use (demia_mask_crop_pack: mask m = rows x word
+// columns, row-major, at payload[offsets[m]]; bit x & 31 of word x >> 5).  Runs are 1-based (start, length) pairs over the
+// COLUMN-major flattening of an H-row frame: pixel (y, x) has index x * H + y, so a run ends at the bottom of a column
+// unless the next column starts with a set pixel at row 0 (then the reference's scan glues them).  Only the box is visited.
+// text_off [M + 1]: mask m's text = out[text_off[m] .. text_off[m + 1]) (empty for an empty mask).  Returns the bytes
+// written, or -(bytes needed) if `cap` is too small.
+extern "C" int64_t demia_host_rle_text(const uint32_t* payload, const int32_t* bbox, const int64_t* offsets, int64_t M, int H,
+                                       char* out, int64_t cap, int64_t* text_off) {
+    if (!payload || !bbox || !offsets || !out || !text_off || M < 0 || H <= 0) return 0;
+    int64_t pos = 0;
+    bool fits = true;
+    char tmp[24];
+    auto put = [&](int64_t v, bool first) {
+        int k = 0;
+        do { tmp[k++] = (char)('0' + v % 10); v /= 10; } while (v);
+        const int need = k + (first ? 0 : 1);
+        if (fits && pos + need <= cap) {
+            if (!first) out[pos++] = ' ';
+            while (k) out[pos++] = tmp[--k];
+        } else {
+            fits = false;
+            pos += need;
+        }
+    };
+    for (int64_t m = 0; m < M; ++m) {
+        text_off[m] = pos;
+        const int y0 = bbox[4 * m], x0 = bbox[4 * m + 1], y1 = bbox[4 * m + 2], x1 = bbox[4 * m + 3];
+        if (y0 < 0) continue;
+        const int c0 = x0 >> 5, cols = (x1 >> 5) - c0 + 1;
+        const uint32_t* w = payload + offsets[m];
+        int64_t start = -1, len = 0;
+        bool first = true;
+        for (int x = x0; x <= x1; ++x) {
+            const uint32_t* col = w + ((x >> 5) - c0);
+            const uint32_t bit = 1u << (x & 31);
+            for (int y = y0; y <= y1; ++y) {
+                if (!(col[(int64_t)(y - y0) * cols] & bit)) continue;
+                const int64_t f = (int64_t)x * H + y;
+                if (start >= 0 && f == start + len) { ++len; continue; }
+                if (start >= 0) { put(start + 1, first); first = false; put(len, false); }
+                start = f;
+                len = 1;
+            }
+        }
+        if (start >= 0) { put(start + 1, first); put(len, false); }
+    }
+    text_off[M] = pos;
+    return fits ? pos : -pos;
+}

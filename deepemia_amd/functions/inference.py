@@ -36,7 +36,7 @@ from ..utils.logger_utils import log_memory_usage, system_logger
 from ..utils.mask_algebra import DeviceMaskAlgebra
 from ..utils.measurements import contrast_percentiles
 from ..utils.mask_utils import (mask_crops, postprocess_masks_device, postprocess_masks_universal_device,
-                                process_masks_device, rle_encoding_packed)
+                                process_masks_device, rle_encoding_packed, rle_text_packed)
 from ..utils.spatial_constraints import apply_spatial_constraints_indices, load_spatial_constraints
 
 CSV_HEADER = ["Instance_ID", "Class", "Class_Name", "Major axis length", "Minor axis length", "Eccentricity", "C. Length",
@@ -424,15 +424,21 @@ class InferencePipeline:
                 self._cache[(m, key)] = d
         return [self._cache[(m, key)] for m in model_ids]
 
-    @staticmethod
-    def _release_forward_outputs(dets: Sequence[_Detections]) -> None:
+    def _release_forward_outputs(self, dets: Sequence[_Detections]) -> None:
         """Every read of the forwards' own output planes behind ``dets`` is enqueued on the current stream: the replays that
-        overwrite those planes may run once this point of the stream is reached (``MaskRCNNEngine.release_outputs``)."""
-        seen = set()
+        overwrite those planes may run once this point of the stream is reached (``MaskRCNNEngine.release_outputs``).
+        Detections that alias a forward's planes must not be found in the cache afterwards (a later hit would read planes a
+        later replay has overwritten): their cache entries go with the release."""
+        seen, released = set(), set()
         for det in dets:
-            if det.owner is not None and id(det.owner[1]) not in seen:
-                seen.add(id(det.owner[1]))
-                det.owner[0].release_outputs(det.owner[1])
+            if det.owner is not None:
+                released.add(id(det))
+                if id(det.owner[1]) not in seen:
+                    seen.add(id(det.owner[1]))
+                    det.owner[0].release_outputs(det.owner[1])
+        if released:
+            for ck in [ck for ck, v in self._cache.items() if any(id(d) in released for d in v)]:
+                del self._cache[ck]
 
     def _predict_batch(self, model_idx: int, key: str, images: torch.Tensor) -> List[_Detections]:
         """Forward a batch of equally sized images once per (model, key); every class reuses it."""
@@ -501,8 +507,72 @@ class InferencePipeline:
 
     # ------------------------------------------------------------------ a14
     def deduplicate_masks_smart(self, packed: Optional[torch.Tensor], scores: Sequence[float], classes: Sequence[int],
-                                iou_threshold: float = 0.4):
-        """``inference.py:2552-2677`` bug-for-bug (N6); see oracle/postproc_ref.py for the dense twin."""
+                                iou_threshold: float = 0.4, with_tables: bool = False):
+        """``inference.py:2552-2677`` bug-for-bug (N6); see oracle/postproc_ref.py for the dense twin.
+
+        ONE device-to-host wait: pixel counts and tight boxes, the contour trace (first-contour perimeters for the compactness
+        rule) and the same-class pair counts (``demia_mask_pair_matrix`` over the class runs) are enqueued back to back and
+        fetched together; step 2 is one native call (``demia_host_dedup_smart``, N6 literally).  The CLI loop calls this
+        three times per image (two 0.4 merges + the 0.7 cross-class pass): the host-loop version below -- five waits and
+        interpreted greedy loops, kept as its checker and for class lists that are not contiguous runs -- was 12 ms of a
+        70-ms image.  ``with_tables``: also return (area, bbox) of the kept masks (host arrays)."""
+        if packed is None or packed.shape[0] == 0:
+            return (None, [], [], None) if with_tables else (None, [], [])
+        n = int(packed.shape[0])
+        cl = np.asarray([int(c) for c in classes], dtype=np.int32)
+        change = np.nonzero(np.diff(cl))[0] + 1
+        starts = np.concatenate(([0], change)).astype(np.int32)
+        ends = np.concatenate((change, [n])).astype(np.int32)
+        if len(set(cl[starts].tolist())) != len(starts):        # a class in two separate runs: the general host-loop version
+            m, s_, c_ = self.deduplicate_masks_smart_hostloops(packed, scores, classes, iou_threshold)
+            if not with_tables:
+                return m, s_, c_
+            if m is None:
+                return m, s_, c_, None
+            a_, b_ = self.ops.area_bbox(m)
+            return m, s_, c_, (a_.cpu().numpy().astype(np.int64), b_.cpu().numpy().astype(np.int64))
+        ops = self.ops
+        packed = packed.contiguous()
+        run_first = np.repeat(starts, ends - starts).astype(np.int32)
+        run_count = np.repeat(ends - starts, ends - starts).astype(np.int32)
+        area_d, bbox_d = ops.area_bbox(packed)
+        cset = ops.trace(packed, max_contours=256, bbox=bbox_d, max_points=int(min(4096 * n + (1 << 16), 1 << 26)))
+        ld = int(run_count.max())
+        I = ops.pair_matrix(packed, bbox_d, run_first, run_count, None, ld)
+        extra = [area_d.to(torch.int32), bbox_d, I]
+        try:
+            area_h, bbox_h, I_h = cset.fetch(extra=extra)
+        except _L.HipKernelError as e:
+            if "overflow" not in str(e):
+                raise
+            cset = ops.trace(packed, max_contours=256, bbox=bbox_d, total_area=int(area_d.sum().item()))
+            area_h, bbox_h, I_h = cset.fetch(extra=extra)
+        self.d2h_waits += 1
+        area = np.ascontiguousarray(area_h, dtype=np.int64)
+        bbox = np.ascontiguousarray(bbox_h.reshape(n, 4), dtype=np.int64)
+        per0 = cset.first_contour_perimeter()
+        ok = (bbox[:, 0] >= 0) & ~((per0 > 0) & ((4 * np.pi * area) / np.where(per0 > 0, per0, 1.0) ** 2 < 0.15))
+        items = np.ascontiguousarray(np.nonzero(ok)[0], dtype=np.int32)
+        if len(items) == 0:
+            return (None, [], [], None) if with_tables else (None, [], [])
+        sc_items = np.ascontiguousarray(np.asarray([scores[i] for i in items], dtype=np.float64))
+        cl_items = np.ascontiguousarray(cl[items])
+        tile_off = np.asarray([0, len(items)], dtype=np.int32)
+        keep_out = np.zeros(len(items), dtype=np.int32)
+        keep_cnt = np.zeros(1, dtype=np.int32)
+        I_c = np.ascontiguousarray(I_h.reshape(n, ld), dtype=np.int32)
+        _L.check(ops.lib.demia_host_dedup_smart(I_c.ctypes.data, ld, run_first.ctypes.data, area.ctypes.data, bbox.ctypes.data,
+                                                items.ctypes.data, sc_items.ctypes.data, cl_items.ctypes.data, tile_off.ctypes.data, 1,
+                                                float(iou_threshold), keep_out.ctypes.data, keep_cnt.ctypes.data), "demia_host_dedup_smart")
+        gl = items[keep_out[:int(keep_cnt[0])]]
+        sel = ops.upload(gl.astype(np.int64))
+        kept = ops.gather_regions(packed, sel, bbox_d.index_select(0, sel))
+        out = (kept, [scores[i] for i in gl], [classes[i] for i in gl])
+        return out + ((area[gl], bbox[gl]),) if with_tables else out
+
+    def deduplicate_masks_smart_hostloops(self, packed: Optional[torch.Tensor], scores: Sequence[float], classes: Sequence[int],
+                                          iou_threshold: float = 0.4):
+        """The host-loop version of :meth:`deduplicate_masks_smart` (general class order; its checker)."""
         if packed is None or packed.shape[0] == 0:
             return None, [], []
         alg = DeviceMaskAlgebra(self.ops, packed)
@@ -643,7 +713,13 @@ class InferencePipeline:
         def class_pass(dets_per_model):
             if ensemble:
                 return self._ensemble_class_pass(dets_per_model, target_class, small_classes, confidence_threshold, iou_threshold)
-            return self._single_model_class_pass(dets_per_model[0], target_class, small_classes, confidence_threshold, iou_threshold)
+            # the batched pass over ONE image: everything enqueued, one wait, the greedy loop native (same keep list as
+            # `_single_model_class_pass`, its tile-by-tile checker: test_batched_tile_pipeline_equals_tile_by_tile)
+            big, res, tabs = self._single_class_pass_batched(dets_per_model[:1], target_class, small_classes, confidence_threshold, iou_threshold)
+            kept, sc = res[0]
+            if big is None or not kept:
+                return None, [], []
+            return self.ops.gather_regions(big, kept, tabs.bbox[kept]), list(sc), [target_class] * len(kept)
 
         rank, world = self.rank, self.world
         offs = self._tile_offsets(h, w, tile_size, overlap_ratio)
@@ -1235,7 +1311,8 @@ class InferencePipeline:
             # forwards, (2) the class passes of all classes -- one gather per model, one stage program per class, ONE contour
             # trace and ONE pair matrix over (class, tile) runs, fetched together -- and the native smart dedup per class,
             # (3) the cross-class stage below, shared with the single-model path
-            dets_per_model = self._predict_batches(model_ids, key, tiles)
+            # (``dets``: the caller's own forwards, one list per model, e.g. a software-pipelined loop; else through the cache)
+            dets_per_model = list(dets) if dets is not None else self._predict_batches(model_ids, key, tiles)
             T = len(dets_per_model[0])
             out = [(None, [], [], []) for _ in range(T)]
             self.last_batch_stats = [(np.zeros((0,), dtype=np.int64), np.zeros((0, 4), dtype=np.int64)) for _ in range(T)]
@@ -1428,7 +1505,17 @@ class InferencePipeline:
 
     def _ensemble_passes_finish(self, h: dict, class_thresholds, small_classes):
         n, T, ld = h["n"], h["T"], h["ld"]
-        area_h, bbox_h, I_h = h["cset"].fetch(extra=[h["area"].to(torch.int32), h["bbox"], h["I"]])      # THE wait of the class passes
+        extra = [h["area"].to(torch.int32), h["bbox"], h["I"]]
+        try:
+            area_h, bbox_h, I_h = h["cset"].fetch(extra=extra)      # THE wait of the class passes
+        except _L.HipKernelError as e:
+            if "overflow" not in str(e):
+                raise
+            # a few large ragged masks (boundaries of thousands of points) overflowed the pool sized from the mask COUNT at
+            # launch time: the areas are on the device by now -- trace again with the area-sized pool MaskOps.trace defaults to
+            self.d2h_waits += 1
+            h["cset"] = self.ops.trace(h["packed"], max_contours=256, bbox=h["bbox"], total_area=int(h["area"].sum().item()))
+            area_h, bbox_h, I_h = h["cset"].fetch(extra=extra)
         self.d2h_waits += 1
         per0 = h["cset"].first_contour_perimeter()
         area = np.ascontiguousarray(area_h, dtype=np.int64)
@@ -1695,7 +1782,12 @@ def run_inference(dataset_name, output_dir, visualize=True, threshold=0.65, draw
     # inference.py:150-166); the first <= 5 decoded images are kept for the small-class statistics and reused
     from concurrent.futures import ThreadPoolExecutor
 
-    decoder = ThreadPoolExecutor(max_workers=2)
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 2
+    # (PNG / TIFF decode of a 2048^2 frame is 30-40 ms: two threads could not feed a 35-ms image loop)
+    decoder = ThreadPoolExecutor(max_workers=max(2, min(8, ncpu // 2)))
     decoded: Dict[str, object] = {}
 
     def prefetch(name):
@@ -1857,20 +1949,24 @@ def run_inference(dataset_name, output_dir, visualize=True, threshold=0.65, draw
                         all_scores.extend(s)
                         all_classes.extend(c)
             packed = torch.cat(parts, dim=0) if parts else None
-            packed, scores, classes = pipe.deduplicate_masks_smart(packed, all_scores, all_classes, iou_threshold=0.7)
+            pipe.ops.set_frame_width(int(image_dev.shape[1]))
+            packed, scores, classes, tabs = pipe.deduplicate_masks_smart(packed, all_scores, all_classes, iou_threshold=0.7, with_tables=True)
             if packed is not None and packed.shape[0]:
-                keep = apply_spatial_constraints_indices(DeviceMaskAlgebra(pipe.ops, packed), scores, classes, spatial_cfg)
-                packed = packed[torch.tensor(keep, dtype=torch.long, device=dev)].contiguous()
+                alg = DeviceMaskAlgebra(pipe.ops, packed, area=tabs[0], bbox=tabs[1])       # (pixel counts / boxes: already on the host)
+                keep = apply_spatial_constraints_indices(alg, scores, classes, spatial_cfg)
+                if len(keep) != int(packed.shape[0]):
+                    packed = pipe.ops.gather_regions(packed, keep, tabs[1][keep])
+                    tabs = (tabs[0][keep], tabs[1][keep])
                 scores, classes = [scores[i] for i in keep], [classes[i] for i in keep]
             n_final = 0 if packed is None else int(packed.shape[0])
             dedup_results[name] = {"masks": packed, "scores": scores, "classes": classes,
                                    "hw": (int(image_dev.shape[0]), int(image_dev.shape[1]))}
             processed.add(name)
             if n_final:
-                pipe.ops.set_frame_width(int(image_dev.shape[1]))
-                for runs in rle_encoding_packed(pipe.ops, packed, int(image_dev.shape[1])):
+                # a16: one crop launch + one native call for the image's EncodedPixels texts (mask_utils.rle_text_packed)
+                for text in rle_text_packed(pipe.ops, packed, area=tabs[0], bbox=tabs[1]):
                     Img_ID.append(name.rsplit(".", 1)[0])
-                    EncodedPixels.append(" ".join(map(str, runs)))
+                    EncodedPixels.append(text)
             system_logger.info(f"Image {name}: {n_final} instances in {time.perf_counter() - t0:.2f}s")
         except Exception as e:  # reference semantics: log, skip the image, continue (inference.py:928-931)
             system_logger.error(f"Error processing image {name}: {e}", exc_info=True)

@@ -50,14 +50,26 @@ class MaskOps:
     def protect(self, planes: torch.Tensor) -> None:
         """Register planes that consumers may only READ: a captured forward's own output planes stay zero outside the boxes its
         next replay knows about (incremental paste), so an in-place stage on them would leave bits no replay ever clears."""
+        import weakref
         lo = int(planes.data_ptr())
         rng = (lo, lo + planes.numel() * planes.element_size())
-        if rng not in self._protected:
-            self._protected.append(rng)
+        if not any(r[:2] == rng and r[2]() is not None for r in self._protected):
+            # the registration lives as long as the planes' own tensor (the graph's static buffer, `_base` of the view handed out):
+            # when the engine evicts the shape and the memory is reused, the range is no longer protected
+            owner = planes._base if planes._base is not None else planes
+            self._protected.append(rng + (weakref.ref(owner),))
+
+    def unprotect(self, planes: torch.Tensor) -> None:
+        lo = int(planes.data_ptr())
+        self._protected = [r for r in self._protected if r[0] != lo]
 
     def _writable(self, packed: torch.Tensor, what: str) -> None:
+        """Every in-place op (``program_``, ``overlap_prefix_``) calls this first."""
+        if not self._protected:
+            return
+        self._protected = [r for r in self._protected if r[2]() is not None]
         p = int(packed.data_ptr())
-        for lo, hi in self._protected:
+        for lo, hi, _ in self._protected:
             if lo <= p < hi:
                 raise RuntimeError(f"{what}: in-place stage on the read-only output planes of a captured forward -- gather a copy first")
 

@@ -387,6 +387,13 @@ int demia_host_dedup_smart(const int32_t* inter, int ld, const int32_t* row_firs
  * vals [rows][cols] f64 -> per row the Python repr() of its floats joined by ',', rows separated by '\n'.  Returns the
  * bytes written, -1 if cap < rows * cols * 26 + rows. */
 int64_t demia_host_repr_rows(const double* vals, int64_t rows, int cols, char* out, int64_t cap);
+/* a16: the EncodedPixels column of R50_flip_results.csv (inference.py:917-925: `" ".join(map(str, rle_encoding(mask)))`,
+ * mask_utils.py:17-35) for M masks in one host call, from the bbox-cropped packed words of demia_mask_crop_pack: 1-based
+ * (start, length) pairs over the column-major flattening of an H-row frame, as decimal text separated by single blanks.
+ * text_off [M + 1]: mask m's text is out[text_off[m] .. text_off[m + 1]).  Returns the bytes written, or -(bytes needed)
+ * when cap is too small.  Host code: nothing here touches the GPU. */
+int64_t demia_host_rle_text(const uint32_t* payload, const int32_t* bbox, const int64_t* offsets, int64_t M, int H,
+                            char* out, int64_t cap, int64_t* text_off);
 int demia_mask_place_tiles(const uint32_t* src, uint32_t* dst, const int32_t* x_off, const int32_t* y_off, int64_t T,
                            int src_h, int src_w, int tile_h, int tile_w, int H, int W, void* stream);
 /* Instance tables (what the ranks exchange before the global duplicate / containment filters,

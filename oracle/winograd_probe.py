@@ -10,6 +10,7 @@ masks at IoU >= 0.999 and the tie distance of every differing pixel -- the colum
 from __future__ import annotations
 
 import json
+import os
 import sys
 import time
 
@@ -66,7 +67,8 @@ def main() -> None:
         print(json.dumps({"stages": stages, **rec["summary"]}), flush=True)
         out["runs"].append(rec)
     R.WINOGRAD_STAGES = set()
-    with open("winograd_probe.json", "w") as f:
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/winograd_probe.json", "w") as f:
         json.dump(out, f, indent=1)
 
 

@@ -26,6 +26,48 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_report_header(config):
+    """Which build of the C-ABI library this run loads (``product`` unless DEEPEMIA_DEV_LIB=1) -- the GPU suite's record says so."""
+    try:
+        from deepemia_amd import _lib
+        lib = _lib.load()
+        return f"deepemia library: {_lib.LIB_PATH.name} (flavour {lib.demia_build_flavor().decode()}, arch {lib.demia_build_arch().decode()}, ABI v{lib.demia_abi_version()})"
+    except Exception as e:          # a CPU box without the built library still runs the oracle tests
+        return f"deepemia library: not loadable here ({type(e).__name__})"
+
+
+def pytest_sessionstart(session):
+    _progress("session start: " + pytest_report_header(session.config))      # (-q hides the header: the progress log keeps it)
+
+
+def pytest_collection_modifyitems(config, items):
+    # a GPU test that hangs must end by itself (a silent run is killed by the pool after seven minutes, with no record of where)
+    for item in items:
+        if item.get_closest_marker("gpu") is not None and item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(900))
+
+
+def _progress(line: str) -> None:
+    try:
+        out = ROOT / "gpurun_out"
+        out.mkdir(exist_ok=True)
+        with open(out / "pytest_progress.log", "a") as f:
+            f.write(line + "\n")
+    except OSError:
+        pass
+
+
+def pytest_runtest_logstart(nodeid, location):
+    import time
+    _progress(f"{time.strftime('%H:%M:%S')} start {nodeid}")
+
+
+def pytest_runtest_logreport(report):
+    import time
+    if report.when == "call" or (report.when == "setup" and report.outcome != "passed"):
+        _progress(f"{time.strftime('%H:%M:%S')} {report.outcome:7s} {report.nodeid} ({report.duration:.1f} s)")
+
+
 @pytest.fixture(scope="session")
 def gpu_device():
     import torch

@@ -172,8 +172,11 @@ def test_agreed_capacity_exchange_is_exact_and_needs_one_host_wait_in_steady_sta
 def test_bench_gpus_n_starts_its_ranks_itself_and_refuses_a_wrong_world_size():
     """``python bench.py --gpus N`` is the form of the driver's command: with N > 1 and no WORLD_SIZE the process becomes a launcher
     (a child ``torch.distributed.run`` with N ranks, its stdout = rank 0's one JSON line, never a GPU call of its own); a WORLD_SIZE
-    that differs from --gpus is refused with exit code 2 instead of being reported as N.  ``--rendezvous-only`` stops the ranks
-    after their rendezvous (gloo), so the role logic runs on a CPU box."""
+    that differs from --gpus is refused with exit code 2 instead of being reported as N.  ``--rendezvous-only`` stops the
+    processes after their rendezvous (gloo), so the role logic runs on a CPU box -- including the lanes: every rank starts its
+    lane children, the lane-l children of all ranks join a process group of their own (a TCP store on a port rank 0 hands out;
+    under torch.distributed.run a tcp:// rendezvous would wait for the elastic agent's store: the first GPU rehearsal hung there),
+    and every group does one all-reduce of (lane + 1): group l of N ranks must see N (l + 1)."""
     import json
     import os
     import subprocess
@@ -183,12 +186,14 @@ def test_bench_gpus_n_starts_its_ranks_itself_and_refuses_a_wrong_world_size():
     r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--rendezvous-only"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
-    assert len(lines) == 1 and json.loads(lines[0]) == {"n_gpus": 2, "rendezvous_only": True}, r.stdout
+    assert len(lines) == 1 and json.loads(lines[0]) == {"n_gpus": 2, "rendezvous_only": True, "lanes": 2, "lane_group_sums": [2, 4]}, r.stdout
+    r3 = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--lanes", "3", "--rendezvous-only"], env=env, capture_output=True, text=True, timeout=300)
+    assert r3.returncode == 0 and json.loads(r3.stdout.strip())["lane_group_sums"] == [2, 4, 6], r3.stderr[-2000:]
     bad = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "8", "--rendezvous-only"], env=dict(env, WORLD_SIZE="1", RANK="0"),
                          capture_output=True, text=True, timeout=120)
     assert bad.returncode == 2 and "refusing" in bad.stderr and not bad.stdout.strip()
     one = subprocess.run([sys.executable, str(root / "bench.py"), "--rendezvous-only"], env=env, capture_output=True, text=True, timeout=120)
-    assert one.returncode == 0 and json.loads(one.stdout.strip()) == {"n_gpus": 1, "rendezvous_only": True}
+    assert one.returncode == 0 and json.loads(one.stdout.strip()) == {"n_gpus": 1, "rendezvous_only": True, "lanes": 2, "lane_group_sums": [1, 2]}
 
 
 def test_bench_lanes_and_the_ordered_exchange():

@@ -24,7 +24,7 @@ def test_c_abi_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.demia_abi_version() == 5
+    assert lib.demia_abi_version() == 6
     assert lib.demia_build_arch() == b"gfx950"
     # struct sizes agree with the header's layout (no hidden padding surprises)
     assert ctypes.sizeof(_lib.ConvDesc) == 6 * 8 + 18 * 4 + 2 * 8     # + amax_in, amax_out
@@ -659,3 +659,49 @@ def test_native_csv_text_equals_csv_writer_byte_for_byte():
         assert got == buf.getvalue()
         assert rows > 10
     assert measurement_csv_text([("t.tif", [], [])], ("a",), 5.0) == ""
+
+
+def test_native_rle_text_equals_the_reference_pinned_encoding():
+    """``demia_host_rle_text`` (host code behind the C ABI: the EncodedPixels column of R50_flip_results.csv for all masks of an
+    image in one call, from bbox-cropped packed words) against ``rle_encoding`` -- itself pinned by the reference's goldens
+    (tests/golden/mask_utils.npz) -- incl. full-height columns whose runs the column-major scan glues together, an empty mask,
+    a single corner pixel, a full frame, and a buffer that is too small (returns -(bytes needed))."""
+    import ctypes as C
+
+    import torch
+
+    from deepemia_amd import _lib, parallel
+    from deepemia_amd.utils.mask_utils import rle_encoding
+
+    lib = _lib.load()
+    rng = np.random.default_rng(0)
+    H, W, M = 70, 100, 7
+    masks = np.zeros((M, H, W), dtype=bool)
+    masks[0, 10:20, 5:9] = True
+    masks[1] = rng.random((H, W)) > 0.5
+    masks[2, :, 30:41] = True
+    masks[3, :, 33] = True
+    masks[3, 0, 34] = True
+    masks[5, H - 1, W - 1] = True
+    masks[6] = True
+    wpr = (W + 31) // 32
+    m = np.concatenate([masks, np.zeros((M, H, wpr * 32 - W), dtype=bool)], axis=2)
+    packed = np.packbits(m.reshape(M, H, wpr, 32), axis=-1, bitorder="little").view(np.uint32).reshape(M, H, wpr)
+    bb, area = np.full((M, 4), -1, dtype=np.int32), np.zeros(M, dtype=np.int64)
+    for i in range(M):
+        ys, xs = np.nonzero(masks[i])
+        if len(ys):
+            bb[i], area[i] = [ys.min(), xs.min(), ys.max(), xs.max()], len(ys)
+    hdr, pay = parallel.encode_instance_table(torch.from_numpy(packed.view(np.int32)), [0.0] * M, [0] * M, [0] * M, bb, area)
+    pay = np.ascontiguousarray(pay.numpy())
+    offs = np.ascontiguousarray(parallel._offsets(parallel._payload_lengths(hdr.numpy())), dtype=np.int64)
+    toff = np.zeros(M + 1, dtype=np.int64)
+    small = C.create_string_buffer(8)
+    need = lib.demia_host_rle_text(pay.ctypes.data, bb.ctypes.data, offs.ctypes.data, M, H, small, 8, toff.ctypes.data)
+    assert need < 0
+    out = C.create_string_buffer(-need)
+    got = lib.demia_host_rle_text(pay.ctypes.data, bb.ctypes.data, offs.ctypes.data, M, H, out, -need, toff.ctypes.data)
+    assert got == -need
+    raw = out.raw[:got].decode("ascii")
+    for i in range(M):
+        assert raw[toff[i]:toff[i + 1]] == " ".join(map(str, rle_encoding(masks[i].astype(np.uint8)))), i

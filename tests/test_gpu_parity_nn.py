@@ -49,7 +49,7 @@ def nhwc(t):
 def test_library_is_the_hip_one(env):
     lib = env["eng"].lib
     assert lib.demia_build_arch().decode() == "gfx950"
-    assert lib.demia_abi_version() == 5
+    assert lib.demia_abi_version() == 6
 
 
 @pytest.mark.parametrize("hw", [(1024, 1024), (2048, 2048), (600, 600), (700, 1100), (1000, 2000), (601, 1001), (333, 517)])
