@@ -1777,6 +1777,22 @@ def run_inference(dataset_name, output_dir, visualize=True, threshold=0.65, draw
     pipe = InferencePipeline(predictors, dataset_name, inf, global_config)
     dev = pipe.dev
     spatial_cfg = load_spatial_constraints(dataset_name)
+    # Multi-GPU (one process per GPU): what is sharded over the ranks.  A FOLDER of images is sharded by image (image j ->
+    # rank j % world, SURVEY 8(e) "batch": no cross-rank dependency until rank 0 collects the rows it writes); a single large
+    # image -- or fewer images than would keep every rank busy -- by tile, with the per-image all-gather of instance tables
+    # before the global duplicate / containment filters (`gather_and_merge`).  DEEPEMIA_SHARD=images|tiles overrides.
+    job_rank, job_world = pipe.rank, pipe.world
+    shard_images = False
+    if job_world > 1:
+        import torch.distributed as dist
+        box = [images_name, os.environ.get("DEEPEMIA_SHARD", "auto")] if job_rank == 0 else [None, None]
+        dist.broadcast_object_list(box, src=0)             # every rank walks rank 0's list in rank 0's order
+        images_name, mode = box
+        shard_images = mode == "images" or (mode != "tiles" and len(images_name) >= 2 * job_world)
+        if shard_images:
+            pipe.rank, pipe.world = 0, 1                   # every image is whole on its rank: full-image pass + all tiles, no exchange
+        system_logger.info(f"Rank {job_rank}/{job_world}: sharding by {'image' if shard_images else 'tile'}")
+    my_images = images_name[job_rank::job_world] if shard_images else images_name
 
     # decode on a helper thread, one image ahead of the GPU work (the reference preloads with a thread pool too,
     # inference.py:150-166); the first <= 5 decoded images are kept for the small-class statistics and reused
@@ -1799,16 +1815,19 @@ def run_inference(dataset_name, output_dir, visualize=True, threshold=0.65, draw
         img = decoded.pop(name).result()
         return None if img is None else torch.from_numpy(img).to(dev)
 
-    for name in images_name[:6]:
-        prefetch(name)
     sample = []
-    for name in images_name[:5]:
-        t = load(name)
-        if t is not None:
-            sample.append((name, t))
+    if not shard_images or job_rank == 0:
+        for name in images_name[:6]:
+            prefetch(name)
+        for name in images_name[:5]:
+            t = load(name)
+            if t is not None:
+                sample.append((name, t))
     sample_dev = dict(sample)          # the first images are already on the device: no second decode
 
-    Img_ID, EncodedPixels = [], []
+    rle_by_image: Dict[str, List[str]] = {}       # per image the EncodedPixels texts of its final instances (a16)
+    rows_by_image: Dict[str, List[list]] = {}     # per image its measurement rows (a17-a19), measured while the image is still resident
+    keep_masks = os.environ.get("DEEPEMIA_KEEP_MASKS", "0") == "1"
     dedup_results: Dict[str, dict] = {}
     processed = set()
     # The forwards of a GROUP of images are batched across the images and enqueued one group AHEAD of the post-processing
@@ -1818,8 +1837,16 @@ def run_inference(dataset_name, output_dir, visualize=True, threshold=0.65, draw
     tiles_per_image = 1
     if sample:
         tiles_per_image = max(1, len(pipe._tile_offsets(int(sample[0][1].shape[0]), int(sample[0][1].shape[1]), tile_size, overlap_ratio)))
+    if shard_images:
+        box = [tiles_per_image]
+        dist.broadcast_object_list(box, src=0)
+        tiles_per_image = box[0]
     group_size = max(1, min(int(os.environ.get("DEEPEMIA_IMAGE_GROUP", pipe.forward_batch // tiles_per_image)), 16))
-    groups = [images_name[i:i + group_size] for i in range(0, len(images_name), group_size)]
+    groups = [my_images[i:i + group_size] for i in range(0, len(my_images), group_size)]
+    for gn in groups[:3]:                  # decode up to three groups ahead of the image loop on the helper threads
+        for nm in gn:
+            if nm not in sample_dev:
+                prefetch(nm)
     net_stream = torch.cuda.Stream(device=dev)
 
     def enqueue_forwards(ok, model_ids):
@@ -1852,17 +1879,21 @@ def run_inference(dataset_name, output_dir, visualize=True, threshold=0.65, draw
     ahead = launch_group(groups[0], [0]) if groups else None
     if ahead is not None:
         finish_group(ahead[1], 0)
-    if pipe.world > 1:
+    if job_world > 1:
         # every rank must walk the class loop with the SAME small classes: rank 0 (the one that runs the full-image passes the
         # statistics read) decides, the others take its answer -- a rank that could not read one of the first images would
         # otherwise compute its own
-        import torch.distributed as dist
-        box = [sorted(determine_small_classes(pipe.calculate_average_mask_sizes(sample), 50))] if pipe.rank == 0 else [None]
+        box = [sorted(determine_small_classes(pipe.calculate_average_mask_sizes(sample), 50))] if job_rank == 0 else [None]
         dist.broadcast_object_list(box, src=0)
         small_classes = set(box[0])
     else:
         small_classes = determine_small_classes(pipe.calculate_average_mask_sizes(sample), 50)
     system_logger.info(f"Small classes: {sorted(small_classes)}")
+    if shard_images:
+        for nm in [nm for nm in sample_dev if nm not in my_images]:       # statistics images another rank owns
+            sample_dev.pop(nm)
+            pipe.drop_cached(nm)
+    sample = []
     t_all = time.perf_counter()
     targets_all = list(range(num_classes) if classes_to_infer is None else [c for c in classes_to_infer if c < num_classes])
     any_ens = len(predictors) > 1 and any(ensemble_enabled and (not ensemble_small_only or c in small_classes) for c in targets_all)
@@ -1880,13 +1911,13 @@ def run_inference(dataset_name, output_dir, visualize=True, threshold=0.65, draw
     cur_group, cur_items = -1, {}
     for gi, (g, name) in enumerate(flat):
         t0 = time.perf_counter()
-        log_memory_usage(f"Before image {gi + 1}/{len(images_name)}: {name}")
+        log_memory_usage(f"Before image {gi + 1}/{len(my_images)}: {name}")
         if g != cur_group:
             cur_group = g
             cur_items, plan = ahead
             finish_group(plan, g)
-            if g + 2 < len(groups):
-                prefetch_group(groups[g + 2])       # decode two groups ahead on the helper threads
+            if g + 3 < len(groups):
+                prefetch_group(groups[g + 3])       # decode three groups ahead on the helper threads
             ahead = launch_group(groups[g + 1], models_needed) if g + 1 < len(groups) else None
         image_dev = cur_items.pop(name, None)
         if image_dev is None:
@@ -1959,44 +1990,64 @@ def run_inference(dataset_name, output_dir, visualize=True, threshold=0.65, draw
                     tabs = (tabs[0][keep], tabs[1][keep])
                 scores, classes = [scores[i] for i in keep], [classes[i] for i in keep]
             n_final = 0 if packed is None else int(packed.shape[0])
-            dedup_results[name] = {"masks": packed, "scores": scores, "classes": classes,
-                                   "hw": (int(image_dev.shape[0]), int(image_dev.shape[1]))}
+            result = {"masks": packed, "scores": scores, "classes": classes, "hw": (int(image_dev.shape[0]), int(image_dev.shape[1]))}
+            # a16: one crop launch + one native call for the image's EncodedPixels texts (mask_utils.rle_text_packed)
+            texts = rle_text_packed(pipe.ops, packed, area=tabs[0], bbox=tabs[1]) if n_final else []
+            if shard_images or job_rank == 0:
+                # the measurement phase of this image (inference.py:1030-1291) while its masks and pixels are still resident: the
+                # reference walks the folder a second time after the image loop, which gives the same rows; done here, a folder
+                # of any length holds the masks of ONE image group at a time, and a rank measures the images it owns
+                rows_by_image[name] = measure_image(pipe.ops, name, result, inpath, output_dir, metadata, dataset_name, draw_scalebar,
+                                                    visualize, image_dev=image_dev)
+            if not keep_masks:
+                result["masks"] = None
+            dedup_results[name] = result
+            rle_by_image[name] = texts
             processed.add(name)
-            if n_final:
-                # a16: one crop launch + one native call for the image's EncodedPixels texts (mask_utils.rle_text_packed)
-                for text in rle_text_packed(pipe.ops, packed, area=tabs[0], bbox=tabs[1]):
-                    Img_ID.append(name.rsplit(".", 1)[0])
-                    EncodedPixels.append(text)
             system_logger.info(f"Image {name}: {n_final} instances in {time.perf_counter() - t0:.2f}s")
         except Exception as e:  # reference semantics: log, skip the image, continue (inference.py:928-931)
             system_logger.error(f"Error processing image {name}: {e}", exc_info=True)
         finally:
             pipe.drop_cached(name)
-            log_memory_usage(f"After image {gi + 1}/{len(images_name)}: {name}")
+            log_memory_usage(f"After image {gi + 1}/{len(my_images)}: {name}")
     pipe.clear_cache()
     decoder.shutdown(wait=False)
     total = time.perf_counter() - t_all
-    system_logger.info(f"Inference complete: {len(processed)}/{len(images_name)} images, avg "
-                       f"{total / max(len(images_name), 1):.2f}s/image, {pipe.forward_calls} batched forwards")
+    system_logger.info(f"Inference complete: {len(processed)}/{len(my_images)} images, avg "
+                       f"{total / max(len(my_images), 1):.4f}s/image, {pipe.forward_calls} batched forwards")
+    if shard_images:
+        # the ONE exchange of the image-sharded job: every rank's rows and texts go to rank 0, which writes the files
+        mine = (rle_by_image, rows_by_image, {k: {kk: vv for kk, vv in v.items() if kk != "masks"} for k, v in dedup_results.items()}, sorted(processed))
+        gathered = [None] * job_world if job_rank == 0 else None
+        dist.gather_object(mine, gathered, dst=0)
+        if job_rank == 0:
+            for r_rle, r_rows, r_res, r_done in gathered[1:]:
+                rle_by_image.update(r_rle)
+                rows_by_image.update(r_rows)
+                for k, v in r_res.items():
+                    dedup_results.setdefault(k, dict(v, masks=None))
+                processed.update(r_done)
     unprocessed = set(images_name) - processed
-    if unprocessed:
+    if unprocessed and (job_rank == 0 or not shard_images):
         system_logger.warning(f"Unprocessed images: {sorted(unprocessed)}")
-    if pipe.rank != 0:
-        return dedup_results     # every rank holds the same merged result; rank 0 alone writes the output files
+    if job_rank != 0:
+        return dedup_results     # rank 0 alone writes the output files (tile sharding: every rank holds the same merged result)
     try:     # rank 0's host-side output section: no collective below this line
         with open(os.path.join(output_dir, "R50_flip_results.csv"), "w", newline="") as f:
             wri = csv.writer(f)
             wri.writerow(["ImageId", "EncodedPixels"])
-            for a, b in zip(Img_ID, EncodedPixels):
-                wri.writerow([a, b])
+            for name in images_name:               # (the order the reference's image loop appends in, inference.py:917-925)
+                for text in rle_by_image.get(name, []):
+                    wri.writerow([name.rsplit(".", 1)[0], text])
 
-        write_measurements(pipe.ops, dedup_results, inpath, output_dir, metadata, dataset_name, draw_scalebar, visualize)
+        write_measurements(pipe.ops, dedup_results, inpath, output_dir, metadata, dataset_name, draw_scalebar, visualize,
+                           rows_by_image=rows_by_image)
         with open(os.path.join(output_dir, "class_color_legend.txt"), "w") as f:
             f.write("Class Color Legend (BGR)\n")
             for i, cname in enumerate(metadata.thing_classes):
                 f.write(f"Class {i} ({cname}): {CLASS_COLORS[i % len(CLASS_COLORS)]}\n")
     except Exception as e:
-        if pipe.world > 1:
+        if job_world > 1:
             raise OutputWriteError(f"writing the outputs failed on rank 0: {e}") from e
         raise
     return dedup_results
@@ -2117,13 +2168,60 @@ def measurement_csv_text(tiles, thing_classes, min_area: float, psum: str = "0")
     return "".join(h + f + t for h, f, t in zip(heads, floats, tails))
 
 
+def measure_image(ops: MaskOps, test_img: str, data: dict, test_img_path: str, output_dir: str, metadata, dataset_name: str,
+                  draw_scalebar: bool = False, visualize: bool = False, image_dev: Optional[torch.Tensor] = None) -> List[list]:
+    """The measurement phase of ONE image (``inference.py:1030-1291``): scale bar, contours + the 12 measurements of every final
+    mask, optional contrast percentiles, optional overlay / scale-bar debug images; returns the image's CSV rows.
+    ``image_dev``: the decoded image when the caller still holds it on the device (the image loop does: the reference re-reads
+    the file here, which gives the same bytes)."""
+    measure_contrast = bool(get_config().get("measure_contrast_distribution", False))     # inference.py:58: GLOBAL config
+    host = {}
+
+    def im_host():
+        if "im" not in host:
+            host["im"] = image_dev.cpu().numpy() if image_dev is not None else imread_bgr(os.path.join(test_img_path, test_img))
+        return host["im"]
+
+    # N8: the values of the measurement phase's own call (inference.py:1046-1057) are the ones the CSV uses
+    im = im_host() if (draw_scalebar or scale_bar_needs_image(dataset_name)) else None
+    if draw_scalebar and im is not None:
+        debug_image = im.copy()
+        psum, um_pix = detect_scale_bar(debug_image, roi_config=None, dataset_name=dataset_name, draw_debug=True)
+        debug_path = os.path.join(output_dir, f"{test_img}_scalebar_debug.png")
+        if not os.path.exists(debug_path):
+            from PIL import Image
+            Image.fromarray(np.ascontiguousarray(debug_image[..., ::-1])).save(debug_path)
+            system_logger.info(f"Saved scalebar debug visualization to {debug_path}")
+        del debug_image
+    else:
+        psum, um_pix = detect_scale_bar(im, roi_config=None, dataset_name=dataset_name)
+    packed, classes = data["masks"], data["classes"]
+    if packed is None or packed.shape[0] == 0:
+        return []
+    h, wd = data["hw"]
+    ops.set_frame_width(wd)
+    min_area = max(5, h * wd * 0.000005 * 0.05)
+    recs = ops.contours(packed, max_contours=256, um_pix=um_pix)
+    contrast = [(None, None, None)] * int(packed.shape[0])
+    if measure_contrast:
+        # measurements.py:195-215: gray levels under the whole instance mask; the histogram is a device reduction
+        dev_im = image_dev if image_dev is not None else (None if im_host() is None else torch.from_numpy(im_host()).to(ops.device))
+        if dev_im is not None:
+            hist = ops.gray_histogram(packed, dev_im)
+            contrast = [contrast_percentiles(hh) for hh in hist]
+    if visualize and im_host() is not None:
+        write_predictions_png(os.path.join(output_dir, f"{test_img}_predictions.png"), im_host(), mask_crops(ops, packed),
+                              classes, recs, metadata.thing_classes)
+    return measurement_rows(test_img, classes, recs, metadata.thing_classes, min_area, contrast, psum)
+
+
 def write_measurements(ops: MaskOps, dedup_results: Dict[str, dict], test_img_path: str, output_dir: str, metadata,
-                       dataset_name: str, draw_scalebar: bool = False, visualize: bool = False) -> str:
+                       dataset_name: str, draw_scalebar: bool = False, visualize: bool = False,
+                       rows_by_image: Optional[Dict[str, List[list]]] = None) -> str:
     """Measurement phase (``inference.py:983-1291``): one CSV row per external contour that passes
-    the area gate, 20 columns, ``None`` -> empty field, floats through ``csv.writer``."""
+    the area gate, 20 columns, ``None`` -> empty field, floats through ``csv.writer``.  ``rows_by_image``: rows the image
+    loop (or another rank, when images are sharded over ranks) has already measured; images without an entry are measured here."""
     csv_filename = os.path.join(output_dir, "measurements_results.csv")
-    # inference.py:58: read from the GLOBAL config at import time
-    measure_contrast = bool(get_config().get("measure_contrast_distribution", False))
     with open(csv_filename, "w", newline="") as csvfile:
         w = csv.writer(csvfile)
         w.writerow(CSV_HEADER)
@@ -2131,40 +2229,11 @@ def write_measurements(ops: MaskOps, dedup_results: Dict[str, dict], test_img_pa
             data = dedup_results.get(test_img)
             if data is None:
                 continue   # skipped image: the reference finds no masks for it (dedup_results.get(..., {}))
-            # N8: the values of the measurement phase's own call (inference.py:1046-1057) are the ones the CSV uses
-            im = None
-            if draw_scalebar or scale_bar_needs_image(dataset_name):
-                im = imread_bgr(os.path.join(test_img_path, test_img))
-            if draw_scalebar and im is not None:
-                debug_image = im.copy()
-                psum, um_pix = detect_scale_bar(debug_image, roi_config=None, dataset_name=dataset_name, draw_debug=True)
-                debug_path = os.path.join(output_dir, f"{test_img}_scalebar_debug.png")
-                if not os.path.exists(debug_path):
-                    from PIL import Image
-                    Image.fromarray(np.ascontiguousarray(debug_image[..., ::-1])).save(debug_path)
-                    system_logger.info(f"Saved scalebar debug visualization to {debug_path}")
-                del debug_image
+            if rows_by_image is not None and test_img in rows_by_image:
+                rows = rows_by_image[test_img]
             else:
-                psum, um_pix = detect_scale_bar(im, roi_config=None, dataset_name=dataset_name)
-            packed, classes = data["masks"], data["classes"]
-            if packed is None or packed.shape[0] == 0:
-                continue
-            h, wd = data["hw"]
-            ops.set_frame_width(wd)
-            min_area = max(5, h * wd * 0.000005 * 0.05)
-            recs = ops.contours(packed, max_contours=256, um_pix=um_pix)
-            if im is None and (visualize or measure_contrast):
-                im = imread_bgr(os.path.join(test_img_path, test_img))
-            contrast = [(None, None, None)] * int(packed.shape[0])
-            if measure_contrast and im is not None:
-                # measurements.py:195-215: gray levels under the whole instance mask; the histogram is a device reduction
-                hist = ops.gray_histogram(packed, torch.from_numpy(im).to(ops.device))
-                contrast = [contrast_percentiles(hh) for hh in hist]
-            if visualize:
-                if im is not None:
-                    write_predictions_png(os.path.join(output_dir, f"{test_img}_predictions.png"), im, mask_crops(ops, packed),
-                                          classes, recs, metadata.thing_classes)
-            for r in measurement_rows(test_img, classes, recs, metadata.thing_classes, min_area, contrast, psum):
+                rows = measure_image(ops, test_img, data, test_img_path, output_dir, metadata, dataset_name, draw_scalebar, visualize)
+            for r in rows:
                 w.writerow(r)
             csvfile.flush()
     system_logger.info(f"Measurements complete. Results: {csv_filename}")

@@ -1,57 +1,69 @@
-"""Dev script: `main.py --task inference` on N synthetic 2048^2 images (R101, full-image pass + 9 tiles of 1024 with 12.5 % overlap per
-image: 10 forwards of the 800-pixel network per image, containment + overlap rules, both CSVs): images/s and tile-forwards/s.
+"""Dev script / bench side leg: `main.py --task inference` as a user runs it (a subprocess) on N synthetic 2048^2 images (R101,
+full-image pass + 9 tiles of 1024 with 12.5 % overlap per image: 10 forwards of the 800-pixel network per image, containment +
+overlap rules, both CSVs): seconds per image of the image loop and tile-forwards/s, for 1 .. W worker processes on the one GPU.
 
-    python scripts/gpu_cli_throughput.py [n_images=16] [--profile]
+    python scripts/gpu_cli_throughput.py [n_images=32] [workers=1,2,3] [--profile]
 """
-import csv, io, json, logging, os, re, sys, tempfile, time
+import csv, hashlib, json, os, re, subprocess, sys, tempfile, time
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
-import numpy as np, torch
+import numpy as np
 from PIL import Image
 import test_gpu_pipeline_e2e as T
 from deepemia_amd import synth
-args = [a for a in sys.argv[1:] if not a.startswith("--")]
-n = int(args[0]) if args else 16
-profile = "--profile" in sys.argv
-root = Path(tempfile.mkdtemp())
-ds_cfg = {"inference_overrides": {"confidence_mode": "manual",
-                                  "class_specific_settings": {"class_0": {"confidence_threshold": 0.3, "iou_threshold": 0.6, "min_size": 25},
-                                                              "class_1": {"confidence_threshold": 0.35, "iou_threshold": 0.5, "min_size": 5}},
-                                  "tile_settings": {"tile_size": 1024, "overlap_ratio": 0.125, "upscale_factor": 1.0, "edge_filter_enabled": True},
-                                  "spatial_constraints": {"enabled": True, "containment_rules": {1: 0}, "containment_threshold": 0.5,
-                                                          "overlap_rules": {0: {"allow_overlap": False, "max_iou_threshold": 0.3}}}}}
-cfgdir, split, sds, images = T._write_tree(root, [101], 0.5, 6.0, 0, 512, ds_cfg)
-inf = root / "DATASET" / "INFERENCE"
-for i in range(n):
-    Image.fromarray(synth.em_tile(300 + i, 2048)[:, :, ::-1]).save(inf / f"em_{i}.png")
-os.environ["DEEPEMIA_CONFIG_DIR"] = str(cfgdir); os.environ["DEEPEMIA_OFFLINE"] = "1"
-os.chdir(root)
-import main as cli
-from deepemia_amd.utils.logger_utils import system_logger
-buf = io.StringIO()
-h = logging.StreamHandler(buf); h.setLevel(logging.INFO); system_logger.addHandler(h)
-if profile:
-    import cProfile, pstats
-    pr = cProfile.Profile(); pr.enable()
-t0 = time.time()
-rc = cli.main(["--task", "inference", "--dataset_name", T.DATASET, "--threshold", "0.3", "--no-gpu-check"])
-dt = time.time() - t0
-if profile:
-    pr.disable()
-rows = list(csv.reader(open(split / "measurements_results.csv")))
-log = buf.getvalue()
-m = re.search(r"Inference complete: (\d+)/(\d+) images, avg ([0-9.]+)s/image, (\d+) batched forwards", log)
-tm = re.search(r"Inference task finished in ([0-9.]+)s", log)
-loop_s = float(m.group(3)) * n if m else None
-tiles_per_image = 9
-rec = {"rc": rc, "images": n, "wall_s_incl_model_load": dt, "csv_rows": len(rows) - 1,
-       "image_loop_s": loop_s, "image_loop_s_per_image": (loop_s / n if loop_s else None),
-       "tile_forwards_per_image": 1 + tiles_per_image,
-       "tile_forwards_per_s_image_loop": (n * (1 + tiles_per_image) / loop_s if loop_s else None),
-       "task_s": float(tm.group(1)) if tm else None,
-       "tile_forwards_per_s_whole_task": (n * (1 + tiles_per_image) / float(tm.group(1)) if tm else None),
-       "batched_forwards": int(m.group(4)) if m else None}
-print("CLI_THROUGHPUT " + json.dumps(rec))
-if profile:
-    s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats('cumulative').print_stats(60); print(s.getvalue()[:12000])
+
+TILES_PER_IMAGE = 9
+
+
+def make_tree(n):
+    root = Path(tempfile.mkdtemp())
+    ds_cfg = {"inference_overrides": {"confidence_mode": "manual",
+                                      "class_specific_settings": {"class_0": {"confidence_threshold": 0.3, "iou_threshold": 0.6, "min_size": 25},
+                                                                  "class_1": {"confidence_threshold": 0.35, "iou_threshold": 0.5, "min_size": 5}},
+                                      "tile_settings": {"tile_size": 1024, "overlap_ratio": 0.125, "upscale_factor": 1.0, "edge_filter_enabled": True},
+                                      "spatial_constraints": {"enabled": True, "containment_rules": {1: 0}, "containment_threshold": 0.5,
+                                                              "overlap_rules": {0: {"allow_overlap": False, "max_iou_threshold": 0.3}}}}}
+    cfgdir, split, sds, images = T._write_tree(root, [101], 0.5, 6.0, 0, 512, ds_cfg)
+    inf = root / "DATASET" / "INFERENCE"
+    for i in range(n):
+        Image.fromarray(synth.em_tile(300 + i, 2048)[:, :, ::-1]).save(inf / f"em_{i}.png")
+    return root, cfgdir, split
+
+
+def run_cli(root, cfgdir, split, workers, n, profile=False):
+    env = dict(os.environ, DEEPEMIA_CONFIG_DIR=str(cfgdir), DEEPEMIA_OFFLINE="1", DEEPEMIA_WORKERS=str(workers), DEEPEMIA_LOG_DIR=str(root))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable] + (["-m", "cProfile", "-o", str(root / "cli.prof")] if profile else []) + \
+          [str(ROOT / "main.py"), "--task", "inference", "--dataset_name", T.DATASET, "--threshold", "0.3", "--no-gpu-check"]
+    t0 = time.time()
+    r = subprocess.run(cmd, cwd=str(root), env=env, capture_output=True, text=True, timeout=1200)
+    dt = time.time() - t0
+    log = r.stderr + r.stdout
+    loops = [(int(a), float(b)) for a, b in re.findall(r"Inference complete: (\d+)/\d+ images, avg ([0-9.]+)s/image", log)]
+    loop_s = max((a * b for a, b in loops), default=None)          # the slowest rank's image loop
+    tm = re.search(r"Inference task finished in ([0-9.]+)s", log)
+    rows = list(csv.reader(open(split / "measurements_results.csv"))) if (split / "measurements_results.csv").exists() else []
+    sha = hashlib.sha256(b"".join(open(split / f, "rb").read() for f in ("measurements_results.csv", "R50_flip_results.csv"))).hexdigest() if rows else None
+    return {"rc": r.returncode, "workers": workers, "images": n, "wall_s_incl_start_up": dt, "csv_rows": max(len(rows) - 1, 0),
+            "image_loop_s": loop_s, "image_loop_ms_per_image": (1e3 * loop_s / n if loop_s else None),
+            "tile_forwards_per_image": 1 + TILES_PER_IMAGE,
+            "tile_forwards_per_s_image_loop": (n * (1 + TILES_PER_IMAGE) / loop_s if loop_s else None),
+            "task_s": float(tm.group(1)) if tm else None, "outputs_sha256": sha,
+            "stderr_tail": "" if r.returncode == 0 else log[-1500:]}
+
+
+if __name__ == "__main__":
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    n = int(args[0]) if args else 32
+    ws = [int(w) for w in (args[1].split(",") if len(args) > 1 else ["1", "2", "3"])]
+    root, cfgdir, split = make_tree(n)
+    recs = [run_cli(root, cfgdir, split, w, n) for w in ws]
+    for rec in recs:
+        print("CLI_THROUGHPUT " + json.dumps(rec), flush=True)
+    print("CLI_SAME_OUTPUTS", len({r["outputs_sha256"] for r in recs}) == 1)
+    if "--profile" in sys.argv:
+        import pstats
+        run_cli(root, cfgdir, split, 1, n, profile=True)
+        pstats.Stats(str(root / "cli.prof")).sort_stats("cumulative").print_stats(45)
