@@ -175,6 +175,97 @@ def load_or_make_device_tiles(first: int, n: int, size: int, dev, cache_dir):
     return synth.em_tiles_device(range(first, first + n), size, dev)
 
 
+def cli_leg(sd, depth: int, dev, n_images: int, value: float, tmp_root=None) -> dict:
+    """Side leg (never `value`): the DROP-IN itself -- ``main.py --task inference`` run as a user runs it, a subprocess with its own
+    config tree, Detectron2-layout checkpoint and image folder -- on (a) a folder of ``n_images`` synthetic 2048^2 micrographs
+    (full-image pass + 9 overlapping tiles of 1024 each = 10 forwards of the 800-pixel network per image, containment + overlap rules,
+    RLE and measurement CSVs) and (b) BASELINE configs[2]'s shape, ONE 8192^2 image (full-image pass + 16 tiles of 2048^2).  Reports
+    the image loop's seconds per image and tile-forwards/s next to the headline `value` (same network work per forward).
+    Reference loop: src/functions/inference.py:713-942, 2299-2485."""
+    import csv
+    import re
+    import tempfile
+
+    import yaml
+    from PIL import Image
+
+    from deepemia_amd import synth
+    Image.MAX_IMAGE_PIXELS = None
+    root = Path(tmp_root or tempfile.mkdtemp(prefix="deepemia_cli_leg_"))
+    name = "benchfolder"
+
+    def tree(sub, tile, images):
+        base = root / sub
+        (base / "cfg" / "datasets").mkdir(parents=True, exist_ok=True)
+        split = base / "split_dir"
+        cfg = {"bucket": None,
+               "paths": {"split_dir": str(split), "category_json": str(base / "dataset_info.json"), "local_dataset_root": str(base)},
+               "inference_settings": {"confidence_mode": "manual", "ensemble_settings": {"enabled": False},
+                                      "spatial_constraints": {"default": {"enabled": False}}},
+               "l4_performance_optimizations": {"enable_parallel_mask_processing": True}}
+        (base / "cfg" / "config.yaml").write_text(yaml.safe_dump(cfg, sort_keys=False))
+        ds = {"inference_overrides": {"confidence_mode": "manual",
+                                      "class_specific_settings": {"class_0": {"confidence_threshold": 0.3, "iou_threshold": 0.6, "min_size": 25},
+                                                                  "class_1": {"confidence_threshold": 0.35, "iou_threshold": 0.5, "min_size": 5}},
+                                      "tile_settings": tile,
+                                      "spatial_constraints": {"enabled": True, "containment_rules": {1: 0}, "containment_threshold": 0.5,
+                                                              "overlap_rules": {0: {"allow_overlap": False, "max_iou_threshold": 0.3}}}}}
+        (base / "cfg" / "datasets" / f"{name}.yaml").write_text(yaml.safe_dump(ds, sort_keys=False))
+        (base / "dataset_info.json").write_text(json.dumps({name: ["imgs", "labels", ["pore", "throat"]]}))
+        mdir = split / name / f"rcnn_r{depth}"
+        mdir.mkdir(parents=True, exist_ok=True)
+        synth.save_d2_checkpoint(str(mdir / f"model_final_r{depth}.pth"), sd)
+        inf = base / "DATASET" / "INFERENCE"
+        inf.mkdir(parents=True, exist_ok=True)
+        for fn, arr in images:
+            Image.fromarray(arr).save(inf / fn, compress_level=1)
+        return base, split
+
+    def run(base, split, workers):
+        env = dict(os.environ, DEEPEMIA_CONFIG_DIR=str(base / "cfg"), DEEPEMIA_OFFLINE="1", DEEPEMIA_WORKERS=str(workers), DEEPEMIA_LOG_DIR=str(base))
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+            env.pop(k, None)
+        t0 = time.perf_counter()
+        r = subprocess.run([sys.executable, str(ROOT / "main.py"), "--task", "inference", "--dataset_name", name, "--threshold", "0.3", "--no-gpu-check"],
+                           cwd=str(base), env=env, capture_output=True, text=True, timeout=900)
+        wall = time.perf_counter() - t0
+        log = r.stderr + r.stdout
+        loops = [(int(a), float(b)) for a, b in re.findall(r"Inference complete: (\d+)/\d+ images, avg ([0-9.]+)s/image", log)]
+        tm = re.search(r"Inference task finished in ([0-9.]+)s", log)
+        rows = sum(1 for _ in csv.reader(open(split / "measurements_results.csv"))) - 1 if (split / "measurements_results.csv").exists() else 0
+        return {"rc": r.returncode, "processes_on_the_gpu": len(loops), "image_loop_s": max((a * b for a, b in loops), default=None),
+                "task_s": float(tm.group(1)) if tm else None, "wall_s_incl_start_up": wall, "csv_rows": rows,
+                **({} if r.returncode == 0 else {"stderr_tail": log[-800:]})}
+
+    # (a) the folder: device-generated micrographs (gray, like the reference's inputs), written as PNG
+    tiles = synth.em_tiles_device(range(300, 300 + n_images), 2048, dev)[..., 0].cpu().numpy()
+    base, split = tree("folder", {"tile_size": 1024, "overlap_ratio": 0.125, "upscale_factor": 1.0, "edge_filter_enabled": True},
+                       [(f"em_{i:03d}.png", tiles[i]) for i in range(n_images)])
+    fwd_per_image = 10
+    out = {"workload": f"main.py --task inference (subprocess) on {n_images} synthetic 2048^2 images: per image the full-image pass + 9 tiles of "
+                       f"1024 (12.5 % overlap) = {fwd_per_image} forwards, class loops, 0.4 / 0.7 dedups, containment + overlap rules, RLE + measurement CSVs",
+           "folder": {}}
+    for label, workers in (("default", "auto"), ("one_process", "1")):
+        rec = run(base, split, workers)
+        if rec["image_loop_s"]:
+            rec["ms_per_image"] = 1e3 * rec["image_loop_s"] / n_images
+            rec["tile_forwards_per_s"] = n_images * fwd_per_image / rec["image_loop_s"]
+            rec["frac_of_value"] = rec["tile_forwards_per_s"] / value if value else None
+        out["folder"][label] = rec
+    # (b) configs[2]: one 8192^2 image = 16 device-generated tiles side by side
+    t16 = synth.em_tiles_device(range(100, 116), 2048, dev)[..., 0].cpu().numpy()
+    big = np.concatenate([np.concatenate(list(t16[4 * r_:4 * r_ + 4]), axis=1) for r_ in range(4)], axis=0)
+    base2, split2 = tree("c2", {"tile_size": 2048, "overlap_ratio": 0.0, "upscale_factor": 1.0, "edge_filter_enabled": True}, [("big.png", big)])
+    rec = run(base2, split2, "1")
+    if rec["image_loop_s"]:
+        rec["tile_forwards_per_s"] = 17 / rec["image_loop_s"]
+    rec["workload"] = "configs[2] shape: ONE 8192^2 image, full-image pass + 16 tiles of 2048^2 (17 forwards), one process"
+    out["one_8192_image"] = rec
+    import shutil
+    shutil.rmtree(root, ignore_errors=True)
+    return out
+
+
 def free_port() -> int:
     with socket.socket() as s_:
         s_.bind(("127.0.0.1", 0))
@@ -356,6 +447,9 @@ def main() -> None:
                     "per rank); threads: round 4's host threads in one interpreter (exchanges of N > 1 through OrderedExchange)")
     ap.add_argument("--lane-child", type=int, default=0, help=argparse.SUPPRESS)       # (internal) this process is lane l of its rank
     ap.add_argument("--lane-fd", type=int, default=-1, help=argparse.SUPPRESS)         # (internal) reply pipe of a lane child
+    ap.add_argument("--no-cli-leg", action="store_true", help="skip the `cli` side leg (main.py --task inference as a subprocess on a folder "
+                    "of 2048^2 images and on one 8192^2 image; ~40 s)")
+    ap.add_argument("--cli-images", type=int, default=32, help="images of the `cli` side leg's folder")
     ap.add_argument("--no-one-lane-leg", action="store_true", help="skip the `one_lane` side leg (K more steps with lane 0 alone)")
     ap.add_argument("--rendezvous-only", action="store_true", help="(test hook, no GPU) ranks rendezvous over gloo, rank 0 prints "
                     "{n_gpus, rendezvous_only} and everything exits: checks the launcher role on a CPU box")
@@ -1026,6 +1120,13 @@ def run_rank(args, world, rank, local_rank, my_lane, proc_lanes, children, reply
                 line["value"] = None          # a fast path whose results differ from the reference's is not measured
         elif world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"], _ = cpu_baseline(args.depth, args.size, args.threshold, sd, args.cpu_tiles)
+        if world == 1 and not args.no_cli_leg and not args.forward_only and not native and args.precision == "f16x2" and not args.single_stages \
+                and (args.depth, args.size) == (101, 2048):
+            # the drop-in CLI on its own workloads, as a subprocess (the lanes' children only hold their arenas meanwhile)
+            try:
+                line["cli"] = cli_leg(sd, args.depth, dev, args.cli_images, line["value"] or line.get("value_rejected") or 0.0)
+            except Exception as e:          # a side leg never takes the headline down with it
+                line["cli"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(line), flush=True)
         if not ok:
             sys.exit(3)

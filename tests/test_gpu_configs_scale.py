@@ -120,7 +120,7 @@ def test_bench_default_line_carries_its_contract(gpu_device):
     """The default bench command at a small batch: one JSON line with the driver's fields, two lanes, two distinct resident batches,
     the input hashes (tile 0 is byte-reproducible: numpy PCG64), the side figure of the repeated batch, the upload leg, and the
     parity leg on tile 0 of the last timed step over batch 0."""
-    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "6", "--warmup", "1", "--batch", "8", "--parity-only"],
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "6", "--warmup", "1", "--batch", "8", "--parity-only", "--cli-images", "8"],
                        cwd=str(ROOT), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:] + r.stdout[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -140,6 +140,12 @@ def test_bench_default_line_carries_its_contract(gpu_device):
     rf = line["roofline"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and rf["single_plane_launches"] == 0
     assert line["config"]["post_d2h_waits_per_step"] <= 3.5        # three per step; the first batch of a lane copies its contour points separately
+    # the drop-in CLI as a subprocess: a folder of 2048^2 images (two processes on the GPU by default) and one 8192^2 image
+    cli = line["cli"]
+    assert cli["folder"]["default"]["rc"] == 0 and cli["folder"]["one_process"]["rc"] == 0 and cli["one_8192_image"]["rc"] == 0, cli
+    assert cli["folder"]["default"]["processes_on_the_gpu"] == 2 and cli["folder"]["one_process"]["processes_on_the_gpu"] == 1
+    assert cli["folder"]["default"]["csv_rows"] == cli["folder"]["one_process"]["csv_rows"] > 100
+    assert cli["folder"]["default"]["tile_forwards_per_s"] > 0 and cli["one_8192_image"]["csv_rows"] > 100
     # conv time of one pass over a ONE-lane step of the same process: a share
     assert 0.3 < rf["conv_share_of_one_lane_step"] < 1.0 and rf["conv_alone_over_step_period"] > 0
 
@@ -148,7 +154,7 @@ def test_config4_job_of_256_distinct_tiles_at_size(gpu_device):
     """BASELINE configs[4] at its stated size on one GPU: a job of 256 DISTINCT 2048^2 tiles (16 steps of 16; step 0 holds
     the numpy tiles, the rest are generated on the device), the whole per-tile path on every tile, the parity leg on tile 0
     of the timed job (graph replay) against the CPU path, and the eager launch sequence against its replay."""
-    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--total-tiles", "256", "--batch", "16", "--warmup", "1", "--parity-only"],
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--total-tiles", "256", "--batch", "16", "--warmup", "1", "--parity-only", "--no-cli-leg"],
                        cwd=str(ROOT), capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stderr[-2000:] + r.stdout[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])

@@ -380,12 +380,13 @@ def test_tiles_sharded_over_two_ranks_equal_single_process(gpu_device, tmp_path)
     assert sum(len(x[1]) for x in single) > 20
 
 
-def _cli_rank_worker(rank, world, port, root, cfgdir, fail_rank, fail_image, encode_fail, load_fail, out):
+def _cli_rank_worker(rank, world, port, root, cfgdir, fail_rank, fail_image, encode_fail, load_fail, out, shard="tiles"):
     """``main.py --task inference`` as rank ``rank`` of ``world`` (gloo; both ranks on the one GPU of the test box), with the
     local passes of ``fail_image`` made to raise on ``fail_rank``, the instance-table encoding of ``encode_fail = (rank, image)``
     made to raise, and ``load_fail = (rank, image)`` made unreadable on that rank only."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
-                      DEEPEMIA_DIST_BACKEND="gloo", DEEPEMIA_CONFIG_DIR=str(cfgdir), DEEPEMIA_OFFLINE="1", DEEPEMIA_LOG_DIR=str(root))
+                      DEEPEMIA_DIST_BACKEND="gloo", DEEPEMIA_CONFIG_DIR=str(cfgdir), DEEPEMIA_OFFLINE="1", DEEPEMIA_LOG_DIR=str(root),
+                      DEEPEMIA_SHARD=shard, DEEPEMIA_ONE_DEVICE="1")
     os.chdir(root)
     import main as cli
     from deepemia_amd.functions import inference as INF
@@ -395,7 +396,7 @@ def _cli_rank_worker(rank, world, port, root, cfgdir, fail_rank, fail_image, enc
 
     def flaky(self, model_ids, image_key, *a, **k):
         state["image"] = image_key
-        if self.rank == fail_rank and image_key == fail_image:
+        if (fail_rank is None or rank == fail_rank) and image_key == fail_image:
             raise RuntimeError(f"injected failure of rank {fail_rank}'s local passes of {fail_image}")
         return orig(self, model_ids, image_key, *a, **k)
 
@@ -424,7 +425,8 @@ def test_one_ranks_failure_on_an_image_makes_every_rank_skip_that_image_together
     """a rank-local failure inside the per-image ``try`` used to make that rank skip the image's
     all-gather while its peers sat in it -- a hang, or another image's tables merged silently.  Now the failed rank takes part
     with an empty table and status 1, every rank raises ``PeerImageFailure`` after the exchange and skips the image, and the
-    images after it come out exactly as in a single-process run.  Three kinds of rank-local failure, one image each: rank 1's
+    images after it come out exactly as in a single-process run (tiles sharded over the ranks: ``DEEPEMIA_SHARD=tiles``; a
+    folder this size would otherwise be sharded by image).  Three kinds of rank-local failure, one image each: rank 1's
     local passes raise (em_1), rank 0's instance-table ENCODING raises -- the allocations between the passes and the collective
     (em_2) --, and rank 1 alone cannot read the file (em_3)."""
     import socket
@@ -459,6 +461,45 @@ def test_one_ranks_failure_on_an_image_makes_every_rank_skip_that_image_together
     assert rle[1:] == [r for r in single_rle[1:] if r[0] + ".tif" not in skipped]
     log = "".join(p.read_text(errors="replace") for p in tmp_path.glob("system_*.log"))
     assert log.count("every rank skips this image") >= 3 and "building the instance table of an image failed" in log
+
+
+def test_images_sharded_over_two_ranks_write_the_single_process_files(tmp_path, monkeypatch, gpu_device):
+    """SURVEY 8(e) "batch": a FOLDER of images is sharded by image (image j -> rank j % world), no exchange per image; every rank
+    runs the whole per-image path (full-image pass + all tiles, dedups, constraints, RLE, measurements) for the images it owns and
+    rank 0 collects rows and texts once at the end.  Two ranks (gloo, both on this box's GPU): byte-identical CSVs to the
+    single-process run; and an image whose passes raise on its owner is skipped ALONE (the reference's per-image semantics,
+    inference.py:928-931) -- no other rank is involved."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    tile = {"tile_size": 256, "overlap_ratio": 0.125, "upscale_factor": 1.0, "edge_filter_enabled": True}
+    ds_cfg = {"inference_overrides": {"confidence_mode": "manual",
+                                      "class_specific_settings": {"class_0": {"confidence_threshold": 0.3, "iou_threshold": 0.6},
+                                                                  "class_1": {"confidence_threshold": 0.35, "iou_threshold": 0.5}},
+                                      "tile_settings": tile, "spatial_constraints": {"enabled": True, "containment_rules": {1: 0}, "containment_threshold": 0.5}}}
+    cfgdir, split, sds, images = _write_tree(tmp_path, [50], 0.5, 6.0, 5, 512, ds_cfg)
+    monkeypatch.setenv("DEEPEMIA_WORKERS", "1")
+    _run_cli_plain(monkeypatch, cfgdir, tmp_path)
+    single = open(split / "measurements_results.csv").read()
+    single_rle = open(split / "R50_flip_results.csv").read()
+    assert len(single.splitlines()) > 20
+    for fail_image in (None, "em_2.tif"):
+        for f in (split / "measurements_results.csv", split / "R50_flip_results.csv"):
+            f.unlink()
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        out = mp.Manager().dict()
+        mp.spawn(_cli_rank_worker, args=(2, port, str(tmp_path), str(cfgdir), None, fail_image, None, None, out, "images"), nprocs=2, join=True)
+        assert dict(out) == {0: 0, 1: 0}
+        rows, rle = open(split / "measurements_results.csv").read(), open(split / "R50_flip_results.csv").read()
+        if fail_image is None:
+            assert rows == single and rle == single_rle
+        else:
+            assert rows.splitlines() == [ln for ln in single.splitlines() if not ln.endswith("," + fail_image)]
+            assert rle.splitlines() == [ln for ln in single_rle.splitlines() if not ln.startswith(fail_image.rsplit(".", 1)[0] + ",")]
 
 
 def test_cli_edge_inputs_nothing_detected_grayscale_and_odd_sizes(tmp_path, monkeypatch, gpu_device):
