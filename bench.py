@@ -449,7 +449,7 @@ def main() -> None:
     ap.add_argument("--lane-fd", type=int, default=-1, help=argparse.SUPPRESS)         # (internal) reply pipe of a lane child
     ap.add_argument("--no-cli-leg", action="store_true", help="skip the `cli` side leg (main.py --task inference as a subprocess on a folder "
                     "of 2048^2 images and on one 8192^2 image; ~40 s)")
-    ap.add_argument("--cli-images", type=int, default=32, help="images of the `cli` side leg's folder")
+    ap.add_argument("--cli-images", type=int, default=64, help="images of the `cli` side leg's folder")
     ap.add_argument("--no-one-lane-leg", action="store_true", help="skip the `one_lane` side leg (K more steps with lane 0 alone)")
     ap.add_argument("--rendezvous-only", action="store_true", help="(test hook, no GPU) ranks rendezvous over gloo, rank 0 prints "
                     "{n_gpus, rendezvous_only} and everything exits: checks the launcher role on a CPU box")

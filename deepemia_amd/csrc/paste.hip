@@ -113,12 +113,77 @@ __global__ __launch_bounds__(256) void paste_kernel(const PasteP p) {
         }
         __syncthreads();
     }
+    // the bits of one 32-pixel word of the plane (row Y, word column wx): zero outside the box
+    auto word_bits = [&](int Y, int wx) -> uint32_t {
+        uint32_t bits = 0u;
+        const int xa = wx << 5;
+        if (ok && Y >= y0i && Y < y1i && xa < x1i && xa + 32 > x0i) {
+            float gy = ((float)Y + 0.5f - y0) / invh * 2.0f - 1.0f;
+            const float iy = ((gy + 1.0f) * 28.0f - 1.0f) / 2.0f;
+            const float yn = floorf(iy);
+            const float ns = iy - yn, ss = 1.0f - ns;  // weights: n (south part), s
+            const int yi0 = (int)yn, yi1 = yi0 + 1;
+            const bool vy0 = (unsigned)yi0 < 28u, vy1 = (unsigned)yi1 < 28u;
+            const float* r0 = sm + (vy0 ? yi0 : 0) * 28;
+            const float* r1 = sm + (vy1 ? yi1 : 0) * 28;
+            for (int bx = 0; bx < 32; ++bx) {
+                const int X = xa + bx;
+                if (X < x0i || X >= x1i) continue;
+                float we;
+                int xi0;
+                if (col_table) {
+                    we = s_we[X - x0i];
+                    xi0 = s_xi[X - x0i];
+                } else {
+                    float gx = ((float)X + 0.5f - x0) / invw * 2.0f - 1.0f;
+                    const float ix = ((gx + 1.0f) * 28.0f - 1.0f) / 2.0f;
+                    const float xw = floorf(ix);
+                    we = ix - xw;
+                    xi0 = (int)xw;
+                }
+                const float ww = 1.0f - we;
+                const int xi1 = xi0 + 1;
+                const bool vx0 = (unsigned)xi0 < 28u, vx1 = (unsigned)xi1 < 28u;
+                const float nw_ = (vy0 && vx0) ? r0[xi0] : 0.f;
+                const float ne = (vy0 && vx1) ? r0[xi1] : 0.f;
+                const float sw = (vy1 && vx0) ? r1[xi0] : 0.f;
+                const float se = (vy1 && vx1) ? r1[xi1] : 0.f;
+                const float v = nw_ * (ss * ww) + ne * (ss * we) + sw * (ns * ww) + se * (ns * we);
+                if (v >= 0.5f) bits |= 1u << bx;
+            }
+        }
+        return bits;
+    };
+    uint32_t* plane = p.packed + (long)inst * p.out_h * wpr;
+    if (p.prev_bbox) {
+        // INCREMENTAL, two rectangles instead of their union: A = the words the new box touches (pasted), B = the words the
+        // PREVIOUS paste into this plane could have set (cleared where A does not cover them).  When consecutive replays bring
+        // different tiles the two boxes lie anywhere in the frame, and their union -- what this kernel wrote until round 5 --
+        // is mostly zeros between them (0.87 ms per 48-tile step); the rectangles themselves are a few KiB per instance.
+        const int4 pb = reinterpret_cast<const int4*>(p.prev_bbox)[inst];
+        const int ar0 = ok ? y0i : 0, ar1 = ok ? y1i : 0, aw0 = ok ? (x0i >> 5) : 0, aw1 = ok ? ((x1i - 1) >> 5) : -1;
+        const int br0 = pb.x >= 0 ? pb.x : 0, br1 = pb.x >= 0 ? pb.z + 1 : 0, bw0 = pb.x >= 0 ? (pb.y >> 5) : 0, bw1 = pb.x >= 0 ? (pb.w >> 5) : -1;
+        const int anw = aw1 - aw0 + 1, bnw = bw1 - bw0 + 1;
+        const int na = (ar1 - ar0) * anw, nb = (br1 - br0) * bnw;
+        for (int t = blockIdx.x * 256 + tid; t < na + nb; t += gridDim.x * 256) {
+            if (t < na) {
+                const int ry = t / anw, wx = aw0 + (t - ry * anw);
+                plane[(long)(ar0 + ry) * wpr + wx] = word_bits(ar0 + ry, wx);
+            } else {
+                const int u = t - na;
+                const int ry = u / bnw, wx = bw0 + (u - ry * bnw);
+                const int Y = br0 + ry;
+                if (!(Y >= ar0 && Y < ar1 && wx >= aw0 && wx <= aw1)) plane[(long)Y * wpr + wx] = 0u;
+            }
+        }
+        return;
+    }
     const int c0 = ry0 / PASTE_ROWS, c1 = (ry1 - 1) / PASTE_ROWS;
     const int nw = whi - wlo + 1;
     for (int chunk = c0 + blockIdx.x; chunk <= c1; chunk += gridDim.x) {
         const int row0 = chunk * PASTE_ROWS;
         const int nrows = min(PASTE_ROWS, p.out_h - row0);
-        uint32_t* dst = p.packed + ((long)inst * p.out_h + row0) * wpr;
+        uint32_t* dst = plane + (long)row0 * wpr;
         const bool live = ok && (row0 < y1i) && (row0 + nrows > y0i);
         if (!live && nw == wpr && (wpr & 3) == 0) {   // whole rows of zeros, 16-byte stores (rows and the plane base are 16-byte multiples)
             uint4* d4 = reinterpret_cast<uint4*>(dst);
@@ -127,45 +192,7 @@ __global__ __launch_bounds__(256) void paste_kernel(const PasteP p) {
         }
         for (int t = tid; t < nrows * nw; t += 256) {
             const int ry = t / nw, wx = wlo + (t - ry * nw);
-            const int Y = row0 + ry;
-            uint32_t bits = 0u;
-            const int xa = wx << 5;
-            if (live && Y >= y0i && Y < y1i && xa < x1i && xa + 32 > x0i) {
-                float gy = ((float)Y + 0.5f - y0) / invh * 2.0f - 1.0f;
-                const float iy = ((gy + 1.0f) * 28.0f - 1.0f) / 2.0f;
-                const float yn = floorf(iy);
-                const float ns = iy - yn, ss = 1.0f - ns;  // weights: n (south part), s
-                const int yi0 = (int)yn, yi1 = yi0 + 1;
-                const bool vy0 = (unsigned)yi0 < 28u, vy1 = (unsigned)yi1 < 28u;
-                const float* r0 = sm + (vy0 ? yi0 : 0) * 28;
-                const float* r1 = sm + (vy1 ? yi1 : 0) * 28;
-                for (int bx = 0; bx < 32; ++bx) {
-                    const int X = xa + bx;
-                    if (X < x0i || X >= x1i) continue;
-                    float we;
-                    int xi0;
-                    if (col_table) {
-                        we = s_we[X - x0i];
-                        xi0 = s_xi[X - x0i];
-                    } else {
-                        float gx = ((float)X + 0.5f - x0) / invw * 2.0f - 1.0f;
-                        const float ix = ((gx + 1.0f) * 28.0f - 1.0f) / 2.0f;
-                        const float xw = floorf(ix);
-                        we = ix - xw;
-                        xi0 = (int)xw;
-                    }
-                    const float ww = 1.0f - we;
-                    const int xi1 = xi0 + 1;
-                    const bool vx0 = (unsigned)xi0 < 28u, vx1 = (unsigned)xi1 < 28u;
-                    const float nw_ = (vy0 && vx0) ? r0[xi0] : 0.f;
-                    const float ne = (vy0 && vx1) ? r0[xi1] : 0.f;
-                    const float sw = (vy1 && vx0) ? r1[xi0] : 0.f;
-                    const float se = (vy1 && vx1) ? r1[xi1] : 0.f;
-                    const float v = nw_ * (ss * ww) + ne * (ss * we) + sw * (ns * ww) + se * (ns * we);
-                    if (v >= 0.5f) bits |= 1u << bx;
-                }
-            }
-            dst[ry * wpr + wx] = bits;
+            dst[ry * wpr + wx] = live ? word_bits(row0 + ry, wx) : 0u;
         }
     }
 }
@@ -261,7 +288,7 @@ extern "C" int demia_paste_masks(const demia_paste_desc* d, void* stream) {
     DEMIA_REQUIRE(!d->prev_bbox || (d->out_bbox && d->prev_bbox != d->out_bbox), "incremental paste: out_bbox set and distinct from prev_bbox");
     if (d->N * d->D == 0) return DEMIA_OK;
     // whole planes: one block per 16-row chunk; incremental: eight blocks share the chunks of an instance's two boxes
-    const int gx = d->prev_bbox ? 8 : cdiv(d->out_h, PASTE_ROWS);
+    const int gx = d->prev_bbox ? 2 : cdiv(d->out_h, PASTE_ROWS);     // incremental: two rectangles of a few hundred words per instance
     hipLaunchKernelGGL(paste_kernel, dim3(gx, d->N * d->D), dim3(256), 0, (hipStream_t)stream, p);
     DEMIA_CHECK_LAUNCH("paste_kernel");
     return DEMIA_OK;

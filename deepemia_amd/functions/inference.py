@@ -748,9 +748,10 @@ class InferencePipeline:
             # nearest-resize launch to tile scale, one bbox reduction for the edge test, one paste into the global frame
             self.ops.set_frame_width(uw)           # the tile masks' own frame: its right border is pixel uw - 1
             if ensemble:
-                big, res, _ = self._ensemble_class_pass_batched(tile_dets, target_class, small_classes, confidence_threshold, iou_threshold)
+                big, res, pass_tabs = self._ensemble_class_pass_batched(tile_dets, target_class, small_classes, confidence_threshold, iou_threshold)
+                pass_tabs = None          # (a DeviceMaskAlgebra there)
             else:
-                big, res, _ = self._single_class_pass_batched(tile_dets[0], target_class, small_classes, confidence_threshold, iou_threshold)
+                big, res, pass_tabs = self._single_class_pass_batched(tile_dets[0], target_class, small_classes, confidence_threshold, iou_threshold)
             src, xo, yo, un, sc_all = [], [], [], [], []
             for k, t in enumerate(mine):
                 kept, sc = res[k]
@@ -761,13 +762,23 @@ class InferencePipeline:
                 sc_all.extend(sc)
             if src:
                 n = len(src)
-                tm = big[torch.tensor(src, dtype=torch.long, device=self.dev)].contiguous()
-                small = self.ops.place_tiles(tm, [0] * n, [0] * n, tile_size, tile_size, tile_size, tile_size, src_w=uw)
-                self.ops.set_frame_width(tile_size)
+                tabs_ = pass_tabs
+                if (uh, uw) == (tile_size, tile_size) and tabs_ is not None:
+                    # tiles were not upscaled: the nearest resize back to tile scale is the identity, and the tight boxes the
+                    # class pass reduced are the edge filter's boxes -- one gather of the regions, no launch + wait for boxes
+                    bb = np.asarray(tabs_.bbox)[src]
+                    small = self.ops.gather_regions(big, src, bb)
+                    self.ops.set_frame_width(tile_size)
+                else:
+                    tm = big[torch.tensor(src, dtype=torch.long, device=self.dev)].contiguous()
+                    small = self.ops.place_tiles(tm, [0] * n, [0] * n, tile_size, tile_size, tile_size, tile_size, src_w=uw)
+                    self.ops.set_frame_width(tile_size)
+                    bb = None
                 keep = list(range(n))
                 if edge_filter_enabled:
-                    _, bb = self.ops.area_bbox(small)
-                    bb = bb.cpu().numpy()
+                    if bb is None:
+                        _, bb = self.ops.area_bbox(small)
+                        bb = bb.cpu().numpy()
                     keep = [i for i in range(n) if not (bb[i, 0] < 0 or bb[i, 0] < edge or bb[i, 2] > tile_size - edge
                                                         or bb[i, 1] < edge or bb[i, 3] > tile_size - edge)]
                 if keep:
@@ -1990,7 +2001,8 @@ def run_inference(dataset_name, output_dir, visualize=True, threshold=0.65, draw
                     tabs = (tabs[0][keep], tabs[1][keep])
                 scores, classes = [scores[i] for i in keep], [classes[i] for i in keep]
             n_final = 0 if packed is None else int(packed.shape[0])
-            result = {"masks": packed, "scores": scores, "classes": classes, "hw": (int(image_dev.shape[0]), int(image_dev.shape[1]))}
+            result = {"masks": packed, "scores": scores, "classes": classes, "hw": (int(image_dev.shape[0]), int(image_dev.shape[1])),
+                      "area": None if tabs is None else tabs[0], "bbox": None if tabs is None else tabs[1]}
             # a16: one crop launch + one native call for the image's EncodedPixels texts (mask_utils.rle_text_packed)
             texts = rle_text_packed(pipe.ops, packed, area=tabs[0], bbox=tabs[1]) if n_final else []
             if shard_images or job_rank == 0:
@@ -2201,7 +2213,11 @@ def measure_image(ops: MaskOps, test_img: str, data: dict, test_img_path: str, o
     h, wd = data["hw"]
     ops.set_frame_width(wd)
     min_area = max(5, h * wd * 0.000005 * 0.05)
-    recs = ops.contours(packed, max_contours=256, um_pix=um_pix)
+    if data.get("bbox") is not None:       # pixel counts / tight boxes already on the host (the image loop): no reduction, no wait for it
+        recs = ops.contours(packed, max_contours=256, um_pix=um_pix, bbox=ops.upload(np.ascontiguousarray(data["bbox"], dtype=np.int32)),
+                            total_area=int(np.sum(data["area"])))
+    else:
+        recs = ops.contours(packed, max_contours=256, um_pix=um_pix)
     contrast = [(None, None, None)] * int(packed.shape[0])
     if measure_contrast:
         # measurements.py:195-215: gray levels under the whole instance mask; the histogram is a device reduction

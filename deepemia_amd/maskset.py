@@ -324,13 +324,19 @@ class MaskOps:
         return cs
 
     def contours(self, packed: torch.Tensor, max_contours: int = 64, max_points: Optional[int] = None,
-                 um_pix: float = 1.0, measure: bool = True):
+                 um_pix: float = 1.0, measure: bool = True, bbox: Optional[torch.Tensor] = None, total_area: Optional[int] = None):
         """Per mask: external contours in OpenCV's order, with area, perimeter and the 12 measurement
         values.  Returns a list (per mask) of lists of dicts with keys ``points`` (P, 2) int32,
         ``area``, ``perimeter`` and (if ``measure``) ``values`` (12,) float64."""
         if int(packed.shape[0]) == 0:
             return []
-        cs = self.trace(packed, max_contours, max_points)
+        cs = self.trace(packed, max_contours, max_points, bbox=bbox, total_area=total_area)
+        # ONE device-to-host wait: the measurements of every mask's first contours are enqueued right behind the trace and come
+        # over with the counts, the contour tables and the points (a mask with more than four contours falls back to the
+        # sliced copies of ContourSet.host(): five waits, rare)
+        if measure:
+            cs.launch_measure(um_pix, slots=4)
+        cs.fetch(with_points=True)
         return cs.records(um_pix=um_pix, measure=measure)
 
 
