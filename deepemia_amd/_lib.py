@@ -73,6 +73,7 @@ class RoiAlignDesc(C.Structure):
         ("N", C.c_int32), ("R", C.c_int32), ("C", C.c_int32), ("P", C.c_int32), ("dtype", C.c_int32),
         ("boxes", C.c_void_p), ("count", C.c_void_p), ("out", C.c_void_p),
         ("meta", C.c_void_p * 4), ("out_meta", C.c_void_p), ("groups", C.c_int32), ("single", C.c_int32),
+        ("order", C.c_void_p),
     ]
 
 
@@ -125,6 +126,7 @@ EXPORTS = {
     "demia_rpn_workspace_bytes": (C.c_int64, [C.c_int]),
     "demia_rpn_proposals": (C.c_int, [C.POINTER(RpnDesc), C.c_void_p]),
     "demia_roi_align": (C.c_int, [C.POINTER(RoiAlignDesc), C.c_void_p]),
+    "demia_roi_order": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "demia_box_detections": (C.c_int, [C.POINTER(DetsDesc), C.c_void_p]),
     "demia_paste_masks": (C.c_int, [C.POINTER(PasteDesc), C.c_void_p]),
     "demia_unpack_masks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),

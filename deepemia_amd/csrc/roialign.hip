@@ -22,6 +22,7 @@ struct RoiP {
     float* out_meta;        // P32 only, [groups][2]
     int groups;             // P32 only: 1, or N (one scale group per image)
     int single;             // P32 only: write a zero low plane (demia_roialign_desc.single)
+    const int* order;       // launch order (demia_roi_order) or NULL
 };
 
 // Element access policies: bytes per pixel, a lane's byte offset inside a pixel (four channels per lane), load / store
@@ -91,7 +92,8 @@ __global__ __launch_bounds__(256, 6) void roi_align_kernel(const RoiP p) {
     typedef Acc<T> A;
     constexpr bool P32 = A::HEADER != 0;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const long roi = blockIdx.x;  // n*R + r
+    // workgroup b takes ROI order[b] (demia_roi_order: spatial neighbours on the same XCD, close in time); NULL: ROI b
+    const long roi = p.order ? (long)p.order[blockIdx.x] : (long)blockIdx.x;  // n*R + r
     const int PP = p.P * p.P;
     const int n = (int)(roi / p.R), r = (int)(roi % p.R);
     const bool lane_on = lane * 4 < p.C;
@@ -284,7 +286,62 @@ __global__ __launch_bounds__(256, 6) void roi_align_kernel(const RoiP p) {
     }
 }
 
+// Launch order of an image's ROIs: sorted by (pyramid level, row band, column) of the box centre, so that workgroups that run
+// at about the same time read overlapping pixels of one level -- proposals arrive in score order, i.e. scattered over the
+// frame and the levels, and every ROI pulls its whole footprint (1-3 MB at its level) through L1 / L2.  Workgroups go to the
+// eight XCDs round robin by index, each XCD with an L2 of its own: a sorted run of R / 8 ROIs is dealt to ONE XCD (slot j of
+// the image = (s % (R / 8)) * 8 + s / (R / 8) for sorted rank s; plain sorted order when 8 does not divide R).  The OUTPUT row
+// of a ROI does not move: results are bit-identical to the unordered launch.  One workgroup per image, bitonic sort in LDS.
+__global__ __launch_bounds__(1024) void roi_order_kernel(const float* __restrict__ boxes, const int* __restrict__ count, int R,
+                                                         int* __restrict__ order) {
+    __shared__ unsigned long long key[1024];
+    const int n = blockIdx.x, t = threadIdx.x;
+    unsigned long long k = ~0ull;                         // padding beyond R sorts last
+    if (t < R) {
+        const float4 b = reinterpret_cast<const float4*>(boxes)[(long)n * R + t];
+        if (t < count[n]) {
+            const float area = (b.z - b.x) * (b.w - b.y);
+            float lvf = floorf(4.0f + log2f(sqrtf(fmaxf(area, 0.f)) / 224.0f + 1e-8f));
+            lvf = fminf(fmaxf(lvf, 2.0f), 5.0f);
+            const int lv = (int)lvf - 2;
+            const float scale = 1.0f / (float)(4 << lv);
+            const int cy = min(max((int)((b.y + b.w) * 0.5f * scale), 0), 4095);
+            const int cx = min(max((int)((b.x + b.z) * 0.5f * scale), 0), 4095);
+            k = ((unsigned long long)lv << 40) | ((unsigned long long)(cy >> 3) << 28) | ((unsigned long long)cx << 12) | (unsigned)t;
+        } else {
+            k = (1ull << 62) | (unsigned)t;               // unused slots of the table: after every real ROI, in index order
+        }
+    }
+    key[t] = k;
+    __syncthreads();
+    for (int size = 2; size <= 1024; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            const int partner = t ^ stride;
+            if (partner > t) {
+                const bool up = (t & size) == 0;
+                const unsigned long long a = key[t], c = key[partner];
+                if ((a > c) == up) { key[t] = c; key[partner] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    if (t < R) {
+        const int s = t, per = R >> 3;
+        const int slot = (R & 7) == 0 ? (s % per) * 8 + s / per : s;
+        order[(long)n * R + slot] = n * R + (int)(key[s] & 0xfffu);
+    }
+}
+
 }  // namespace
+
+extern "C" int demia_roi_order(const float* boxes, const int32_t* count, int N, int R, int32_t* order, void* stream) {
+    DEMIA_REQUIRE(boxes && count && order && N >= 0, "null pointer");
+    DEMIA_REQUIRE(R > 0 && R <= 1024, "R must be in 1..1024");
+    if (N == 0) return DEMIA_OK;
+    hipLaunchKernelGGL(roi_order_kernel, dim3(N), dim3(1024), 0, (hipStream_t)stream, boxes, count, R, order);
+    DEMIA_CHECK_LAUNCH("roi_order_kernel");
+    return DEMIA_OK;
+}
 
 extern "C" int demia_roi_align(const demia_roialign_desc* d, void* stream) {
     DEMIA_REQUIRE(d && d->boxes && d->count && d->out, "null pointer");
@@ -300,6 +357,7 @@ extern "C" int demia_roi_align(const demia_roialign_desc* d, void* stream) {
     p.out_meta = d->out_meta;
     p.groups = d->groups > 1 ? d->groups : 1;
     p.single = d->single;
+    p.order = d->order;
     DEMIA_REQUIRE(p.groups == 1 || p.groups == d->N, "scale groups: one per image");
     if (d->dtype == DEMIA_P32) {
         DEMIA_REQUIRE(d->C % 32 == 0 && d->out_meta && d->meta[0] && d->meta[1] && d->meta[2] && d->meta[3], "P32 needs C % 32 == 0 and the meta pointers");

@@ -300,6 +300,7 @@ class MaskRCNNEngine:
         self.tdt = torch.bfloat16 if precision == "bf16" else torch.float32
         self._tables: Dict[Tuple[int, int], dict] = {}
         self._cell = cell_anchor_table()
+        self.roi_order = os.environ.get("DEEPEMIA_ROI_ORDER", "1") == "1"     # (A/B switch) ROIAlign workgroups in spatial order per XCD
         self.conv_events = None   # bench hook: list of (start_event, end_event, algorithmic_flops, kernel kind, algorithmic_bytes)
         self.unmatched_keys: List[str] = []
         self._used = set()
@@ -786,6 +787,12 @@ class MaskRCNNEngine:
     def roi_align(self, feats, boxes: torch.Tensor, count: torch.Tensor, P: int) -> torch.Tensor:
         b, r, _ = boxes.shape
         d = _lib.RoiAlignDesc()
+        if self.roi_order and r <= 1024:
+            # launch order: an image's ROIs sorted by (level, row band, column) and dealt to the XCDs in runs (demia_roi_order);
+            # output rows stay where they are -- bit-identical results
+            order = torch.empty((b * r,), dtype=torch.int32, device=self.device)
+            _lib.check(self.lib.demia_roi_order(_lib.ptr(boxes), _lib.ptr(count), b, r, _lib.ptr(order), self._stream()), "demia_roi_order")
+            d.order = _lib.ptr(order)
         if isinstance(feats["p2"], p32.P32):
             out = self.new_p32((b, r, P, P, 256), feats["p2"].groups)
             for i, name in enumerate(("p2", "p3", "p4", "p5")):

@@ -256,8 +256,13 @@ typedef struct demia_roialign_desc {
     float* out_meta;         /* dtype DEMIA_P32: receives {max over the levels' max |x|, min over the levels' s} */
     int32_t groups;          /* dtype DEMIA_P32: <= 1 = one meta pair per tensor; N = metas are [N][2], one scale group per image */
     int32_t single;          /* dtype DEMIA_P32: != 0 writes a zero low plane (`--precision f16`) */
+    const int32_t* order;    /* NULL, or [N * R] from demia_roi_order: workgroup b pools ROI order[b] (the output row of a ROI stays
+                              * where it is: same results, neighbouring workgroups share feature lines in one XCD's L2) */
 } demia_roialign_desc;
 int demia_roi_align(const demia_roialign_desc* d, void* stream);
+/* The launch order for demia_roi_align: per image its R (<= 1024) ROIs sorted by (FPN level, row band, column) of the box centre,
+ * dealt to the eight XCDs in runs of R / 8.  boxes [N, R, 4] f32 (network-input coords), count [N]; order [N * R] i32 out. */
+int demia_roi_order(const float* boxes, const int32_t* count, int N, int R, int32_t* order, void* stream);
 
 /* a3: Fast R-CNN inference ---------------------------------------------------------
  * Replaces FastRCNNOutputLayers.inference / fast_rcnn_inference_single_image:

@@ -11,14 +11,14 @@ cd /tmp && export TMPDIR=/tmp
 set -o pipefail
 CACHE=/tmp/deepemia_tiles_cache
 echo "[collect] tile cache (unprofiled)"
-timeout -k 10 300 python3 $R/bench.py --forward-only --eager --steps 1 --warmup 0 --no-cpu-baseline --no-h2d-leg --lanes 1 --tiles-cache $CACHE > $O/tiles_cache.json 2> $O/tiles_cache.err || { tail -5 $O/tiles_cache.err; exit 1; }
+timeout -k 10 300 python3 $R/bench.py --forward-only --eager --steps 1 --warmup 0 --no-cpu-baseline --no-h2d-leg --no-cli-leg --lanes 1 --tiles-cache $CACHE > $O/tiles_cache.json 2> $O/tiles_cache.err || { tail -5 $O/tiles_cache.err; exit 1; }
 if [ -z "$PMC_ONLY" ]; then
 echo "[collect] kernel trace of the default bench command (tiles from the cache: every kernel in the trace belongs to the path)"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-h2d-leg --tiles-cache $CACHE > $O/bench_under_rocprofv3.json 2> $O/stats.err || { tail -5 $O/stats.err; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-h2d-leg --no-cli-leg --tiles-cache $CACHE > $O/bench_under_rocprofv3.json 2> $O/stats.err || { tail -5 $O/stats.err; exit 1; }
 tail -c 600 $O/bench_under_rocprofv3.json; echo
 # ... and with ONE lane: the conv launches of one pipeline alone, the figure roofline.avg_launch_us (HIP events around every launch of
 # two single-lane eager steps) has to agree with; with two lanes in flight every launch shares the CUs with another grid and lasts longer
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_l1 -o bench -- python3 $R/bench.py --lanes 1 --steps 6 --warmup 2 --no-cpu-baseline --no-h2d-leg --tiles-cache $CACHE > $O/bench_l1_under_rocprofv3.json 2> $O/stats_l1.err || { tail -5 $O/stats_l1.err; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_l1 -o bench -- python3 $R/bench.py --lanes 1 --steps 6 --warmup 2 --no-cpu-baseline --no-h2d-leg --no-cli-leg --tiles-cache $CACHE > $O/bench_l1_under_rocprofv3.json 2> $O/stats_l1.err || { tail -5 $O/stats_l1.err; exit 1; }
 fi
 # The counter passes run the bench's REAL batches (numpy tiles + device-generated ones, two distinct batches): the generated
 # tiles are made once by an UNPROFILED process and cached as .npy under /tmp, so the profiled processes start from an H2D
@@ -26,7 +26,7 @@ fi
 pmc() { # name, counters...
     n=$1; shift
     echo "[collect] pmc pass $n: $*"
-    timeout -k 10 240 rocprofv3 --pmc "$@" --output-format csv -d $O/pmc_$n -o p -- python3 $R/bench.py --forward-only --eager --steps 2 --warmup 1 --no-cpu-baseline --no-h2d-leg --lanes 1 --tiles-cache $CACHE > $O/pmc_$n.json 2> $O/pmc_$n.err || { tail -20 $O/pmc_$n.err; return 1; }
+    timeout -k 10 240 rocprofv3 --pmc "$@" --output-format csv -d $O/pmc_$n -o p -- python3 $R/bench.py --forward-only --eager --steps 2 --warmup 1 --no-cpu-baseline --no-h2d-leg --no-cli-leg --lanes 1 --tiles-cache $CACHE > $O/pmc_$n.json 2> $O/pmc_$n.err || { tail -20 $O/pmc_$n.err; return 1; }
 }
 pmc fetch FETCH_SIZE && pmc write WRITE_SIZE && pmc sq SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE \
     && pmc tcc TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE \

@@ -371,6 +371,37 @@ def test_roi_align_on_oracle_inputs(env):
     assert not out[0, 3:].any()
 
 
+def test_roi_launch_order_is_a_permutation_and_changes_no_bit(env):
+    """``demia_roi_order`` (round 5): workgroup b of ROIAlign pools ROI order[b] -- per image sorted by (FPN level, row band, column)
+    and dealt to the XCDs in runs -- while every ROI's output row stays where it is: the order is a permutation of each image's
+    ROIs (unused slots last) and the pooled tensors are bit-identical with and without it, for 1000 ROIs per image (8 | R: the
+    XCD interleave) and for 100 (plain sorted order)."""
+    import ctypes as C
+
+    from deepemia_amd import _lib
+
+    eng, dev = env["eng"], env["dev"]
+    g = torch.Generator().manual_seed(11)
+    n = 3
+    feats = {k: torch.randn(n, h, w, 256, generator=g).to(dev) for k, (h, w) in {"p2": (64, 80), "p3": (32, 40), "p4": (16, 20), "p5": (8, 10)}.items()}
+    for r, P in ((1000, 7), (100, 14)):
+        cx, cy = torch.rand(n, r, generator=g) * 320, torch.rand(n, r, generator=g) * 256
+        sz = torch.exp(torch.rand(n, r, generator=g) * 5.0) * 3.0
+        boxes = torch.stack([cx - sz, cy - sz * 0.7, cx + sz, cy + sz * 0.7], dim=2).clamp(min=0).contiguous().to(dev)
+        cnt = torch.tensor([r, r - 37, 5], dtype=torch.int32, device=dev)
+        order = torch.empty((n * r,), dtype=torch.int32, device=dev)
+        _lib.check(eng.lib.demia_roi_order(_lib.ptr(boxes), _lib.ptr(cnt), n, r, _lib.ptr(order), eng._stream()), "demia_roi_order")
+        o = order.cpu().numpy().reshape(n, r)
+        for i in range(n):
+            assert sorted(o[i].tolist()) == list(range(i * r, (i + 1) * r))
+        eng.roi_order = True
+        a = eng.roi_align(feats, boxes, cnt, P).clone()
+        eng.roi_order = False
+        b = eng.roi_align(feats, boxes, cnt, P)
+        eng.roi_order = True
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("groups", [1, 2])
 def test_roi_align_on_p32_pyramids_equals_the_f32_kernel_on_the_same_values(env, groups):
     """The P32 variant of the ROIAlign kernel (planes in, planes out, per-image scale groups) against the f32 kernel on the
