@@ -45,6 +45,9 @@ def set_console_log_level(level=logging.INFO) -> None:
             h.setLevel(level)
 
 
+_HAS_GPU = None
+
+
 def log_memory_usage(stage: str = "") -> None:
     """RSS and HBM use at one pipeline stage (reference ``logger_utils.py:66-95``)."""
     try:
@@ -52,7 +55,10 @@ def log_memory_usage(stage: str = "") -> None:
         import torch
 
         rss = psutil.Process().memory_info().rss / 1024 ** 2
-        if torch.cuda.is_available():
+        global _HAS_GPU
+        if _HAS_GPU is None:
+            _HAS_GPU = bool(torch.cuda.is_available())       # (asked once: the call costs ~0.1 ms and this runs twice per image)
+        if _HAS_GPU:
             system_logger.info(f"[{stage}] Memory - RAM: {rss:.1f}MB, GPU: {torch.cuda.memory_allocated() / 1024 ** 3:.2f}GB "
                                f"allocated / {torch.cuda.memory_reserved() / 1024 ** 3:.2f}GB reserved")
         else:
