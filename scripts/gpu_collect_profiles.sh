@@ -3,7 +3,7 @@
 #   1. --kernel-trace --stats of the default bench command            -> gpurun_out/r02/stats/
 #   2. separate --pmc passes of the predictor-only eager bench        -> gpurun_out/r02/pmc_{fetch,write,sq,sq2,tcc}/
 # Reduced on the build host by scripts/pmc_conv_summary.py into profiles/r02_*.  usage: gpu_collect_profiles.sh [tag]
-tag=${1:-r04}
+tag=${1:-r05}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$tag
 mkdir -p $O
@@ -14,7 +14,8 @@ echo "[collect] tile cache (unprofiled)"
 timeout -k 10 300 python3 $R/bench.py --forward-only --eager --steps 1 --warmup 0 --no-cpu-baseline --no-h2d-leg --no-cli-leg --lanes 1 --tiles-cache $CACHE > $O/tiles_cache.json 2> $O/tiles_cache.err || { tail -5 $O/tiles_cache.err; exit 1; }
 if [ -z "$PMC_ONLY" ]; then
 echo "[collect] kernel trace of the default bench command (tiles from the cache: every kernel in the trace belongs to the path)"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-h2d-leg --no-cli-leg --tiles-cache $CACHE > $O/bench_under_rocprofv3.json 2> $O/stats.err || { tail -5 $O/stats.err; exit 1; }
+# (two lanes = the rank and its lane child, two processes: no -o, rocprofv3 then writes <hostname>/<pid>_kernel_stats.csv per process)
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-h2d-leg --no-cli-leg --tiles-cache $CACHE > $O/bench_under_rocprofv3.json 2> $O/stats.err || { tail -5 $O/stats.err; exit 1; }
 tail -c 600 $O/bench_under_rocprofv3.json; echo
 # ... and with ONE lane: the conv launches of one pipeline alone, the figure roofline.avg_launch_us (HIP events around every launch of
 # two single-lane eager steps) has to agree with; with two lanes in flight every launch shares the CUs with another grid and lasts longer

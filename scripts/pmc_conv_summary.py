@@ -99,8 +99,15 @@ with open(DST / f"{tag}_conv_{prec}_by_kernel_pmc.csv", "w", newline="") as f:
         w.writerow([k, grid, int(g["n"]), round(g["cyc"] / g["n"]), round(g["cyc"] / cyc, 4), round(g["busy"] / (g["cyc"] * 1024.0), 4),
                     round(g["mfma"] / g["n"]), round(g["wait"] / max(g["wave"], 1.0), 4), round(g["bytes"] / g["n"]), round(g["bytes"] / g["cyc"], 1)])
 
-for path in (SRC / "stats").rglob("*kernel_stats.csv"):
-    shutil.copy(path, DST / f"{tag}_bench_{prec}_b{batch}_whole_path_kernel_stats.csv")
+# the default command: one table per PROCESS on the GPU (round 5: lanes 1.. are child processes of the rank) -- the table with the
+# most conv launches is the rank's (it also runs the warm-up solo pass and the side legs)
+tables = sorted((SRC / "stats").rglob("*kernel_stats.csv"),
+                key=lambda p_: -sum(int(r["Calls"]) for r in csv.DictReader(open(p_)) if kernel in r["Name"]))
+for k, path in enumerate(tables):
+    shutil.copy(path, DST / f"{tag}_bench_{prec}_b{batch}_whole_path_kernel_stats{'' if k == 0 else f'_lane{k}'}.csv")
+    rows = [r for r in csv.DictReader(open(path)) if kernel in r["Name"]]
+    calls, tot = sum(int(r["Calls"]) for r in rows), sum(float(r["TotalDurationNs"]) for r in rows)
+    print(f"default command, process {k}: {calls} {kernel} launches, {tot / max(calls, 1) / 1e3:.1f} us per launch")
 line = [l for l in (SRC / "bench_under_rocprofv3.json").read_text().splitlines() if l.startswith("{")]
 if line:
     (DST / f"{tag}_bench_{prec}_b{batch}_whole_path_under_rocprofv3.json").write_text(line[-1] + "\n")
