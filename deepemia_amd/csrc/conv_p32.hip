@@ -1088,440 +1088,8 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 2 : 1) void conv_p32_k
     }
 }
 
-#if P32_DEV_TILES   // experiments that did not pay, kept for same-box A/B through tile hints (scripts/build_variant.sh -DP32_DEV_TILES=1)
-// ---------------------------------------------------------------------------------------------------------------------
-// Pointwise (1x1, stride 1) layers as a PING-PONG of two four-wave groups inside one persistent workgroup.
-//
-// The plain kernel above keeps one workgroup per CU, so a tile's phases take turns: the K loop (matrix pipe, LDS), then the
-// epilogue (vector ALU) which is also the tile's memory phase (residual lines in, planes out).  On the short-K layers of the
-// bottlenecks the three cost about the same -- res4 conv3 at 48 tiles: 20 us K loop, 7 us epilogue arithmetic, 14 us waiting
-// for memory per 256 x 256 tile -- and every CU reaches its memory phase at the same moment, so HBM is asked for twice what it
-// delivers while the K loops leave it idle.  Here the eight waves are two GROUPS of four (a 2 x 2 grid of
-// 64 x 128 wave tiles over a 128 x 256 tile each).  In every phase one group runs the K loop of its tile while the other runs
-// the epilogue of the tile it finished one phase earlier; then they swap.  The K-loop group owns the two LDS stages; the
-// epilogue group works out of registers (its accumulators) and a small per-wave LDS image.  The matrix pipe always has a
-// group feeding it, and memory traffic is spread over the whole phase instead of a burst at its end.
-//
-// gfx950 has one barrier per workgroup, so BOTH groups execute the same barriers: a phase is `ksteps` steps, each ending in
-// `s_barrier`; the K group does one K-step per step, the epilogue group `ips = ceil(16 / ksteps)` of its 16 items (a hook
-// inside p32_epilogue_planes) and then empty steps.  Barrier counts are equal BY CONSTRUCTION: every wave runs the same phase
-// loop and the same step loop; validity flags skip work, never a barrier.
-// The DMA for a phase's first K-step is issued by the PREVIOUS phase's K group during its last step (the stage it would have
-// filled for itself is free then), so a phase starts computing at once.
-// Results are bit-identical to the plain kernel: the same three MFMAs per accumulator and K-step in the same order, the same
-// epilogue code.
-// OUTCOME (round 4, dev build, tile hint 60): correct on the first run and never hung -- and 0.6-0.95 x the plain kernel's speed
-// (res4 conv3 at 48 tiles 392 vs 348 us, res4 conv1 300 vs 190, res2 conv3 841 vs 796).  With no operand traffic and no epilogue
-// its K-step still takes 0.9-1.0 us for the 0.37 us of MFMAs in it: ONE K-loop wave per SIMD has nothing to cover its fragment
-// reads (64 KiB out of LDS per step, all four waves at once right behind the barrier) and the barrier itself, and the group tile
-// that fits the registers beside the epilogue's working set (128 x 128: 64 accumulator registers; 128 x 256 spilled 45) has half
-// the MFMAs per barrier of the plain tile.  The overlap works as designed -- the epilogue costs nothing extra -- but it is bought
-// with a K loop 2.4 x slower per MFMA.  Kept as a dev tile for the record.
-__global__ __launch_bounds__(512, 1) void conv_p32_pp1x1_kernel(const ConvQ p) {
-    constexpr int HM = 128, BN = 128;                     // a group's tile (wave tiles of 64 x 64: 64 accumulator registers, so
-                                                          // that K-loop operands and the epilogue's working set fit beside them)
-    constexpr int STAGE = (HM + BN) * 128;                // 32 KiB: one K-step of A (128 rows) and B (128 rows)
-    constexpr int EIMG = 32 * (2 * 32 + 4) * 4;           // the epilogue's per-wave image at TN = 2 (32 x 64 floats + padding)
-    constexpr int NITEMS = 8;                             // epilogue items per wave tile (2 passes of 32 rows x 4 items)
-    constexpr int NSTG = 3;                               // LDS stages: a K-step's operands are requested TWO steps ahead (a step of
-                                                          // a 128 x 128 tile is shorter than an L2 round trip)
-    extern __shared__ __attribute__((aligned(16))) char smem[];     // [3 stages][4 images]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int half = wave >> 2, q = wave & 3, wmh = q >> 1, wnh = q & 1;
-    const int S = p.ksteps, T = p.nwg, G = (int)gridDim.x;
-    const int nIter = (T + 2 * G - 1) / (2 * G);
-    const int bl = xcd_remap(blockIdx.x, G);              // tiles that share their rows land on one XCD
-    const i32x4 rsrc_a = make_rsrc(p.in, p.in_bytes), rsrc_b = make_rsrc(p.w, p.w_bytes);
-    const unsigned lds0 = (unsigned)(__SIZE_TYPE__)((lds_void*)smem);
-    const unsigned pixb = (unsigned)(p.Cin * 4);
-
-    auto tile_of = [&](int iter, int h) { return (iter * G + bl) * 2 + h; };
-    // K-step `s_` of tile `t` -> stage `st`: this wave's 4 of the 16 A pieces and 4 of the 16 B pieces (a piece = 8 rows = 1 KiB),
-    // in two halves so that the K loop can put them BETWEEN its MFMA groups (a K-loop wave is alone on its SIMD: whatever it
-    // issues in front of its MFMAs is time the matrix pipe idles)
-    auto issue_a = [&](int st, int t, int s_) {
-        const int tm = t / p.ntn;
-        const int m0_ = tm * HM;
-        const unsigned sbase = __builtin_amdgcn_readfirstlane(lds0 + st * STAGE);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int piece = q + 4 * j;
-            const int row = piece * 8 + (lane >> 3);
-            const int csw = (lane & 7) ^ ((row >> 1) & 7);
-            const int m = m0_ + row;
-            const unsigned vo = m < p.M ? 128u + (unsigned)m * pixb + (unsigned)(csw * 16) + (unsigned)s_ * 128u : (unsigned)(csw * 16);
-            dma16(rsrc_a, sbase + piece * 1024, vo, 0u);
-        }
-    };
-    auto issue_b = [&](int st, int t, int s_) {
-        const int tm = t / p.ntn, tn = t - tm * p.ntn;
-        const int n0_ = tn * BN;
-        const unsigned sbase = __builtin_amdgcn_readfirstlane(lds0 + st * STAGE);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int piece = q + 4 * j;
-            const int row = piece * 8 + (lane >> 3);
-            const int csw = (lane & 7) ^ ((row >> 1) & 7);
-            const int co = n0_ + row;
-            const unsigned vo = (unsigned)(((co >> 6) * S) * 8192 + (co & 63) * 128 + csw * 16);
-            dma16(rsrc_b, sbase + HM * 128 + piece * 1024, vo, (unsigned)s_ * 8192u);
-        }
-    };
-    f32x4 acc[4][4];
-    auto zero_acc = [&]() {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    };
-    // fragment addresses (see the plain kernel): row r of a region at r * 128, logical 16-byte chunk c at (c ^ ((r >> 1) & 7)) * 16
-    // One K-step: fragments of stage `st`, then the three MFMA terms with the DMA of global step `gi` (tile `ti`, K-step `si`, if
-    // `do_issue`) between them.
-    auto kstep = [&](bool do_compute, int st, bool do_issue, int gi, int ti, int si) {
-        if (!do_compute) {
-            if (do_issue) { issue_a(gi % NSTG, ti, si); issue_b(gi % NSTG, ti, si); }
-            return;
-        }
-        const int swz = ((lane & 15) >> 1) & 7, kq = lane >> 4;
-        const char* sa = smem + st * STAGE + (wmh * 64 + (lane & 15)) * 128;
-        const char* sbp = smem + st * STAGE + HM * 128 + (wnh * 64 + (lane & 15)) * 128;
-        const int c0 = (kq ^ swz) * 16, c1 = ((4 + kq) ^ swz) * 16;
-        f16x8 ah[4], al[4], bh[4], blo[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ah[i] = *reinterpret_cast<const f16x8*>(sa + c0 + i * 2048);
-            blo[i] = *reinterpret_cast<const f16x8*>(sbp + c1 + i * 2048);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            al[i] = *reinterpret_cast<const f16x8*>(sa + c1 + i * 2048);
-            bh[i] = *reinterpret_cast<const f16x8*>(sbp + c0 + i * 2048);
-        }
-        // The three terms of a product go into an accumulator in the plain kernel's order (smallest first), but term by term over
-        // ALL sixteen accumulators: three back-to-back MFMAs on one accumulator would each wait for the one before.
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], blo[j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (do_issue) issue_a(gi % NSTG, ti, si);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (do_issue) issue_b(gi % NSTG, ti, si);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-    };
-    auto step_barrier = [&]() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-
-    // Global step g belongs to phase g / S (K group (g / S) & 1, tile iteration (g / S) >> 1) and is K-step g % S of that tile; its
-    // operands live in stage g % 3 and are requested at global step g - 2 by whichever group runs the K loop then.
-    // which (tile, K-step) global step g is, and whether it exists
-    auto global_step = [&](int g, int& t2, int& s2) -> bool {
-        const int ph2 = g / S;
-        s2 = g - ph2 * S;
-        t2 = tile_of(ph2 >> 1, ph2 & 1);
-        if (ph2 >= 2 * nIter || t2 >= T) return false;
-        return !((P32_ABLATE & 3) && g >= NSTG);             // (timing-only: no operand traffic after the first steps)
-    };
-    // prologue: global steps 0 and 1
-    if (half == 0) {
-        int t2, s2;
-        if (global_step(0, t2, s2)) { issue_a(0, t2, s2); issue_b(0, t2, s2); }
-        if (global_step(1, t2, s2)) { issue_a(1, t2, s2); issue_b(1, t2, s2); }
-    }
-    step_barrier();
-    zero_acc();
-    int gstep = 0;                                        // barrier-steps done
-    const int ips = (NITEMS + S - 1) / S;                 // epilogue items per step
-    char* const eimg = smem + NSTG * STAGE - (wave - q) * EIMG;     // p32_epilogue_planes adds (tid >> 6) * EIMG: image q of the four
-
-    for (int ph = 0; ph <= 2 * nIter; ++ph) {
-        const int hk = ph & 1;                            // the group in its K loop
-        if (half == hk) {
-            const int t = tile_of(ph >> 1, hk);
-            const bool valid = ph < 2 * nIter && t < T;
-            for (int s_ = 0; s_ < S; ++s_) {
-                int t2, s2;
-                const bool issued = global_step(gstep + 2, t2, s2);
-                kstep(valid, gstep % NSTG, issued, gstep + 2, t2, s2);
-                // the operands of step g + 1 (requested a step ago) have to be there, the request just made may stay in flight --
-                // except at the phase's last step: the other group takes over the K loop and waits for nothing it did not issue
-                if (issued && s_ + 1 < S) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                else step_barrier();
-                ++gstep;
-            }
-        } else {
-            const int t = ph >= 1 ? tile_of((ph - 1) >> 1, half) : T;
-            int done = 0, cnt = 0;
-            // (a bare barrier: the epilogue's loads and stores stay in flight across it -- that is the point)
-            auto hook = [&]() {
-                if (++cnt == ips) {
-                    cnt = 0;
-                    if (done < S) { asm volatile("s_barrier" ::: "memory"); ++done; }
-                }
-            };
-            if (ph >= 1 && t < T && (P32_ABLATE & 2048)) {       // timing-only: no epilogue, accumulators kept alive
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(acc[i][j]));
-                zero_acc();
-            } else if (ph >= 1 && t < T) {
-                const int tm = t / p.ntn, tn = t - tm * p.ntn;
-                const int m0 = tm * HM, n0 = tn * BN;
-                const GroupScales gs = load_group_scales(p, m0, true);
-                p32_epilogue_planes<2, 2, 2, 2>(p, gs, eimg, [&](int i, float* e) { write_acc16<2, 2 * 32 + 4>(acc[2 * i], acc[2 * i + 1], e, lane); },
-                                                wmh, wnh, m0, n0, q == 0 && lane == 0, hook);
-                zero_acc();
-            }
-            while (done < S) { asm volatile("s_barrier" ::: "memory"); ++done; }
-            gstep += S;
-        }
-    }
-}
-
-int launch_pp1x1(ConvQ p, hipStream_t st) {
-    constexpr int smem = 3 * (128 + 128) * 128 + 4 * 32 * (2 * 32 + 4) * 4;      // 133 120 bytes
-    p.ntn = p.CoutPad / 128;
-    p.nwg = cdiv(p.M, 128) * p.ntn;                        // 128 x 128 tiles
-    const int grid = p.nwg / 2 < 256 ? (p.nwg + 1) / 2 : 256;
-    auto k = conv_p32_pp1x1_kernel;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(k, dim3(grid), dim3(512), smem, st, p);
-    DEMIA_CHECK_LAUNCH("conv_p32_pp1x1_kernel");
-    return DEMIA_OK;
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// The same tile as a PING-PONG of two wave groups (waves 0-3 = the upper half of the rows, waves 4-7 = the lower half;
-// wave w and wave w + 4 share a SIMD).  The plain kernel above runs all eight waves in lockstep -- fragment reads, MFMAs
-// and the barrier hit both waves of a SIMD at the same moment, and timing-only builds show its matrix pipe waiting for
-// LDS most of the time it is not busy (all work 1810 us, MFMAs alone 1090, everything but the MFMAs 914 on the largest
-// 3x3 layer: they add up instead of overlapping).  Here a K-step is four phases separated by workgroup barriers; in each
-// phase ONE group issues nothing but MFMAs on fragments it already holds in registers (24 of them, 768 matrix-pipe
-// cycles) while the OTHER group reads its next twelve fragments from LDS and requests the next K-step's operands:
-//
-//      phase 4t     group 0: LOAD(t, 0) + DMA(t+1): its A rows, B rows 0..127      group 1: MFMA(t-1, 1)
-//      phase 4t + 1 group 0: MFMA(t, 0)                                             group 1: LOAD(t, 0) + DMA(t+1): half of its A rows
-//      phase 4t + 2 group 0: LOAD(t, 1) + DMA(t+1): B rows 128..255                group 1: MFMA(t, 0)
-//      phase 4t + 3 group 0: MFMA(t, 1), then waits for its DMA(t+1)               group 1: LOAD(t, 1) + DMA(t+1): the other half
-//
-// so every SIMD always has one wave feeding the matrix pipe.  Stage (t+1) % 2 was last read in phase 4t - 1, its DMA is
-// issued from phase 4t on and waited for (by the waves that issued it, before a barrier) ahead of its first read in phase
-// 4t + 4 (group 0) / 4t + 5 (group 1): two to four phases of flight, like the plain kernel's one K-step.  A LOAD phase
-// ends with s_waitcnt lgkmcnt(0) before its barrier, so no read of a stage is still in flight when the other group starts
-// refilling it.  Fragments are single-buffered (48 registers): a group's LOAD and MFMA phases never overlap.
-template <int TM, int TN>
-__global__ __launch_bounds__(512, 2) void conv_p32_pp_kernel(const ConvQ p) {
-    constexpr int WM = 2, WN = 4;
-    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int STAGE = (BM + BN) * 128;
-    constexpr int QA = TM;            // A pieces (8 rows = 1 KiB) per wave per K-step: its group's half of the rows / 4 waves
-    constexpr int QB = TN * 4;        // B pieces per GROUP-0 wave per K-step
-    static_assert(QB % 2 == 0, "B pieces split over the two LOAD phases");
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2, wn = wave & 3, wm = grp;
-    const int swz = xcd_remap(blockIdx.x, p.nwg);
-    const int tile_n = swz % p.ntn, tile_m = swz / p.ntn;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const i32x4 rsrc_a = make_rsrc(p.in, p.in_bytes), rsrc_b = make_rsrc(p.w, p.w_bytes);
-    const unsigned lds0 = (unsigned)(__SIZE_TYPE__)((lds_void*)smem);
-
-    // ---- DMA bookkeeping: wave (grp, wn) moves A pieces grp * 4 TM + wn + 4 q (q < TM) = rows of ITS group's half;
-    //      group-0 waves also move B pieces wn + 4 q (q < QB) ----
-    unsigned a_off[QA], a_msk[QA];
-#pragma unroll
-    for (int q = 0; q < QA; ++q) {
-        const int row = (grp * 4 * TM + wn + 4 * q) * 8 + (lane >> 3);
-        const int csw = (lane & 7) ^ ((row >> 1) & 7);
-        const int m = m0 + row;
-        const bool vm = m < p.M;
-        const int mm = vm ? m : 0;
-        const int n = mm / p.HoWo;
-        const int rem = mm - n * p.HoWo;
-        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-        const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
-        const long pix = ((long)n * p.H + hi0) * p.W + wi0;
-        a_off[q] = (unsigned)(128 + pix * (long)(p.Cin * 4) + csw * 16);
-        unsigned mk = 0;
-        for (int t = 0, th = 0, tw = 0; t < p.taps; ++t) {
-            if (vm && (unsigned)(hi0 + th) < (unsigned)p.H && (unsigned)(wi0 + tw) < (unsigned)p.W) mk |= 1u << t;
-            if (++tw == p.KW) { tw = 0; ++th; }
-        }
-        a_msk[q] = mk;
-    }
-    // B piece q of this wave = tile rows (wn + 4 q) * 8 ..: 32 rows further per q, i.e. half a 64-row block of the tiled planes
-    unsigned b_off0;
-    {
-        const int row = wn * 8 + (lane >> 3);
-        const int csw = (lane & 7) ^ ((row >> 1) & 7);
-        const int co = n0 + row;
-        b_off0 = (unsigned)(((co >> 6) * p.ksteps) * 8192 + (co & 63) * 128 + csw * 16);
-    }
-    const unsigned b_blk = (unsigned)p.ksteps * 8192u;          // bytes between consecutive 64-row blocks
-
-    // K-step being REQUESTED (scalar state, identical in every wave)
-    int tap = 0, kw = 0, tstep = 0;
-    unsigned sdelta = 0, srow = 0, sgrp = 0;
-    const unsigned pixb = (unsigned)(p.Cin * 4), rowb = (unsigned)(p.W * p.Cin * 4);
-#define P32_ADVANCE()                                                                   \
-    do {                                                                                \
-        ++tstep;                                                                        \
-        if (++tap == p.taps) { tap = 0; kw = 0; srow = 0; sgrp += 128u; sdelta = sgrp; } \
-        else if (++kw == p.KW) { kw = 0; srow += rowb; sdelta = srow + sgrp; }          \
-        else sdelta += pixb;                                                            \
-    } while (0)
-    auto issue_a = [&](int st, int q0, int q1) {        // A pieces q0 .. q1 - 1 of this wave for the requested K-step
-        const unsigned sbase = __builtin_amdgcn_readfirstlane(lds0 + st * STAGE + (grp * 4 * TM + wn) * 1024);
-#pragma unroll
-        for (int q = 0; q < QA; ++q) {
-            if (q < q0 || q >= q1) continue;
-            const bool ok = (a_msk[q] >> tap) & 1u;
-            const unsigned vo = ok ? a_off[q] + sdelta : (a_off[q] & 0x70u);
-            dma16(rsrc_a, sbase + q * 4096, vo, 0u);
-        }
-    };
-    auto issue_b = [&](int st, int q0, int q1) {        // B pieces (group 0 only)
-        const unsigned sbase = __builtin_amdgcn_readfirstlane(lds0 + st * STAGE + BM * 128 + wn * 1024);
-        const unsigned bd = (unsigned)tstep * 8192u;
-#pragma unroll
-        for (int q = 0; q < QB; ++q) {
-            if (q < q0 || q >= q1) continue;
-            dma16(rsrc_b, sbase + q * 4096, b_off0 + (q & 1) * 4096u + (q >> 1) * b_blk, bd);
-        }
-    };
-
-    // ---- fragments: single-buffered, twelve 16-byte reads per (K-step, kk) ----
-    const int fsw = (lane >> 1) & 7, hh = lane >> 5;
-    const int a_row = (wm * TM * 32 + (lane & 31)) * 128, b_row = BM * 128 + (wn * TN * 32 + (lane & 31)) * 128;
-    f16x8 ah[TM], al[TM], bh[TN], bl[TN];
-    auto load_frags = [&](int st, int kk) {
-        const char* sb = smem + st * STAGE;
-        const int ch = (((kk * 2 + hh) ^ fsw) * 16), cl = (((4 + kk * 2 + hh) ^ fsw) * 16);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            bh[j] = *reinterpret_cast<const f16x8*>(sb + b_row + ch + j * 4096);
-            bl[j] = *reinterpret_cast<const f16x8*>(sb + b_row + cl + j * 4096);
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            ah[i] = *reinterpret_cast<const f16x8*>(sb + a_row + ch + i * 4096);
-            al[i] = *reinterpret_cast<const f16x8*>(sb + a_row + cl + i * 4096);
-        }
-    };
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    auto mfma_phase = [&]() {
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                f32x16 c = acc[i][j];     // smallest terms first
-                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], c, 0, 0, 0);
-                acc[i][j] = c;
-            }
-        __builtin_amdgcn_s_setprio(0);
-    };
-    // phase boundary: every LDS read of this wave has returned, then the workgroup barrier
-#define P32_PHASE_END()                                                  \
-    do {                                                                 \
-        __builtin_amdgcn_sched_barrier(0);                               \
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
-        __builtin_amdgcn_sched_barrier(0);                               \
-    } while (0)
-
-    // ---- prologue: stage 0 <- K-step 0, by the same piece assignment ----
-    issue_a(0, 0, QA);
-    if (grp == 0) issue_b(0, 0, QB);
-    P32_ADVANCE();
-    const GroupScales gs = load_group_scales(p, m0, !p.out_f32);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    P32_PHASE_END();
-
-    const int T = p.ksteps;
-    if (grp == 0) {
-        for (int t = 0; t < T; ++t) {
-            const int st = t & 1;
-            const bool more = t + 1 < T;
-            load_frags(st, 0);                                   // phase 4t
-            if (more) { issue_a(st ^ 1, 0, QA); issue_b(st ^ 1, 0, QB / 2); }
-            P32_PHASE_END();
-            mfma_phase();                                        // phase 4t + 1
-            P32_PHASE_END();
-            load_frags(st, 1);                                   // phase 4t + 2
-            if (more) { issue_b(st ^ 1, QB / 2, QB); P32_ADVANCE(); }
-            P32_PHASE_END();
-            mfma_phase();                                        // phase 4t + 3
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of stage t + 1 has landed
-            P32_PHASE_END();
-        }
-        P32_PHASE_END();                                         // phase 4T: group 1's last MFMAs
-    } else {
-        for (int t = 0; t < T; ++t) {
-            const int st = t & 1;
-            const bool more = t + 1 < T;
-            if (t > 0) mfma_phase();                             // phase 4t: MFMA(t - 1, 1)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's A rows of stage t (requested a K-step ago)
-            P32_PHASE_END();
-            load_frags(st, 0);                                   // phase 4t + 1
-            if (more) issue_a(st ^ 1, 0, (QA + 1) / 2);
-            P32_PHASE_END();
-            mfma_phase();                                        // phase 4t + 2
-            P32_PHASE_END();
-            load_frags(st, 1);                                   // phase 4t + 3
-            if (more) { issue_a(st ^ 1, (QA + 1) / 2, QA); P32_ADVANCE(); }
-            P32_PHASE_END();
-        }
-        mfma_phase();                                            // phase 4T
-        P32_PHASE_END();
-    }
-#undef P32_ADVANCE
-#undef P32_PHASE_END
-    p32_epilogue<WM, WN, TM, TN, false>(p, gs, smem, [&](int i, float* e) { write_acc32<TN, BN + 4>(acc[i], e, lane); }, wm, wn, m0, n0);
-}
-
-template <int TM, int TN>
-int launch_pp(ConvQ p, hipStream_t st) {
-    constexpr int BM = 2 * TM * 32, BN = 4 * TN * 32;
-    constexpr int stages = 2 * (BM + BN) * 128, image = 2 * 32 * (BN * 4 + 16);
-    constexpr int smem = stages > image ? stages : image;
-    p.ntn = p.CoutPad / BN;
-    p.nwg = p.ntn * cdiv(p.M, BM);
-    auto k = conv_p32_pp_kernel<TM, TN>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(k, dim3(p.nwg), dim3(512), smem, st, p);
-    DEMIA_CHECK_LAUNCH("conv_p32_pp_kernel");
-    return DEMIA_OK;
-}
-
+#if P32_DEV_TILES   // experiments that did not pay (ping-pong schedules), kept for same-box A/B through tile hints: a file of their own
+#include "conv_p32_dev.inc"
 #endif  // P32_DEV_TILES
 
 template <int WM, int WN, int TM, int TN, bool M16 = true, int EPI = EPI_PLANES, int NST = 2, bool HK = false>
