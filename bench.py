@@ -233,6 +233,8 @@ def cli_leg(sd, depth: int, dev, n_images: int, value: float, tmp_root=None) -> 
         loops = [(int(a), float(b)) for a, b in re.findall(r"Inference complete: (\d+)/\d+ images, avg ([0-9.]+)s/image", log)]
         tm = re.search(r"Inference task finished in ([0-9.]+)s", log)
         rows = sum(1 for _ in csv.reader(open(split / "measurements_results.csv"))) - 1 if (split / "measurements_results.csv").exists() else 0
+        if r.returncode != 0 and (ROOT / "gpurun_out").is_dir():
+            (ROOT / "gpurun_out" / f"cli_leg_failed_workers_{workers}.log").write_text(log)
         return {"rc": r.returncode, "processes_on_the_gpu": len(loops), "image_loop_s": max((a * b for a, b in loops), default=None),
                 "task_s": float(tm.group(1)) if tm else None, "wall_s_incl_start_up": wall, "csv_rows": rows,
                 **({} if r.returncode == 0 else {"stderr_tail": log[-800:]})}
@@ -1122,8 +1124,22 @@ def run_rank(args, world, rank, local_rank, my_lane, proc_lanes, children, reply
             line["cpu_baseline"], _ = cpu_baseline(args.depth, args.size, args.threshold, sd, args.cpu_tiles)
         if world == 1 and not args.no_cli_leg and not args.forward_only and not native and args.precision == "f16x2" and not args.single_stages \
                 and (args.depth, args.size) == (101, 2048):
-            # the drop-in CLI on its own workloads, as a subprocess (the lanes' children only hold their arenas meanwhile)
+            # the drop-in CLI on its own workloads, as a subprocess -- with the GPU to itself: the lane children end and this process
+            # hands its arenas, graphs and resident batches back first (the CLI's worker processes bring ~45 GiB each)
             try:
+                if children is not None:
+                    children.close()
+                for ln in lanes:
+                    ln.eng.release_cached_shapes()
+                    ln.pipe.clear_cache()
+                lanes.clear()
+                xs.clear()
+                h2d_state.clear()
+                cur.clear()
+                del x, pipe, eng
+                import gc
+                gc.collect()
+                torch.cuda.empty_cache()
                 line["cli"] = cli_leg(sd, args.depth, dev, args.cli_images, line["value"] or line.get("value_rejected") or 0.0)
             except Exception as e:          # a side leg never takes the headline down with it
                 line["cli"] = {"error": f"{type(e).__name__}: {e}"}

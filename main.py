@@ -69,7 +69,27 @@ def worker_processes(args) -> int:
         n = sum(1 for f in os.listdir(get_image_folder_path()) if is_image_file(f))
     except Exception:
         return 1
-    return 3 if n >= 24 else (2 if n >= 8 else 1)
+    want = 3 if n >= 24 else (2 if n >= 8 else 1)
+    free = free_vram_gib()
+    if free is not None:
+        # every process brings its own arena (~26 GiB of activations for a 48-forward batch) and graphs: ~45 GiB each
+        want = max(1, min(want, int(free // 45)))
+    return want
+
+
+def free_vram_gib():
+    """Free device memory of the first GPU in GiB, read from sysfs (no HIP call: the launcher must not initialise the GPU);
+    None when the files are not there."""
+    try:
+        cards = sorted(Path("/sys/class/drm").glob("card*/device/mem_info_vram_total"))
+        if not cards:
+            return None
+        dev = cards[0].parent
+        total = int((dev / "mem_info_vram_total").read_text())
+        used = int((dev / "mem_info_vram_used").read_text())
+        return (total - used) / 2 ** 30
+    except (OSError, ValueError):
+        return None
 
 
 def launch_workers(workers: int, argv) -> int:
