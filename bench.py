@@ -191,6 +191,9 @@ def cli_leg(sd, depth: int, dev, n_images: int, value: float, tmp_root=None) -> 
 
     from deepemia_amd import synth
     Image.MAX_IMAGE_PIXELS = None
+    # the weights of the CLI parity cases and of scripts/gpu_cli_throughput.py (soft masks: mask_bias 0.5, mask_gain 6; the headline
+    # weights' solid masks make every region program a large-region one and measure the morphology kernels, not the loop)
+    sd = synth.random_d2_state_dict(depth, 2, seed=0, mask_bias=0.5, mask_gain=6.0)
     root = Path(tmp_root or tempfile.mkdtemp(prefix="deepemia_cli_leg_"))
     name = "benchfolder"
 
@@ -245,7 +248,8 @@ def cli_leg(sd, depth: int, dev, n_images: int, value: float, tmp_root=None) -> 
                        [(f"em_{i:03d}.png", tiles[i]) for i in range(n_images)])
     fwd_per_image = 10
     out = {"workload": f"main.py --task inference (subprocess) on {n_images} synthetic 2048^2 images: per image the full-image pass + 9 tiles of "
-                       f"1024 (12.5 % overlap) = {fwd_per_image} forwards, class loops, 0.4 / 0.7 dedups, containment + overlap rules, RLE + measurement CSVs",
+                       f"1024 (12.5 % overlap) = {fwd_per_image} forwards, class loops, 0.4 / 0.7 dedups, containment + overlap rules, RLE + measurement CSVs; "
+                       f"R{depth} with the soft-mask weights of the CLI parity cases (mask_bias 0.5, mask_gain 6)",
            "folder": {}}
     for label, workers in (("default", "auto"), ("one_process", "1")):
         rec = run(base, split, workers)
