@@ -2,7 +2,10 @@
 full-image pass + 9 tiles of 1024 with 12.5 % overlap per image: 10 forwards of the 800-pixel network per image, containment +
 overlap rules, both CSVs): seconds per image of the image loop and tile-forwards/s, for 1 .. W worker processes on the one GPU.
 
-    python scripts/gpu_cli_throughput.py [n_images=32] [workers=1,2,3] [--profile]
+    python scripts/gpu_cli_throughput.py [n_images=32] [workers=1,2,3] [--profile] [--solid] [--rocprof]
+
+--solid: the headline weights (mask predictor bias + 2: solid masks, large regions) instead of the CLI parity cases' soft masks;
+--rocprof: one more run with one process under `rocprofv3 --kernel-trace --stats` (tables under gpurun_out/cli_rocprof/).
 """
 import csv, hashlib, json, os, re, subprocess, sys, tempfile, time
 from pathlib import Path
@@ -24,19 +27,23 @@ def make_tree(n):
                                       "tile_settings": {"tile_size": 1024, "overlap_ratio": 0.125, "upscale_factor": 1.0, "edge_filter_enabled": True},
                                       "spatial_constraints": {"enabled": True, "containment_rules": {1: 0}, "containment_threshold": 0.5,
                                                               "overlap_rules": {0: {"allow_overlap": False, "max_iou_threshold": 0.3}}}}}
-    cfgdir, split, sds, images = T._write_tree(root, [101], 0.5, 6.0, 0, 512, ds_cfg)
+    cfgdir, split, sds, images = T._write_tree(root, [101], *((2.0, 1.0) if "--solid" in sys.argv else (0.5, 6.0)), 0, 512, ds_cfg)
     inf = root / "DATASET" / "INFERENCE"
     for i in range(n):
         Image.fromarray(synth.em_tile(300 + i, 2048)[:, :, ::-1]).save(inf / f"em_{i}.png")
     return root, cfgdir, split
 
 
-def run_cli(root, cfgdir, split, workers, n, profile=False):
+def run_cli(root, cfgdir, split, workers, n, profile=False, rocprof=False):
     env = dict(os.environ, DEEPEMIA_CONFIG_DIR=str(cfgdir), DEEPEMIA_OFFLINE="1", DEEPEMIA_WORKERS=str(workers), DEEPEMIA_LOG_DIR=str(root))
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable] + (["-m", "cProfile", "-o", str(root / "cli.prof")] if profile else []) + \
           [str(ROOT / "main.py"), "--task", "inference", "--dataset_name", T.DATASET, "--threshold", "0.3", "--no-gpu-check"]
+    if rocprof:
+        out = ROOT / "gpurun_out" / "cli_rocprof"
+        cmd = ["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", str(out), "-o", "cli", "--", "python3"] + cmd[1:]
+        env["TMPDIR"] = "/tmp"
     t0 = time.time()
     r = subprocess.run(cmd, cwd=str(root), env=env, capture_output=True, text=True, timeout=1200)
     dt = time.time() - t0
@@ -63,6 +70,8 @@ if __name__ == "__main__":
     for rec in recs:
         print("CLI_THROUGHPUT " + json.dumps(rec), flush=True)
     print("CLI_SAME_OUTPUTS", len({r["outputs_sha256"] for r in recs}) == 1)
+    if "--rocprof" in sys.argv:
+        print("CLI_ROCPROF " + json.dumps(run_cli(root, cfgdir, split, 1, n, rocprof=True)), flush=True)
     if "--profile" in sys.argv:
         import pstats
         run_cli(root, cfgdir, split, 1, n, profile=True)
