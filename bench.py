@@ -236,8 +236,8 @@ def cli_leg(sd, depth: int, dev, n_images: int, value: float, tmp_root=None) -> 
         loops = [(int(a), float(b)) for a, b in re.findall(r"Inference complete: (\d+)/\d+ images, avg ([0-9.]+)s/image", log)]
         tm = re.search(r"Inference task finished in ([0-9.]+)s", log)
         rows = sum(1 for _ in csv.reader(open(split / "measurements_results.csv"))) - 1 if (split / "measurements_results.csv").exists() else 0
-        if r.returncode != 0 and (ROOT / "gpurun_out").is_dir():
-            (ROOT / "gpurun_out" / f"cli_leg_failed_workers_{workers}.log").write_text(log)
+        if (r.returncode != 0 or os.environ.get("DEEPEMIA_KEEP_CLI_LOG")) and (ROOT / "gpurun_out").is_dir():
+            (ROOT / "gpurun_out" / f"cli_leg_{'failed_' if r.returncode else ''}{base.name}_workers_{workers}.log").write_text(log)
         return {"rc": r.returncode, "processes_on_the_gpu": len(loops), "image_loop_s": max((a * b for a, b in loops), default=None),
                 "task_s": float(tm.group(1)) if tm else None, "wall_s_incl_start_up": wall, "csv_rows": rows,
                 **({} if r.returncode == 0 else {"stderr_tail": log[-800:]})}
