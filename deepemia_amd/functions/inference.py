@@ -1817,14 +1817,35 @@ def run_inference(dataset_name, output_dir, visualize=True, threshold=0.65, draw
     decoder = ThreadPoolExecutor(max_workers=max(2, min(8, ncpu // 2)))
     decoded: Dict[str, object] = {}
 
+    upload_stream = torch.cuda.Stream(device=dev)
+
+    def decode_and_upload(path):
+        """(helper thread) decode + host-to-device copy on a stream of its own: the image loop's thread neither decodes nor waits
+        for a 12-MB copy from pageable memory (3 ms per 2048^2 image, 15 ms per group of five)."""
+        img = imread_bgr(path)
+        if img is None:
+            return None
+        torch.cuda.set_device(dev)
+        with torch.cuda.stream(upload_stream):
+            t = torch.from_numpy(img).to(dev)
+            ev = torch.cuda.Event()
+            ev.record(upload_stream)
+        return t, ev
+
     def prefetch(name):
         if name not in decoded:
-            decoded[name] = decoder.submit(imread_bgr, os.path.join(inpath, name))
+            decoded[name] = decoder.submit(decode_and_upload, os.path.join(inpath, name))
 
     def load(name):
         prefetch(name)
-        img = decoded.pop(name).result()
-        return None if img is None else torch.from_numpy(img).to(dev)
+        got = decoded.pop(name).result()
+        if got is None:
+            return None
+        t, ev = got
+        cur_s = torch.cuda.current_stream(dev)
+        cur_s.wait_event(ev)
+        t.record_stream(cur_s)
+        return t
 
     sample = []
     if not shard_images or job_rank == 0:
@@ -1942,10 +1963,14 @@ def run_inference(dataset_name, output_dir, visualize=True, threshold=0.65, draw
         if g != cur_group:
             cur_group = g
             cur_items, plan = ahead
+            tg0 = time.perf_counter()
             finish_group(plan, g)
+            tg1 = time.perf_counter()
             if g + 3 < len(groups):
                 prefetch_group(groups[g + 3])       # decode three groups ahead on the helper threads
             ahead = launch_group(groups[g + 1], models_needed) if g + 1 < len(groups) else None
+            system_logger.info(f"Group {g}: waited {1e3 * (tg1 - tg0):.1f} ms for its forwards, next group loaded and enqueued in "
+                                f"{1e3 * (time.perf_counter() - tg1):.1f} ms")
         image_dev = cur_items.pop(name, None)
         if image_dev is None:
             system_logger.warning(f"Could not load image: {name}")
