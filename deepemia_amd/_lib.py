@@ -103,6 +103,8 @@ EXPORTS = {
     "demia_last_error": (C.c_char_p, []),
     "demia_build_arch": (C.c_char_p, []),
     "demia_build_flavor": (C.c_char_p, []),
+    "demia_stream_create_cu_mask": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "demia_stream_destroy": (C.c_int, [C.c_void_p]),
     "demia_conv2d_nhwc": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "demia_conv2d_p32": (C.c_int, [C.POINTER(ConvP32Desc), C.c_void_p]),
     "demia_conv2d_p32_single": (C.c_int, [C.POINTER(ConvP32Desc), C.c_void_p]),
@@ -207,3 +209,22 @@ def check(status: int, what: str) -> None:
 def ptr(t) -> int:
     """Raw device pointer of a torch tensor (None -> NULL)."""
     return 0 if t is None else int(t.data_ptr())
+
+
+def cu_masked_stream(device, spec: str):
+    """A torch stream on ``device`` restricted by a CU mask (``demia_stream_create_cu_mask``).  ``spec`` = ``"mod:M:K"``: of every M
+    consecutive compute-unit indices the ones >= K are left OUT (``mod:32:28``: 28 of every 32), over 256 CUs.  Returns
+    (torch.cuda.ExternalStream, enabled CU count); the stream lives as long as the process."""
+    import numpy as np
+    import torch
+
+    kind, m, k = spec.split(":")
+    assert kind == "mod"
+    m, k = int(m), int(k)
+    bits = np.zeros(256, dtype=np.uint8)
+    bits[(np.arange(256) % m) < k] = 1
+    words = np.packbits(bits.reshape(8, 32), axis=1, bitorder="little").view(np.uint32).reshape(8).copy()
+    handle = C.c_void_p()
+    with torch.cuda.device(device):
+        check(load().demia_stream_create_cu_mask(words.ctypes.data, 8, C.byref(handle)), "demia_stream_create_cu_mask")
+    return torch.cuda.ExternalStream(handle.value, device=device), int(bits.sum())

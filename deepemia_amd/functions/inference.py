@@ -1884,6 +1884,10 @@ def run_inference(dataset_name, output_dir, visualize=True, threshold=0.65, draw
             if nm not in sample_dev:
                 prefetch(nm)
     net_stream = torch.cuda.Stream(device=dev)
+    if os.environ.get("DEEPEMIA_NET_CU_MASK"):
+        # (experiment switch) the network's stream on a CU mask, e.g. mod:32:28 = 28 of every 32 compute units
+        net_stream, n_cu = _L.cu_masked_stream(dev, os.environ["DEEPEMIA_NET_CU_MASK"])
+        system_logger.info(f"Network stream restricted to {n_cu} of 256 compute units ({os.environ['DEEPEMIA_NET_CU_MASK']})")
 
     def enqueue_forwards(ok, model_ids):
         up = torch.cuda.Event()

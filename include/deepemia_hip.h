@@ -57,6 +57,13 @@ const char* demia_build_arch(void);   /* "gfx950" */
  * kernels of the non-default precisions behind demia_conv2d_nhwc (f32x3, bf16x2, f16x2r, bf16) and the experimental tiles /
  * schedules of the P32 kernel reachable through tile hints.  Same symbols in both. */
 const char* demia_build_flavor(void);
+/* A HIP stream restricted to the compute units whose bit is set in mask (bit i of word i / 32; words = 8 for the 256 CUs of an
+ * MI355X) -- hipExtStreamCreateWithCUMask behind the C ABI, so that the host side (which holds streams as torch objects) can give
+ * the network's stream a mask that leaves a few CUs per XCD to the latency-bound post-processing kernels of the images in flight.
+ * The caller owns the stream: demia_stream_destroy.  Replaces nothing in the reference (its loop is sequential,
+ * inference.py:713-942). */
+int demia_stream_create_cu_mask(const uint32_t* mask, int words, void** stream);
+int demia_stream_destroy(void* stream);
 /* Single-plane arithmetic is chosen PER LAUNCH (`single` of demia_conv_p32_desc / demia_roialign_desc, the `single` argument of
  * the stem / pool entry points), never process-wide: engines of different precisions may share the library.
  * (demia_conv2d_p32_single is the conv entry point demia_conv2d_p32 forwards to when d->single != 0: the same source compiled

@@ -66,7 +66,18 @@ if __name__ == "__main__":
     n = int(args[0]) if args else 32
     ws = [int(w) for w in (args[1].split(",") if len(args) > 1 else ["1", "2", "3"])]
     root, cfgdir, split = make_tree(n)
-    recs = [run_cli(root, cfgdir, split, w, n) for w in ws]
+    masks = [a.split("=", 1)[1].split(",") for a in sys.argv if a.startswith("--masks=")]
+    recs = []
+    for mask in (masks[0] if masks else [""]):           # --masks=,mod:32:28,mod:8:7 : DEEPEMIA_NET_CU_MASK values ("" = none)
+        if mask:
+            os.environ["DEEPEMIA_NET_CU_MASK"] = mask
+        else:
+            os.environ.pop("DEEPEMIA_NET_CU_MASK", None)
+        for w in ws:
+            rec = run_cli(root, cfgdir, split, w, n)
+            rec["net_cu_mask"] = mask
+            recs.append(rec)
+    os.environ.pop("DEEPEMIA_NET_CU_MASK", None)
     for rec in recs:
         print("CLI_THROUGHPUT " + json.dumps(rec), flush=True)
     print("CLI_SAME_OUTPUTS", len({r["outputs_sha256"] for r in recs}) == 1)
