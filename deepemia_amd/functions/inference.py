@@ -1818,6 +1818,7 @@ def run_inference(dataset_name, output_dir, visualize=True, threshold=0.65, draw
     decoded: Dict[str, object] = {}
 
     upload_stream = torch.cuda.Stream(device=dev)
+    upload_in_decoder = os.environ.get("DEEPEMIA_UPLOAD_IN_DECODER", "1") == "1"       # (A/B switch)
 
     def decode_and_upload(path):
         """(helper thread) decode + host-to-device copy on a stream of its own: the image loop's thread neither decodes nor waits
@@ -1825,6 +1826,8 @@ def run_inference(dataset_name, output_dir, visualize=True, threshold=0.65, draw
         img = imread_bgr(path)
         if img is None:
             return None
+        if not upload_in_decoder:
+            return img, None
         torch.cuda.set_device(dev)
         with torch.cuda.stream(upload_stream):
             t = torch.from_numpy(img).to(dev)
@@ -1842,6 +1845,8 @@ def run_inference(dataset_name, output_dir, visualize=True, threshold=0.65, draw
         if got is None:
             return None
         t, ev = got
+        if ev is None:
+            return torch.from_numpy(t).to(dev)
         cur_s = torch.cuda.current_stream(dev)
         cur_s.wait_event(ev)
         t.record_stream(cur_s)

@@ -69,7 +69,10 @@ if __name__ == "__main__":
     masks = [a.split("=", 1)[1].split(",") for a in sys.argv if a.startswith("--masks=")]
     recs = []
     for mask in (masks[0] if masks else [""]):           # --masks=,mod:32:28,mod:8:7 : DEEPEMIA_NET_CU_MASK values ("" = none)
-        if mask:
+        if mask.startswith("env:"):                     # env:NAME=VALUE -- any A/B switch of the CLI
+            k_, v_ = mask[4:].split("=", 1)
+            os.environ[k_] = v_
+        elif mask:
             os.environ["DEEPEMIA_NET_CU_MASK"] = mask
         else:
             os.environ.pop("DEEPEMIA_NET_CU_MASK", None)
