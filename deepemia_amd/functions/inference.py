@@ -1817,40 +1817,17 @@ def run_inference(dataset_name, output_dir, visualize=True, threshold=0.65, draw
     decoder = ThreadPoolExecutor(max_workers=max(2, min(8, ncpu // 2)))
     decoded: Dict[str, object] = {}
 
-    upload_stream = torch.cuda.Stream(device=dev)
-    upload_in_decoder = os.environ.get("DEEPEMIA_UPLOAD_IN_DECODER", "1") == "1"       # (A/B switch)
-
-    def decode_and_upload(path):
-        """(helper thread) decode + host-to-device copy on a stream of its own: the image loop's thread neither decodes nor waits
-        for a 12-MB copy from pageable memory (3 ms per 2048^2 image, 15 ms per group of five)."""
-        img = imread_bgr(path)
-        if img is None:
-            return None
-        if not upload_in_decoder:
-            return img, None
-        torch.cuda.set_device(dev)
-        with torch.cuda.stream(upload_stream):
-            t = torch.from_numpy(img).to(dev)
-            ev = torch.cuda.Event()
-            ev.record(upload_stream)
-        return t, ev
-
     def prefetch(name):
         if name not in decoded:
-            decoded[name] = decoder.submit(decode_and_upload, os.path.join(inpath, name))
+            decoded[name] = decoder.submit(imread_bgr, os.path.join(inpath, name))
 
     def load(name):
+        # (the upload stays on this thread: copying from the helper threads on a stream of their own -- round 5 -- made the loop
+        # 13 ms per image SLOWER, 43.5 against 30.5 ms, same box, and one of eight runs died; the 3 ms per image it would save
+        # are not worth a second thread talking to the runtime)
         prefetch(name)
-        got = decoded.pop(name).result()
-        if got is None:
-            return None
-        t, ev = got
-        if ev is None:
-            return torch.from_numpy(t).to(dev)
-        cur_s = torch.cuda.current_stream(dev)
-        cur_s.wait_event(ev)
-        t.record_stream(cur_s)
-        return t
+        img = decoded.pop(name).result()
+        return None if img is None else torch.from_numpy(img).to(dev)
 
     sample = []
     if not shard_images or job_rank == 0:
