@@ -1955,7 +1955,7 @@ def run_inference(dataset_name, output_dir, visualize=True, threshold=0.65, draw
             if g + 3 < len(groups):
                 prefetch_group(groups[g + 3])       # decode three groups ahead on the helper threads
             ahead = launch_group(groups[g + 1], models_needed) if g + 1 < len(groups) else None
-            system_logger.info(f"Group {g}: waited {1e3 * (tg1 - tg0):.1f} ms for its forwards, next group loaded and enqueued in "
+            system_logger.debug(f"Group {g}: waited {1e3 * (tg1 - tg0):.1f} ms for its forwards, next group loaded and enqueued in "
                                 f"{1e3 * (time.perf_counter() - tg1):.1f} ms")
         image_dev = cur_items.pop(name, None)
         if image_dev is None:
