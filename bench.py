@@ -814,6 +814,8 @@ def run_rank(args, world, rank, local_rank, my_lane, proc_lanes, children, reply
 
     if my_lane:
         # ---- a lane child: warm up, report, then serve the rank's RUN commands until EXIT / end of input ----
+        if os.environ.get("DEEPEMIA_BENCH_FAIL_LANE_CHILD"):       # (test hook: the rank must carry on with one lane)
+            sys.exit(7)
         try:
             for i in range(max(1, args.warmup)):
                 step(-1 - i, None, lanes[0])
@@ -845,8 +847,19 @@ def run_rank(args, world, rank, local_rank, my_lane, proc_lanes, children, reply
         for i in range(args.warmup):
             step(-1 - i, None, ln)
             torch.cuda.synchronize()
+    lane_note = None
     if children is not None:
-        children.recv("READY")                # the lane children have built their engines and warmed up meanwhile
+        try:
+            children.recv("READY")            # the lane children have built their engines and warmed up meanwhile
+        except RuntimeError as e:
+            if world > 1:
+                raise                         # (the lane groups of the other ranks would wait for this rank's child)
+            # a lane child that cannot start (or dies while it warms up) must not take the measurement with it: the run goes on
+            # with lane 0 alone and the line says so (`config.lanes` = 1, `config.lane_fallback`)
+            print(f"bench.py: {e}; continuing with one lane", file=sys.stderr)
+            children.close(kill=True)
+            children, lane_note = None, str(e)
+            args.lanes = 1
     if args.lanes > 1:
         tw0 = time.perf_counter()
         step(-1, None, lanes[0])
@@ -1015,6 +1028,7 @@ def run_rank(args, world, rank, local_rank, my_lane, proc_lanes, children, reply
                        "csv_rows_last_step_rank0": rows_total, "stage": "predictor only" if args.forward_only else "whole per-tile path",
                        "overlap": (not args.forward_only) and (not args.no_overlap), "hipgraph_forward": bool(args.graph),
                        "lanes": args.lanes, "lane_mode": (args.lane_mode if args.lanes > 1 else None),
+                       **({"lane_fallback": lane_note} if lane_note else {}),
                        "post_d2h_waits_per_step": None if args.forward_only else d2h_waits_per_step,
                        "post_wall_ms_per_step": None if args.forward_only else post_wall_ms,
                        "post_after_forward_ms_per_step": None if args.forward_only else post_after_fwd_ms},

@@ -150,6 +150,17 @@ def test_bench_default_line_carries_its_contract(gpu_device):
     assert 0.3 < rf["conv_share_of_one_lane_step"] < 1.0 and rf["conv_alone_over_step_period"] > 0
 
 
+def test_bench_carries_on_with_one_lane_when_the_lane_child_dies(gpu_device):
+    """A lane child that cannot start (here: made to exit before its warm-up) must not take the measurement with it: the rank
+    continues with lane 0 alone and the line says so."""
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "4", "--warmup", "1", "--batch", "4", "--no-cpu-baseline", "--no-h2d-leg", "--no-cli-leg"],
+                       cwd=str(ROOT), env=dict(os.environ, DEEPEMIA_BENCH_FAIL_LANE_CHILD="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["config"]["lanes"] == 1 and "lane child 1 ended" in line["config"]["lane_fallback"] and line["value"] > 0
+    assert "one_lane" not in line and "continuing with one lane" in r.stderr
+
+
 def test_config4_job_of_256_distinct_tiles_at_size(gpu_device):
     """BASELINE configs[4] at its stated size on one GPU: a job of 256 DISTINCT 2048^2 tiles (16 steps of 16; step 0 holds
     the numpy tiles, the rest are generated on the device), the whole per-tile path on every tile, the parity leg on tile 0
