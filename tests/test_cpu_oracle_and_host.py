@@ -705,3 +705,49 @@ def test_native_rle_text_equals_the_reference_pinned_encoding():
     raw = out.raw[:got].decode("ascii")
     for i in range(M):
         assert raw[toff[i]:toff[i + 1]] == " ".join(map(str, rle_encoding(masks[i].astype(np.uint8)))), i
+
+
+def test_cli_worker_count_rule(tmp_path, monkeypatch):
+    """``main.py::worker_processes``: how many processes share one GPU for a run -- an explicit ``DEEPEMIA_WORKERS`` wins (1..6), ``auto``
+    looks at the input folder (>= 24 images: 3, >= 8: 2, else 1), never starts workers when a GCS download is pending, and is
+    bounded by the free device memory it can read from sysfs (~45 GiB per process).  Pure host logic: no GPU call."""
+    import types
+
+    import yaml
+
+    import main as cli
+    from deepemia_amd.utils import config as C
+
+    cfgdir = tmp_path / "cfg"
+    cfgdir.mkdir()
+    (cfgdir / "config.yaml").write_text(yaml.safe_dump({"bucket": None, "paths": {"split_dir": str(tmp_path / "s"), "category_json": str(tmp_path / "d.json"),
+                                                                                   "local_dataset_root": str(tmp_path)}}))
+    inf = tmp_path / "DATASET" / "INFERENCE"
+    inf.mkdir(parents=True)
+    monkeypatch.setenv("DEEPEMIA_CONFIG_DIR", str(cfgdir))
+    monkeypatch.setenv("DEEPEMIA_OFFLINE", "1")
+    C.reset_cache()
+    args = types.SimpleNamespace(task="inference", dataset_name="x", download=True)
+    monkeypatch.setattr(cli, "free_vram_gib", lambda: None)
+
+    def with_images(n):
+        for f in inf.glob("*.png"):
+            f.unlink()
+        for i in range(n):
+            (inf / f"im_{i}.png").write_bytes(b"x")
+        return cli.worker_processes(args)
+
+    monkeypatch.delenv("DEEPEMIA_WORKERS", raising=False)
+    assert with_images(3) == 1 and with_images(8) == 2 and with_images(23) == 2 and with_images(24) == 3
+    monkeypatch.setattr(cli, "free_vram_gib", lambda: 100.0)          # room for two processes only
+    assert with_images(30) == 2
+    monkeypatch.setattr(cli, "free_vram_gib", lambda: 10.0)
+    assert with_images(30) == 1
+    monkeypatch.setattr(cli, "free_vram_gib", lambda: None)
+    monkeypatch.setenv("DEEPEMIA_WORKERS", "5")
+    assert with_images(1) == 5
+    monkeypatch.setenv("DEEPEMIA_WORKERS", "99")
+    assert cli.worker_processes(args) == 6
+    monkeypatch.setenv("DEEPEMIA_WORKERS", "auto")
+    assert cli.worker_processes(types.SimpleNamespace(task="train", dataset_name="x", download=True)) == 1
+    C.reset_cache()
