@@ -271,7 +271,9 @@ class InferencePipeline:
         self.inf = inf_settings
         self.gcfg = global_config
         self.dev = self.predictors[0].engine.device
-        self.ops = MaskOps(str(self.dev))
+        import threading
+        self._tls = threading.local()        # every host thread that walks images gets a MaskOps of its own (frame width, pools, upload stream)
+        self._cache_lock = threading.RLock()
         l4 = global_config.get("l4_performance_optimizations", {})
         self.parallel_mask_processing = l4.get("enable_parallel_mask_processing", True)
         gens = global_config.get("inference_settings", {}).get("ensemble_settings", {})
@@ -313,6 +315,13 @@ class InferencePipeline:
         self.rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
         self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         self.exchange = parallel.ExchangeState()     # this job's agreed capacities: every rank builds its pipeline at the same point
+
+    @property
+    def ops(self) -> MaskOps:
+        o = getattr(self._tls, "ops", None)
+        if o is None:
+            o = self._tls.ops = MaskOps(str(self.dev))
+        return o
 
     # ------------------------------------------------------------------ predictor plumbing
     def forward_async(self, model_idx: int, images: torch.Tensor):
@@ -418,11 +427,12 @@ class InferencePipeline:
     def _predict_batches(self, model_ids: Sequence[int], key: str, images: torch.Tensor) -> List[List[_Detections]]:
         """:meth:`_predict_batch` for several models at once: the forwards that are not cached yet are all enqueued first and
         their tables come over in ONE wait."""
-        todo = [m for m in model_ids if (m, key) not in self._cache]
-        if todo:
-            for m, d in zip(todo, self.finish_forwards([self.forward_async(m, images) for m in todo])):
-                self._cache[(m, key)] = d
-        return [self._cache[(m, key)] for m in model_ids]
+        with self._cache_lock:
+            todo = [m for m in model_ids if (m, key) not in self._cache]
+            if todo:
+                for m, d in zip(todo, self.finish_forwards([self.forward_async(m, images) for m in todo])):
+                    self._cache[(m, key)] = d
+            return [self._cache[(m, key)] for m in model_ids]
 
     def _release_forward_outputs(self, dets: Sequence[_Detections]) -> None:
         """Every read of the forwards' own output planes behind ``dets`` is enqueued on the current stream: the replays that
@@ -443,9 +453,10 @@ class InferencePipeline:
     def _predict_batch(self, model_idx: int, key: str, images: torch.Tensor) -> List[_Detections]:
         """Forward a batch of equally sized images once per (model, key); every class reuses it."""
         ck = (model_idx, key)
-        if ck not in self._cache:
-            self._cache[ck] = self.finish_forward(self.forward_async(model_idx, images))
-        return self._cache[ck]
+        with self._cache_lock:              # (a miss runs the engine: one thread at a time)
+            if ck not in self._cache:
+                self._cache[ck] = self.finish_forward(self.forward_async(model_idx, images))
+            return self._cache[ck]
 
     def clear_cache(self) -> None:
         self._cache.clear()
@@ -695,8 +706,9 @@ class InferencePipeline:
     def drop_cached(self, image_key: str) -> None:
         """Forget the cached forwards of ONE image (the CLI loop calls it when the image is done; forwards of the images
         ahead stay)."""
-        for ck in [ck for ck in self._cache if ck[1] == image_key or ck[1].startswith(image_key + "|")]:
-            del self._cache[ck]
+        with self._cache_lock:
+            for ck in [ck for ck in self._cache if ck[1] == image_key or ck[1].startswith(image_key + "|")]:
+                del self._cache[ck]
 
     # ------------------------------------------------------------------ a13 + the tile pipeline
     def _tile_pipeline_local(self, model_ids: Sequence[int], image_key: str, image_dev: torch.Tensor, target_class,
@@ -1943,23 +1955,9 @@ def run_inference(dataset_name, output_dir, visualize=True, threshold=0.65, draw
             if nm not in sample_dev:
                 prefetch(nm)
 
-    flat = [(g, nm) for g, gn in enumerate(groups) for nm in gn]
-    cur_group, cur_items = -1, {}
-    for gi, (g, name) in enumerate(flat):
-        t0 = time.perf_counter()
-        log_memory_usage(f"Before image {gi + 1}/{len(my_images)}: {name}")
-        if g != cur_group:
-            cur_group = g
-            cur_items, plan = ahead
-            tg0 = time.perf_counter()
-            finish_group(plan, g)
-            tg1 = time.perf_counter()
-            if g + 3 < len(groups):
-                prefetch_group(groups[g + 3])       # decode three groups ahead on the helper threads
-            ahead = launch_group(groups[g + 1], models_needed) if g + 1 < len(groups) else None
-            system_logger.debug(f"Group {g}: waited {1e3 * (tg1 - tg0):.1f} ms for its forwards, next group loaded and enqueued in "
-                                f"{1e3 * (time.perf_counter() - tg1):.1f} ms")
-        image_dev = cur_items.pop(name, None)
+    def process_image(gi, name, image_dev, t0):
+        """One image through the class loop, the merges, the cross-class pass, the constraints, RLE and its measurement rows
+        (reference inference.py:735-931 + 1030-1291 for this image); a failure is logged and the image skipped."""
         if image_dev is None:
             system_logger.warning(f"Could not load image: {name}")
             if pipe.world > 1:
@@ -1968,7 +1966,7 @@ def run_inference(dataset_name, output_dir, visualize=True, threshold=0.65, draw
                     pipe.gather_and_merge({}, (0, 0), {}, status=1)
                 except PeerImageFailure as e:
                     system_logger.error(f"Error processing image {name}: {e}")
-            continue
+            return
         try:
             image_host = None
             parts, all_scores, all_classes = [], [], []
@@ -2051,6 +2049,45 @@ def run_inference(dataset_name, output_dir, visualize=True, threshold=0.65, draw
         finally:
             pipe.drop_cached(name)
             log_memory_usage(f"After image {gi + 1}/{len(my_images)}: {name}")
+    # DEEPEMIA_IMAGE_THREADS=k (experiment switch, default 1): the images of a group are post-processed by k host threads at once
+    # (every thread its own MaskOps; forwards stay on this thread) -- their device-to-host waits then overlap instead of queueing
+    # one after the other behind the next group's convolution grids
+    image_threads = max(1, int(os.environ.get("DEEPEMIA_IMAGE_THREADS", "1"))) if pipe.world == 1 else 1
+    image_pool = ThreadPoolExecutor(max_workers=image_threads) if image_threads > 1 else None
+
+    def process_image_on_thread(gi, name, image_dev, t0):
+        torch.cuda.set_device(dev)
+        process_image(gi, name, image_dev, t0)
+
+    flat = [(g, nm) for g, gn in enumerate(groups) for nm in gn]
+    cur_group, cur_items = -1, {}
+    pending = []
+    for gi, (g, name) in enumerate(flat):
+        t0 = time.perf_counter()
+        log_memory_usage(f"Before image {gi + 1}/{len(my_images)}: {name}")
+        if g != cur_group:
+            for f_ in pending:                      # (image threads: a group's images are done before the next group's forwards are waited for)
+                f_.result()
+            pending = []
+            cur_group = g
+            cur_items, plan = ahead
+            tg0 = time.perf_counter()
+            finish_group(plan, g)
+            tg1 = time.perf_counter()
+            if g + 3 < len(groups):
+                prefetch_group(groups[g + 3])       # decode three groups ahead on the helper threads
+            ahead = launch_group(groups[g + 1], models_needed) if g + 1 < len(groups) else None
+            system_logger.debug(f"Group {g}: waited {1e3 * (tg1 - tg0):.1f} ms for its forwards, next group loaded and enqueued in "
+                                f"{1e3 * (time.perf_counter() - tg1):.1f} ms")
+        image_dev = cur_items.pop(name, None)
+        if image_pool is not None:
+            pending.append(image_pool.submit(process_image_on_thread, gi, name, image_dev, t0))
+        else:
+            process_image(gi, name, image_dev, t0)
+    for f_ in pending:
+        f_.result()
+    if image_pool is not None:
+        image_pool.shutdown(wait=True)
     pipe.clear_cache()
     decoder.shutdown(wait=False)
     total = time.perf_counter() - t_all
