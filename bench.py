@@ -230,7 +230,7 @@ def cli_leg(sd, depth: int, dev, n_images: int, value: float, tmp_root=None) -> 
             env.pop(k, None)
         t0 = time.perf_counter()
         r = subprocess.run([sys.executable, str(ROOT / "main.py"), "--task", "inference", "--dataset_name", name, "--threshold", "0.3", "--no-gpu-check"],
-                           cwd=str(base), env=env, capture_output=True, text=True, timeout=900)
+                           cwd=str(base), env=env, capture_output=True, text=True, timeout=300)
         wall = time.perf_counter() - t0
         log = r.stderr + r.stdout
         loops = [(int(a), float(b)) for a, b in re.findall(r"Inference complete: (\d+)/\d+ images, avg ([0-9.]+)s/image", log)]
