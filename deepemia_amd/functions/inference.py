@@ -2096,8 +2096,8 @@ def run_inference(dataset_name, output_dir, visualize=True, threshold=0.65, draw
     if shard_images:
         # the ONE exchange of the image-sharded job: every rank's rows and texts go to rank 0, which writes the files
         mine = (rle_by_image, rows_by_image, {k: {kk: vv for kk, vv in v.items() if kk != "masks"} for k, v in dedup_results.items()}, sorted(processed))
-        gathered = [None] * job_world if job_rank == 0 else None
-        dist.gather_object(mine, gathered, dst=0)
+        gathered = [None] * job_world
+        dist.all_gather_object(gathered, mine)         # (an all-gather: the object collective every backend, RCCL included, supports)
         if job_rank == 0:
             for r_rle, r_rows, r_res, r_done in gathered[1:]:
                 rle_by_image.update(r_rle)
