@@ -174,6 +174,9 @@ def _compare(split, images, ref_rows, ref_masks, contrast=False):
                                   "single_r50_tile200_upscale1p5_f32x3",
                                   "single_r50_blobby_upscale2_f16x2", "ensemble_r50_r101_upscale1_f16x2",
                                   "single_r50_tile200_upscale1p5_f16x2",
+                                  # round 5: ONE model, nine overlapping tiles that are NOT upscaled -- the branch of the tile pipeline that
+                                  # takes the edge filter's boxes from the class pass's tables instead of a resize + reduction
+                                  "single_r50_tile256_upscale1_f16x2",
                                   # BASELINE configs[3] as ONE run: R50 + R101 ensemble, multi-scale full-image pass, soft-NMS
                                   # merge of full-image + tile results, containment rule (flagged non-parity modes, f4:
                                   # checked against the composed oracle, not against the reference's live path)
@@ -199,6 +202,9 @@ def test_cli_inference_matches_oracle_pipeline(case, tmp_path, monkeypatch, gpu_
     elif case.startswith("single_r50_blobby_upscale2"):
         depths, bias, gain, size = [50], 0.5, 6.0, 512
         tile = {"tile_size": 256, "overlap_ratio": 0.125, "upscale_factor": 2.0, "edge_filter_enabled": True}
+    elif case.startswith("single_r50_tile256_upscale1"):
+        depths, bias, gain, size = [50], 0.5, 6.0, 512
+        tile = {"tile_size": 256, "overlap_ratio": 0.125, "upscale_factor": 1.0, "edge_filter_enabled": True}
     else:
         depths, bias, gain, size = [50, 101], 0.5, 6.0, 512   # blobby masks: a solid box mask flips a whole edge row on a 1e-4 px box shift
         tile = {"tile_size": 512, "overlap_ratio": 0.0, "upscale_factor": 1.0, "edge_filter_enabled": True}
