@@ -469,6 +469,34 @@ def test_one_ranks_failure_on_an_image_makes_every_rank_skip_that_image_together
     assert log.count("every rank skips this image") >= 3 and "building the instance table of an image failed" in log
 
 
+def test_grouped_padded_and_graphed_forwards_write_the_image_by_image_files(tmp_path, monkeypatch, gpu_device):
+    """The image loop batches the forwards of a GROUP of images across the images, pads a short last group to the captured batch
+    shape and, for a long folder, replays hipGraphs from the first group on.  None of it may change a byte: seven images in groups
+    of three (3 + 3 + 1 padded, graphs from group 0) against the same folder image by image (groups of one: no cross-image batch, no
+    padding), and with two host threads per group (``DEEPEMIA_IMAGE_THREADS``)."""
+    tile = {"tile_size": 256, "overlap_ratio": 0.125, "upscale_factor": 1.0, "edge_filter_enabled": True}
+    ds_cfg = {"inference_overrides": {"confidence_mode": "manual",
+                                      "class_specific_settings": {"class_0": {"confidence_threshold": 0.3, "iou_threshold": 0.6},
+                                                                  "class_1": {"confidence_threshold": 0.35, "iou_threshold": 0.5}},
+                                      "tile_settings": tile, "spatial_constraints": {"enabled": True, "containment_rules": {1: 0}, "containment_threshold": 0.5}}}
+    cfgdir, split, sds, images = _write_tree(tmp_path, [50], 0.5, 6.0, 7, 512, ds_cfg)
+    monkeypatch.setenv("DEEPEMIA_WORKERS", "1")
+    outs = {}
+    for label, env in (("one_by_one", {"DEEPEMIA_IMAGE_GROUP": "1"}), ("groups_of_three", {"DEEPEMIA_IMAGE_GROUP": "3"}),
+                       ("groups_of_three_two_threads", {"DEEPEMIA_IMAGE_GROUP": "3", "DEEPEMIA_IMAGE_THREADS": "2"})):
+        for k in ("DEEPEMIA_IMAGE_GROUP", "DEEPEMIA_IMAGE_THREADS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        _run_cli_plain(monkeypatch, cfgdir, tmp_path)
+        outs[label] = (open(split / "measurements_results.csv").read(), open(split / "R50_flip_results.csv").read())
+        for f in (split / "measurements_results.csv", split / "R50_flip_results.csv"):
+            f.unlink()
+    assert len(outs["one_by_one"][0].splitlines()) > 50
+    assert outs["groups_of_three"] == outs["one_by_one"]
+    assert outs["groups_of_three_two_threads"] == outs["one_by_one"]
+
+
 def test_images_sharded_over_two_ranks_write_the_single_process_files(tmp_path, monkeypatch, gpu_device):
     """SURVEY 8(e) "batch": a FOLDER of images is sharded by image (image j -> rank j % world), no exchange per image; every rank
     runs the whole per-image path (full-image pass + all tiles, dedups, constraints, RLE, measurements) for the images it owns and
