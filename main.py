@@ -54,8 +54,9 @@ def worker_processes(args) -> int:
     loop's post-processing is host-bound (class loops, dedups, writers: ~35 ms of interpreted host work per 2048^2 image against
     ~15 ms of network), so a folder of images goes faster with the images dealt out to two processes -- each with its own
     interpreter, engine and hipGraphs, exactly as with one process per GPU on a multi-GPU node (`run_inference` shards by image).
-    ``auto``: when the run is local (no GCS download pending), 3 for a folder of at least 24 images, 2 from 8 images, else 1
-    (64 images of 2048^2, round 5: 29.2 / 21.5 / 19.0 ms per image with 1 / 2 / 3 processes, byte-identical CSVs)."""
+    ``auto``: when the run is local (no GCS download pending), 4 for a folder of at least 48 images, 3 from 24, 2 from 8, else 1
+    (2048^2 images, round 5: 28.1 / 20.9 / 18.5 ms per image with 1 / 2 / 3 processes on 64 images, 19.0 / 16.7 / 24.3 ms with
+    3 / 4 / 5 on 96 -- five is too many; byte-identical CSVs throughout)."""
     want = os.environ.get("DEEPEMIA_WORKERS", "auto").strip().lower()
     if want != "auto":
         try:
@@ -69,7 +70,7 @@ def worker_processes(args) -> int:
         n = sum(1 for f in os.listdir(get_image_folder_path()) if is_image_file(f))
     except Exception:
         return 1
-    want = 3 if n >= 24 else (2 if n >= 8 else 1)
+    want = 4 if n >= 48 else (3 if n >= 24 else (2 if n >= 8 else 1))
     free = free_vram_gib()
     if free is not None:
         # every process brings its own arena (~26 GiB of activations for a 48-forward batch) and graphs: ~45 GiB each

@@ -709,7 +709,7 @@ def test_native_rle_text_equals_the_reference_pinned_encoding():
 
 def test_cli_worker_count_rule(tmp_path, monkeypatch):
     """``main.py::worker_processes``: how many processes share one GPU for a run -- an explicit ``DEEPEMIA_WORKERS`` wins (1..6), ``auto``
-    looks at the input folder (>= 24 images: 3, >= 8: 2, else 1), never starts workers when a GCS download is pending, and is
+    looks at the input folder (>= 48 images: 4, >= 24: 3, >= 8: 2, else 1), never starts workers when a GCS download is pending, and is
     bounded by the free device memory it can read from sysfs (~45 GiB per process).  Pure host logic: no GPU call."""
     import types
 
@@ -738,7 +738,7 @@ def test_cli_worker_count_rule(tmp_path, monkeypatch):
         return cli.worker_processes(args)
 
     monkeypatch.delenv("DEEPEMIA_WORKERS", raising=False)
-    assert with_images(3) == 1 and with_images(8) == 2 and with_images(23) == 2 and with_images(24) == 3
+    assert with_images(3) == 1 and with_images(8) == 2 and with_images(23) == 2 and with_images(24) == 3 and with_images(47) == 3 and with_images(48) == 4
     monkeypatch.setattr(cli, "free_vram_gib", lambda: 100.0)          # room for two processes only
     assert with_images(30) == 2
     monkeypatch.setattr(cli, "free_vram_gib", lambda: 10.0)
