@@ -482,6 +482,18 @@ def main() -> None:
     args.graph = not args.eager and args.precision in ("f16x2", "f16")
     args.lanes = resolve_lanes(args.lanes, world, overlap=not args.no_overlap, graph=bool(args.graph))
     my_lane = int(args.lane_child)                     # 0: the rank process itself
+    import signal
+    if my_lane:
+        # a lane child must not outlive its rank (a rank that torch.distributed.run terminates cannot say goodbye, and a child that
+        # sits in a collective of its lane group would hold the GPU until the collective's timeout): the kernel ends it with the rank
+        try:
+            import ctypes
+            ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, int(signal.SIGKILL))        # PR_SET_PDEATHSIG
+        except OSError:
+            pass
+    else:
+        # SIGTERM (torch.distributed.run tearing the job down) becomes an exception, so that the `except` below ends the lane children
+        signal.signal(signal.SIGTERM, lambda *_: sys.exit(143))
     proc_lanes = args.lane_mode == "processes" and args.lanes > 1
     children = None
     reply = os.fdopen(args.lane_fd, "w") if my_lane else None
