@@ -880,7 +880,7 @@ def run_rank(args, world, rank, local_rank, my_lane, proc_lanes, children, reply
     sync_all()
     # the start offset between lanes: with L forwards in flight a lane's forward takes about L single forwards, so the lanes sit
     # one single forward apart (a pass alone is the forward + ~1/4 of it for the post-processing)
-    xchg["stagger_s"] = 0.8 * t_warm if (t_warm and args.lanes > 1) else 0.0
+    xchg["stagger_s"] = float(os.environ.get("DEEPEMIA_BENCH_STAGGER", "0.8")) * t_warm if (t_warm and args.lanes > 1) else 0.0      # (the factor: an A/B switch)
     eng.conv_events = None if (args.no_conv_events or args.graph) else []
     t0 = time.perf_counter()
     (det_total, rows_total), st_main = run_steps(args.steps)      # K complete passes
