@@ -529,27 +529,56 @@ class InferencePipeline:
         70-ms image.  ``with_tables``: also return (area, bbox) of the kept masks (host arrays)."""
         if packed is None or packed.shape[0] == 0:
             return (None, [], [], None) if with_tables else (None, [], [])
+        out = self.deduplicate_masks_smart_segments(packed, scores, classes, [(0, int(packed.shape[0]))], iou_threshold)[0]
+        return out if with_tables else out[:3]
+
+    def deduplicate_masks_smart_segments(self, packed: torch.Tensor, scores: Sequence[float], classes: Sequence[int],
+                                         segments: Sequence[Tuple[int, int]], iou_threshold: float):
+        """:meth:`deduplicate_masks_smart` for SEVERAL independent calls at once -- ``segments`` = [start, end) of each call's masks in
+        ``packed`` (the two per-class 0.4 merges of an image) -- with ONE device-to-host wait for all of them: one reduction, one contour
+        trace and one pair matrix over the (segment, class) runs, one native call with a "tile" per segment (every segment is
+        filtered with its own local indices, N6 included: exactly what separate calls do).  Returns per segment
+        (masks, scores, classes, (area, bbox)) -- (None, [], [], None) for an empty result."""
+        empty = (None, [], [], None)
         n = int(packed.shape[0])
+        if n == 0:
+            return [empty for _ in segments]
         cl = np.asarray([int(c) for c in classes], dtype=np.int32)
-        change = np.nonzero(np.diff(cl))[0] + 1
-        starts = np.concatenate(([0], change)).astype(np.int32)
-        ends = np.concatenate((change, [n])).astype(np.int32)
-        if len(set(cl[starts].tolist())) != len(starts):        # a class in two separate runs: the general host-loop version
-            m, s_, c_ = self.deduplicate_masks_smart_hostloops(packed, scores, classes, iou_threshold)
-            if not with_tables:
-                return m, s_, c_
-            if m is None:
-                return m, s_, c_, None
-            a_, b_ = self.ops.area_bbox(m)
-            return m, s_, c_, (a_.cpu().numpy().astype(np.int64), b_.cpu().numpy().astype(np.int64))
+        run_first = np.zeros(n, dtype=np.int32)
+        run_count = np.zeros(n, dtype=np.int32)
+        general = False
+        for s0, s1 in segments:
+            if s1 <= s0:
+                continue
+            seg = cl[s0:s1]
+            change = np.nonzero(np.diff(seg))[0] + 1
+            starts = np.concatenate(([0], change))
+            ends = np.concatenate((change, [s1 - s0]))
+            if len(set(seg[starts].tolist())) != len(starts):      # a class in two separate runs: the general host-loop version
+                general = True
+                break
+            for a_, b_ in zip(starts, ends):
+                run_first[s0 + a_:s0 + b_] = s0 + a_
+                run_count[s0 + a_:s0 + b_] = b_ - a_
+        if general:
+            out = []
+            for s0, s1 in segments:
+                if s1 <= s0:
+                    out.append(empty)
+                    continue
+                m, s_, c_ = self.deduplicate_masks_smart_hostloops(packed[s0:s1].contiguous(), list(scores[s0:s1]), list(classes[s0:s1]), iou_threshold)
+                if m is None:
+                    out.append(empty)
+                else:
+                    a_, b_ = self.ops.area_bbox(m)
+                    out.append((m, s_, c_, (a_.cpu().numpy().astype(np.int64), b_.cpu().numpy().astype(np.int64))))
+            return out
         ops = self.ops
         packed = packed.contiguous()
-        run_first = np.repeat(starts, ends - starts).astype(np.int32)
-        run_count = np.repeat(ends - starts, ends - starts).astype(np.int32)
         area_d, bbox_d = ops.area_bbox(packed)
         cset = ops.trace(packed, max_contours=256, bbox=bbox_d, max_points=int(min(4096 * n + (1 << 16), 1 << 26)))
-        ld = int(run_count.max())
-        I = ops.pair_matrix(packed, bbox_d, run_first, run_count, None, ld)
+        ld = max(1, int(run_count.max()))
+        I = ops.pair_matrix(packed, bbox_d, run_first, np.maximum(run_count, 1), None, ld)
         extra = [area_d.to(torch.int32), bbox_d, I]
         try:
             area_h, bbox_h, I_h = cset.fetch(extra=extra)
@@ -563,23 +592,35 @@ class InferencePipeline:
         bbox = np.ascontiguousarray(bbox_h.reshape(n, 4), dtype=np.int64)
         per0 = cset.first_contour_perimeter()
         ok = (bbox[:, 0] >= 0) & ~((per0 > 0) & ((4 * np.pi * area) / np.where(per0 > 0, per0, 1.0) ** 2 < 0.15))
-        items = np.ascontiguousarray(np.nonzero(ok)[0], dtype=np.int32)
+        per_seg = [np.nonzero(ok[s0:s1])[0] + s0 for s0, s1 in segments]
+        items = np.ascontiguousarray(np.concatenate(per_seg) if per_seg else np.zeros(0), dtype=np.int32)
         if len(items) == 0:
-            return (None, [], [], None) if with_tables else (None, [], [])
+            return [empty for _ in segments]
+        T = len(segments)
+        tile_off = np.concatenate(([0], np.cumsum([len(k) for k in per_seg]))).astype(np.int32)
         sc_items = np.ascontiguousarray(np.asarray([scores[i] for i in items], dtype=np.float64))
         cl_items = np.ascontiguousarray(cl[items])
-        tile_off = np.asarray([0, len(items)], dtype=np.int32)
         keep_out = np.zeros(len(items), dtype=np.int32)
-        keep_cnt = np.zeros(1, dtype=np.int32)
+        keep_cnt = np.zeros(T, dtype=np.int32)
         I_c = np.ascontiguousarray(I_h.reshape(n, ld), dtype=np.int32)
         _L.check(ops.lib.demia_host_dedup_smart(I_c.ctypes.data, ld, run_first.ctypes.data, area.ctypes.data, bbox.ctypes.data,
-                                                items.ctypes.data, sc_items.ctypes.data, cl_items.ctypes.data, tile_off.ctypes.data, 1,
+                                                items.ctypes.data, sc_items.ctypes.data, cl_items.ctypes.data, tile_off.ctypes.data, T,
                                                 float(iou_threshold), keep_out.ctypes.data, keep_cnt.ctypes.data), "demia_host_dedup_smart")
-        gl = items[keep_out[:int(keep_cnt[0])]]
-        sel = ops.upload(gl.astype(np.int64))
-        kept = ops.gather_regions(packed, sel, bbox_d.index_select(0, sel))
-        out = (kept, [scores[i] for i in gl], [classes[i] for i in gl])
-        return out + ((area[gl], bbox[gl]),) if with_tables else out
+        gls = [per_seg[t][keep_out[tile_off[t]:tile_off[t] + keep_cnt[t]]] for t in range(T)]
+        flat = np.concatenate(gls) if gls else np.zeros(0, dtype=np.int64)
+        if len(flat) == 0:
+            return [empty for _ in segments]
+        sel = ops.upload(flat.astype(np.int64))
+        kept_all = ops.gather_regions(packed, sel, bbox_d.index_select(0, sel))
+        out, pos = [], 0
+        for gl in gls:
+            k = len(gl)
+            if k == 0:
+                out.append(empty)
+            else:
+                out.append((kept_all[pos:pos + k], [scores[i] for i in gl], [classes[i] for i in gl], (area[gl], bbox[gl])))
+            pos += k
+        return out
 
     def deduplicate_masks_smart_hostloops(self, packed: Optional[torch.Tensor], scores: Sequence[float], classes: Sequence[int],
                                           iou_threshold: float = 0.4):
@@ -764,45 +805,57 @@ class InferencePipeline:
                 pass_tabs = None          # (a DeviceMaskAlgebra there)
             else:
                 big, res, pass_tabs = self._single_class_pass_batched(tile_dets[0], target_class, small_classes, confidence_threshold, iou_threshold)
-            src, xo, yo, un, sc_all = [], [], [], [], []
-            for k, t in enumerate(mine):
-                kept, sc = res[k]
-                src.extend(kept)
-                xo.extend([offs[t][0]] * len(kept))
-                yo.extend([offs[t][1]] * len(kept))
-                un.extend([1 + t] * len(kept))
-                sc_all.extend(sc)
-            if src:
-                n = len(src)
-                tabs_ = pass_tabs
-                if (uh, uw) == (tile_size, tile_size) and tabs_ is not None:
-                    # tiles were not upscaled: the nearest resize back to tile scale is the identity, and the tight boxes the
-                    # class pass reduced are the edge filter's boxes -- one gather of the regions, no launch + wait for boxes
-                    bb = np.asarray(tabs_.bbox)[src]
-                    small = self.ops.gather_regions(big, src, bb)
-                    self.ops.set_frame_width(tile_size)
-                else:
-                    tm = big[torch.tensor(src, dtype=torch.long, device=self.dev)].contiguous()
-                    small = self.ops.place_tiles(tm, [0] * n, [0] * n, tile_size, tile_size, tile_size, tile_size, src_w=uw)
-                    self.ops.set_frame_width(tile_size)
-                    bb = None
-                keep = list(range(n))
-                if edge_filter_enabled:
-                    if bb is None:
-                        _, bb = self.ops.area_bbox(small)
-                        bb = bb.cpu().numpy()
-                    keep = [i for i in range(n) if not (bb[i, 0] < 0 or bb[i, 0] < edge or bb[i, 2] > tile_size - edge
-                                                        or bb[i, 1] < edge or bb[i, 3] > tile_size - edge)]
-                if keep:
-                    sel = torch.tensor(keep, dtype=torch.long, device=self.dev)
-                    glob = self.ops.place_tiles(small[sel].contiguous(), [xo[i] for i in keep], [yo[i] for i in keep],
-                                                tile_size, tile_size, h, w, src_w=tile_size)
-                    tile_masks.append(glob)
-                    tile_scores.extend(sc_all[i] for i in keep)
-                    tile_classes.extend([target_class] * len(keep))
-                    tile_units.extend(un[i] for i in keep)
+            tm_, ts_, tc_, tu_ = self._place_tile_results(big, res, pass_tabs, mine, offs, tile_size, uh, uw, h, w, edge, edge_filter_enabled, target_class)
+            tile_masks += tm_
+            tile_scores += ts_
+            tile_classes += tc_
+            tile_units += tu_
             self.ops.set_frame_width(w)
         return full_masks, full_scores, full_classes, tile_masks, tile_scores, tile_classes, tile_units
+
+    def _place_tile_results(self, big, res, pass_tabs, mine, offs, tile_size, uh, uw, h, w, edge, edge_filter_enabled, target_class):
+        """a13 for one class: the kept masks of this rank's tiles (``res[k]`` = (indices into ``big``, scores) of tile ``mine[k]``) back at
+        tile scale (nearest resize; the identity when the tiles were not upscaled), the edge filter on their boxes, the paste into the
+        global frame.  Returns ([global masks], scores, classes, unit ids)."""
+        tile_masks, tile_scores, tile_classes, tile_units = [], [], [], []
+        src, xo, yo, un, sc_all = [], [], [], [], []
+        for k, t in enumerate(mine):
+            kept, sc = res[k]
+            src.extend(kept)
+            xo.extend([offs[t][0]] * len(kept))
+            yo.extend([offs[t][1]] * len(kept))
+            un.extend([1 + t] * len(kept))
+            sc_all.extend(sc)
+        if src:
+            n = len(src)
+            tabs_ = pass_tabs
+            if (uh, uw) == (tile_size, tile_size) and tabs_ is not None:
+                # tiles were not upscaled: the nearest resize back to tile scale is the identity, and the tight boxes the
+                # class pass reduced are the edge filter's boxes -- one gather of the regions, no launch + wait for boxes
+                bb = np.asarray(tabs_.bbox)[src]
+                small = self.ops.gather_regions(big, src, bb)
+                self.ops.set_frame_width(tile_size)
+            else:
+                tm = big[torch.tensor(src, dtype=torch.long, device=self.dev)].contiguous()
+                small = self.ops.place_tiles(tm, [0] * n, [0] * n, tile_size, tile_size, tile_size, tile_size, src_w=uw)
+                self.ops.set_frame_width(tile_size)
+                bb = None
+            keep = list(range(n))
+            if edge_filter_enabled:
+                if bb is None:
+                    _, bb = self.ops.area_bbox(small)
+                    bb = bb.cpu().numpy()
+                keep = [i for i in range(n) if not (bb[i, 0] < 0 or bb[i, 0] < edge or bb[i, 2] > tile_size - edge
+                                                    or bb[i, 1] < edge or bb[i, 3] > tile_size - edge)]
+            if keep:
+                sel = torch.tensor(keep, dtype=torch.long, device=self.dev)
+                glob = self.ops.place_tiles(small[sel].contiguous(), [xo[i] for i in keep], [yo[i] for i in keep],
+                                            tile_size, tile_size, h, w, src_w=tile_size)
+                tile_masks.append(glob)
+                tile_scores.extend(sc_all[i] for i in keep)
+                tile_classes.extend([target_class] * len(keep))
+                tile_units.extend(un[i] for i in keep)
+        return tile_masks, tile_scores, tile_classes, tile_units
 
     # ------------------------------------------------------------------ f4: flagged NON-parity modes
     def soft_nms_merge(self, packed: Optional[torch.Tensor], scores: Sequence[float], classes: Sequence[int],
@@ -996,6 +1049,77 @@ class InferencePipeline:
             if not ensemble_by_class.get(cls, False):
                 sc = [np.float32(v) for v in sc]      # single-model scores are the predictor's float32 values
             out[cls] = self.deduplicate_masks_smart(packed_all[sel].contiguous(), sc, [cls] * len(rows), 0.4)
+        return out
+
+    def tile_pipeline_all_classes(self, image_key: str, image_dev: torch.Tensor, class_params: Dict[int, Tuple[float, float]], small_classes,
+                                  tile_size=512, overlap_ratio=0.1, upscale_factor=2.0, edge_filter_enabled=True):
+        """``tile_based_inference_pipeline`` (``inference.py:2299-2485``) of ONE model for ALL classes of an image at once, in phases
+        instead of class by class -- the same kernels on the same masks, TWO device-to-host waits instead of four per class:
+        (1) the class passes of every class over the full image AND over the tiles are enqueued back to back and their tables
+        fetched together; (2) after the placement of the tile results (a13) the per-class 0.4 merges run as the segments of one
+        ``deduplicate_masks_smart_segments`` call.  ``class_params``: {class: (confidence threshold, IoU threshold)} in class-loop
+        order.  Returns {class: (masks, scores, classes)} exactly as the per-class calls do (checked byte for byte on the CLI's
+        files: ``test_grouped_padded_and_graphed_forwards_write_the_image_by_image_files`` runs both)."""
+        assert self.world == 1 and self.merge_mode == "smart"
+        h, w = int(image_dev.shape[0]), int(image_dev.shape[1])
+        offs = self._tile_offsets(h, w, tile_size, overlap_ratio)
+        uh = uw = int(tile_size * upscale_factor)
+        mine = list(range(len(offs)))
+        edge = int(tile_size * overlap_ratio / 2)
+        full_det = self._predict_batch(0, image_key + "|full", image_dev[None])
+        tkey = self._tiles_key(image_key, tile_size, overlap_ratio, upscale_factor)
+        tile_dets = self._predict_batch(0, tkey, None if (0, tkey) in self._cache else self._my_tiles(image_dev, tile_size, overlap_ratio, upscale_factor))
+        # ---- phase 1: every class pass enqueued, one wait --------------------------------------------------------------------
+        handles = []
+        for cls, (conf, _) in class_params.items():
+            self.ops.set_frame_width(w)
+            hf = self._single_class_pass_launch(full_det, cls, small_classes, conf)
+            self.ops.set_frame_width(uw)           # the tile masks' own frame: its right border is pixel uw - 1
+            ht = self._single_class_pass_launch(tile_dets, cls, small_classes, conf)
+            handles.append((cls, hf, ht))
+        live = [h_ for _, hf, ht in handles for h_ in (hf, ht) if h_ is not None]
+        host = torch.cat([t_ for h_ in live for t_ in (h_["ncols"], h_["area"], h_["bbox"].reshape(-1), h_["I"].reshape(-1))]).cpu().numpy() if live else None
+        if live:
+            self.d2h_waits += 1
+        pos = 0
+
+        def tables(h_):
+            nonlocal pos
+            T, n, ld = h_["T"], h_["n"], h_["ld"]
+            tabs = dict(ncols=host[pos:pos + T], area=host[pos + T:pos + T + n].astype(np.int64),
+                        bbox=host[pos + T + n:pos + T + 5 * n].reshape(n, 4).astype(np.int64),
+                        I=np.ascontiguousarray(host[pos + T + 5 * n:pos + T + 5 * n + n * ld]).reshape(n, ld))
+            pos += T + 5 * n + n * ld
+            return tabs
+        parts, scores, classes, segments = [], [], [], []
+        for cls, hf, ht in handles:
+            iou_thr = class_params[cls][1]
+            is_small = cls in small_classes
+            s0 = len(scores)
+            if hf is not None:
+                big, res, tabs = self._single_class_pass_finish(hf, tables(hf), is_small, iou_thr)
+                kept, sc = res[0]
+                if kept:
+                    self.ops.set_frame_width(w)
+                    parts.append(self.ops.gather_regions(big, kept, tabs.bbox[kept]))
+                    scores += list(sc)
+                    classes += [cls] * len(kept)
+            if ht is not None:
+                big, res, tabs = self._single_class_pass_finish(ht, tables(ht), is_small, iou_thr)
+                self.ops.set_frame_width(uw)
+                tm_, ts_, tc_, _ = self._place_tile_results(big, res, tabs, mine, offs, tile_size, uh, uw, h, w, edge, edge_filter_enabled, cls)
+                parts += tm_
+                scores += ts_
+                classes += tc_
+            segments.append((s0, len(scores)))
+        self.ops.set_frame_width(w)
+        out = {cls: (None, [], []) for cls in class_params}
+        if not parts:
+            return out
+        # ---- phase 2: the per-class 0.4 merges (inference.py:2452-2472) as the segments of one call, one wait --------------------
+        merged = self.deduplicate_masks_smart_segments(torch.cat(parts, dim=0), scores, classes, segments, 0.4)
+        for (cls, _, _), m in zip(handles, merged):
+            out[cls] = m[:3]
         return out
 
     def tile_based_inference_pipeline(self, model_ids: Sequence[int], image_key: str, image_dev: torch.Tensor, target_class,
@@ -1972,6 +2096,32 @@ def run_inference(dataset_name, output_dir, visualize=True, threshold=0.65, draw
             parts, all_scores, all_classes = [], [], []
             locals_by_class, ens_by_class, local_err = {}, {}, None
             targets = range(num_classes) if classes_to_infer is None else [c for c in classes_to_infer if c < num_classes]
+            fast = {}
+            if phases_ok:
+                for target_class in targets:
+                    is_small = target_class in small_classes
+                    ccfg = class_specific_settings.get(f"class_{target_class}", {})
+                    use_ens = ensemble_enabled and (not ensemble_small_only or is_small)
+                    if (use_ens and len(predictors) > 1) or pipe.uses_multiscale(target_class):
+                        fast = None
+                        break
+                    if confidence_mode == "manual":
+                        conf = ccfg.get("confidence_threshold", 0.3 if is_small else 0.5)
+                    else:
+                        if image_host is None:
+                            image_host = image_dev.cpu().numpy()
+                        conf = get_confidence_threshold(image_host, target_class, small_classes, global_config)
+                    fast[target_class] = (conf, ccfg.get("iou_threshold", 0.5 if is_small else 0.7))
+            if fast:
+                # every class goes through the one model's standard passes: all classes in phases, two waits (tile_pipeline_all_classes)
+                by_class = pipe.tile_pipeline_all_classes(name, image_dev, fast, small_classes, tile_size, overlap_ratio, upscale_factor, edge_filter_enabled)
+                for target_class in targets:
+                    m, s, c = by_class[target_class]
+                    if m is not None and m.shape[0]:
+                        parts.append(m)
+                        all_scores.extend(s)
+                        all_classes.extend(c)
+                targets = []
             for target_class in targets:
                 is_small = target_class in small_classes
                 ccfg = class_specific_settings.get(f"class_{target_class}", {})
@@ -2052,6 +2202,7 @@ def run_inference(dataset_name, output_dir, visualize=True, threshold=0.65, draw
     # DEEPEMIA_IMAGE_THREADS=k (experiment switch, default 1): the images of a group are post-processed by k host threads at once
     # (every thread its own MaskOps; forwards stay on this thread) -- their device-to-host waits then overlap instead of queueing
     # one after the other behind the next group's convolution grids
+    phases_ok = pipe.world == 1 and pipe.merge_mode == "smart" and os.environ.get("DEEPEMIA_IMAGE_PHASES", "1") == "1"     # (A/B switch)
     image_threads = max(1, int(os.environ.get("DEEPEMIA_IMAGE_THREADS", "1"))) if pipe.world == 1 else 1
     image_pool = ThreadPoolExecutor(max_workers=image_threads) if image_threads > 1 else None
 

@@ -472,8 +472,9 @@ def test_one_ranks_failure_on_an_image_makes_every_rank_skip_that_image_together
 def test_grouped_padded_and_graphed_forwards_write_the_image_by_image_files(tmp_path, monkeypatch, gpu_device):
     """The image loop batches the forwards of a GROUP of images across the images, pads a short last group to the captured batch
     shape and, for a long folder, replays hipGraphs from the first group on.  None of it may change a byte: seven images in groups
-    of three (3 + 3 + 1 padded, graphs from group 0) against the same folder image by image (groups of one: no cross-image batch, no
-    padding), and with two host threads per group (``DEEPEMIA_IMAGE_THREADS``)."""
+    of three (3 + 3 + 1 padded, graphs from group 0; all classes of an image in phases, ``tile_pipeline_all_classes``) against the same
+    folder image by image and class by class (groups of one: no cross-image batch, no padding; ``DEEPEMIA_IMAGE_PHASES=0``: one
+    ``tile_based_inference_pipeline`` call per class), and with two host threads per group (``DEEPEMIA_IMAGE_THREADS``)."""
     tile = {"tile_size": 256, "overlap_ratio": 0.125, "upscale_factor": 1.0, "edge_filter_enabled": True}
     ds_cfg = {"inference_overrides": {"confidence_mode": "manual",
                                       "class_specific_settings": {"class_0": {"confidence_threshold": 0.3, "iou_threshold": 0.6},
@@ -482,9 +483,9 @@ def test_grouped_padded_and_graphed_forwards_write_the_image_by_image_files(tmp_
     cfgdir, split, sds, images = _write_tree(tmp_path, [50], 0.5, 6.0, 7, 512, ds_cfg)
     monkeypatch.setenv("DEEPEMIA_WORKERS", "1")
     outs = {}
-    for label, env in (("one_by_one", {"DEEPEMIA_IMAGE_GROUP": "1"}), ("groups_of_three", {"DEEPEMIA_IMAGE_GROUP": "3"}),
+    for label, env in (("one_by_one", {"DEEPEMIA_IMAGE_GROUP": "1", "DEEPEMIA_IMAGE_PHASES": "0"}), ("groups_of_three", {"DEEPEMIA_IMAGE_GROUP": "3"}),
                        ("groups_of_three_two_threads", {"DEEPEMIA_IMAGE_GROUP": "3", "DEEPEMIA_IMAGE_THREADS": "2"})):
-        for k in ("DEEPEMIA_IMAGE_GROUP", "DEEPEMIA_IMAGE_THREADS"):
+        for k in ("DEEPEMIA_IMAGE_GROUP", "DEEPEMIA_IMAGE_THREADS", "DEEPEMIA_IMAGE_PHASES"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
