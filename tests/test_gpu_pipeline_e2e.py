@@ -407,6 +407,15 @@ def _cli_rank_worker(rank, world, port, root, cfgdir, fail_rank, fail_image, enc
         return orig(self, model_ids, image_key, *a, **k)
 
     INF.InferencePipeline._tile_pipeline_local = flaky
+    orig_all = INF.InferencePipeline.tile_pipeline_all_classes
+
+    def flaky_all(self, image_key, *a, **k):          # (images sharded over ranks: every class of an image in phases)
+        state["image"] = image_key
+        if (fail_rank is None or rank == fail_rank) and image_key == fail_image:
+            raise RuntimeError(f"injected failure of the passes of {fail_image}")
+        return orig_all(self, image_key, *a, **k)
+
+    INF.InferencePipeline.tile_pipeline_all_classes = flaky_all
     orig_encode = INF.parallel.encode_instance_table
 
     def flaky_encode(*a, **k):
