@@ -36,7 +36,8 @@ from ..utils.logger_utils import log_memory_usage, system_logger
 from ..utils.mask_algebra import DeviceMaskAlgebra
 from ..utils.measurements import contrast_percentiles
 from ..utils.mask_utils import (mask_crops, postprocess_masks_device, postprocess_masks_universal_device,
-                                process_masks_device, rle_encoding_packed, rle_text_packed)
+                                process_masks_device, rle_crop_launch, rle_encoding_packed, rle_text_from_payload,
+                                rle_text_packed)
 from ..utils.spatial_constraints import apply_spatial_constraints_indices, load_spatial_constraints
 
 CSV_HEADER = ["Instance_ID", "Class", "Class_Name", "Major axis length", "Minor axis length", "Eccentricity", "C. Length",
@@ -2180,14 +2181,21 @@ def run_inference(dataset_name, output_dir, visualize=True, threshold=0.65, draw
             n_final = 0 if packed is None else int(packed.shape[0])
             result = {"masks": packed, "scores": scores, "classes": classes, "hw": (int(image_dev.shape[0]), int(image_dev.shape[1])),
                       "area": None if tabs is None else tabs[0], "bbox": None if tabs is None else tabs[1]}
-            # a16: one crop launch + one native call for the image's EncodedPixels texts (mask_utils.rle_text_packed)
-            texts = rle_text_packed(pipe.ops, packed, area=tabs[0], bbox=tabs[1]) if n_final else []
+            # a16: one crop launch + one native call for the image's EncodedPixels texts; where this rank also measures the image, the
+            # cropped words come to the host in the SAME copy as the contour tables (one wait for RLE + measurements)
+            texts = []
             if shard_images or job_rank == 0:
                 # the measurement phase of this image (inference.py:1030-1291) while its masks and pixels are still resident: the
                 # reference walks the folder a second time after the image loop, which gives the same rows; done here, a folder
                 # of any length holds the masks of ONE image group at a time, and a rank measures the images it owns
+                crop = rle_crop_launch(pipe.ops, packed, tabs[0], tabs[1]) if n_final else None
+                extra = [crop[0]] if crop is not None else None
                 rows_by_image[name] = measure_image(pipe.ops, name, result, inpath, output_dir, metadata, dataset_name, draw_scalebar,
-                                                    visualize, image_dev=image_dev)
+                                                    visualize, image_dev=image_dev, extra=extra)
+                if crop is not None:
+                    texts = rle_text_from_payload(extra[0], crop[1], crop[2], int(packed.shape[1]))
+            elif n_final:
+                texts = rle_text_packed(pipe.ops, packed, area=tabs[0], bbox=tabs[1])
             if not keep_masks:
                 result["masks"] = None
             dedup_results[name] = result
@@ -2398,7 +2406,8 @@ def measurement_csv_text(tiles, thing_classes, min_area: float, psum: str = "0")
 
 
 def measure_image(ops: MaskOps, test_img: str, data: dict, test_img_path: str, output_dir: str, metadata, dataset_name: str,
-                  draw_scalebar: bool = False, visualize: bool = False, image_dev: Optional[torch.Tensor] = None) -> List[list]:
+                  draw_scalebar: bool = False, visualize: bool = False, image_dev: Optional[torch.Tensor] = None,
+                  extra: Optional[list] = None) -> List[list]:
     """The measurement phase of ONE image (``inference.py:1030-1291``): scale bar, contours + the 12 measurements of every final
     mask, optional contrast percentiles, optional overlay / scale-bar debug images; returns the image's CSV rows.
     ``image_dev``: the decoded image when the caller still holds it on the device (the image loop does: the reference re-reads
@@ -2431,10 +2440,17 @@ def measure_image(ops: MaskOps, test_img: str, data: dict, test_img_path: str, o
     ops.set_frame_width(wd)
     min_area = max(5, h * wd * 0.000005 * 0.05)
     if data.get("bbox") is not None:       # pixel counts / tight boxes already on the host (the image loop): no reduction, no wait for it
+        # (``extra``: a list of int32 device tensors the image loop wants on the host in the same copy -- the cropped words of the RLE
+        # texts --; replaced in place by their host arrays)
         recs = ops.contours(packed, max_contours=256, um_pix=um_pix, bbox=ops.upload(np.ascontiguousarray(data["bbox"], dtype=np.int32)),
-                            total_area=int(np.sum(data["area"])))
+                            total_area=int(np.sum(data["area"])), extra=extra)
+        if extra is not None:
+            recs, host = recs
+            extra[:] = host
     else:
         recs = ops.contours(packed, max_contours=256, um_pix=um_pix)
+        if extra is not None:
+            extra[:] = [e.cpu().numpy() for e in extra]
     contrast = [(None, None, None)] * int(packed.shape[0])
     if measure_contrast:
         # measurements.py:195-215: gray levels under the whole instance mask; the histogram is a device reduction

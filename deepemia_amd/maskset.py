@@ -329,20 +329,23 @@ class MaskOps:
         return cs
 
     def contours(self, packed: torch.Tensor, max_contours: int = 64, max_points: Optional[int] = None,
-                 um_pix: float = 1.0, measure: bool = True, bbox: Optional[torch.Tensor] = None, total_area: Optional[int] = None):
+                 um_pix: float = 1.0, measure: bool = True, bbox: Optional[torch.Tensor] = None, total_area: Optional[int] = None,
+                 extra: Optional[Sequence[torch.Tensor]] = None):
         """Per mask: external contours in OpenCV's order, with area, perimeter and the 12 measurement
         values.  Returns a list (per mask) of lists of dicts with keys ``points`` (P, 2) int32,
-        ``area``, ``perimeter`` and (if ``measure``) ``values`` (12,) float64."""
+        ``area``, ``perimeter`` and (if ``measure``) ``values`` (12,) float64.  ``extra``: int32 device tensors that come to the
+        host in the SAME copy (e.g. the cropped words the RLE texts are made of); the call then returns (records, host arrays)."""
         if int(packed.shape[0]) == 0:
-            return []
+            return [] if extra is None else ([], [e.cpu().numpy() for e in extra])
         cs = self.trace(packed, max_contours, max_points, bbox=bbox, total_area=total_area)
         # ONE device-to-host wait: the measurements of every mask's first contours are enqueued right behind the trace and come
         # over with the counts, the contour tables and the points (a mask with more than four contours falls back to the
         # sliced copies of ContourSet.host(): five waits, rare)
         if measure:
             cs.launch_measure(um_pix, slots=4)
-        cs.fetch(with_points=True)
-        return cs.records(um_pix=um_pix, measure=measure)
+        got = cs.fetch(extra=extra, with_points=True)
+        recs = cs.records(um_pix=um_pix, measure=measure)
+        return recs if extra is None else (recs, list(got))
 
 
 class ContourSet:

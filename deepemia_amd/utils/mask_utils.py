@@ -83,28 +83,28 @@ def rle_encoding_packed(ops, packed: torch.Tensor, W: int) -> List[List[int]]:
     return [[] if c is None else rle_from_crop(c[2], c[0], c[1], H) for c in mask_crops(ops, packed)]
 
 
-def rle_text_packed(ops, packed: torch.Tensor, area=None, bbox=None) -> List[str]:
-    """The ``EncodedPixels`` text of every packed device mask (``" ".join(map(str, rle_encoding(mask)))``, reference
-    ``inference.py:917-925``): one crop launch, one device-to-host copy of the bounding-box words, ONE native call for all masks
-    (``demia_host_rle_text``) -- the per-mask numpy encoding + str() of ~40 000 integers per image was 14 ms of a 70-ms image.
-    ``area`` / ``bbox`` (host arrays of the tight boxes) save the reduction when the caller has them."""
-    import ctypes as C
-
-    from .. import _lib, parallel
+def rle_crop_launch(ops, packed: torch.Tensor, area, bbox):
+    """First half of :func:`rle_text_packed`: the crop launch.  Returns (payload on the device, boxes, offsets) -- the caller brings
+    the payload to the host together with whatever else it waits for and hands it to :func:`rle_text_from_payload`."""
+    from .. import parallel
 
     n = int(packed.shape[0])
-    if n == 0:
-        return []
-    if bbox is None or area is None:
-        a, b = ops.area_bbox(packed)
-        area, bbox = a.cpu().numpy(), b.cpu().numpy()
     bb = np.ascontiguousarray(bbox, dtype=np.int32).reshape(n, 4)
-    hdr, pay = parallel.encode_instance_table(packed, [0.0] * n, [0] * n, [0] * n, bb, np.asarray(area))
-    pay = np.ascontiguousarray(pay.cpu().numpy())
+    _, pay = parallel.encode_instance_table(packed, [0.0] * n, [0] * n, [0] * n, bb, np.asarray(area))
     hd = np.zeros((n, parallel.HDR), dtype=np.int32)
     hd[:, 4:8] = bb
     offs = np.ascontiguousarray(parallel._offsets(parallel._payload_lengths(hd)), dtype=np.int64)
-    H = int(packed.shape[1])
+    return pay, bb, offs
+
+
+def rle_text_from_payload(pay: np.ndarray, bb: np.ndarray, offs: np.ndarray, H: int) -> List[str]:
+    """Second half: ONE native call for all masks (``demia_host_rle_text``) over the cropped words on the host."""
+    import ctypes as C
+
+    from .. import _lib
+
+    n = int(bb.shape[0])
+    pay = np.ascontiguousarray(pay)
     toff = np.zeros(n + 1, dtype=np.int64)
     cap = max(1 << 16, 16 * int(pay.size) + 64)
     lib = _lib.load()
@@ -116,6 +116,21 @@ def rle_text_packed(ops, packed: torch.Tensor, area=None, bbox=None) -> List[str
         cap = -got + 64
     raw = out.raw[:got].decode("ascii")
     return [raw[toff[i]:toff[i + 1]] for i in range(n)]
+
+
+def rle_text_packed(ops, packed: torch.Tensor, area=None, bbox=None) -> List[str]:
+    """The ``EncodedPixels`` text of every packed device mask (``" ".join(map(str, rle_encoding(mask)))``, reference
+    ``inference.py:917-925``): one crop launch, one device-to-host copy of the bounding-box words, ONE native call for all masks
+    (``demia_host_rle_text``) -- the per-mask numpy encoding + str() of ~40 000 integers per image was 14 ms of a 70-ms image.
+    ``area`` / ``bbox`` (host arrays of the tight boxes) save the reduction when the caller has them."""
+    n = int(packed.shape[0])
+    if n == 0:
+        return []
+    if bbox is None or area is None:
+        a, b = ops.area_bbox(packed)
+        area, bbox = a.cpu().numpy(), b.cpu().numpy()
+    pay, bb, offs = rle_crop_launch(ops, packed, area, bbox)
+    return rle_text_from_payload(pay.cpu().numpy(), bb, offs, int(packed.shape[1]))
 
 
 def postprocess_masks_device(ops, packed: torch.Tensor, scores: np.ndarray, min_crys_size: Optional[int] = None,
