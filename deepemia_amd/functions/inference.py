@@ -2445,8 +2445,8 @@ def measure_image(ops: MaskOps, test_img: str, data: dict, test_img_path: str, o
         recs = ops.contours(packed, max_contours=256, um_pix=um_pix, bbox=ops.upload(np.ascontiguousarray(data["bbox"], dtype=np.int32)),
                             total_area=int(np.sum(data["area"])), extra=extra)
         if extra is not None:
-            recs, host = recs
-            extra[:] = host
+            recs, extra_host = recs
+            extra[:] = extra_host
     else:
         recs = ops.contours(packed, max_contours=256, um_pix=um_pix)
         if extra is not None:
