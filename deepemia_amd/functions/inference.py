@@ -519,7 +519,7 @@ class InferencePipeline:
 
     # ------------------------------------------------------------------ a14
     def deduplicate_masks_smart(self, packed: Optional[torch.Tensor], scores: Sequence[float], classes: Sequence[int],
-                                iou_threshold: float = 0.4, with_tables: bool = False):
+                                iou_threshold: float = 0.4, with_tables: bool = False, all_pairs: bool = False):
         """``inference.py:2552-2677`` bug-for-bug (N6); see oracle/postproc_ref.py for the dense twin.
 
         ONE device-to-host wait: pixel counts and tight boxes, the contour trace (first-contour perimeters for the compactness
@@ -530,16 +530,19 @@ class InferencePipeline:
         70-ms image.  ``with_tables``: also return (area, bbox) of the kept masks (host arrays)."""
         if packed is None or packed.shape[0] == 0:
             return (None, [], [], None) if with_tables else (None, [], [])
-        out = self.deduplicate_masks_smart_segments(packed, scores, classes, [(0, int(packed.shape[0]))], iou_threshold)[0]
+        out = self.deduplicate_masks_smart_segments(packed, scores, classes, [(0, int(packed.shape[0]))], iou_threshold, all_pairs=all_pairs)[0]
         return out if with_tables else out[:3]
 
     def deduplicate_masks_smart_segments(self, packed: torch.Tensor, scores: Sequence[float], classes: Sequence[int],
-                                         segments: Sequence[Tuple[int, int]], iou_threshold: float):
+                                         segments: Sequence[Tuple[int, int]], iou_threshold: float, all_pairs: bool = False):
         """:meth:`deduplicate_masks_smart` for SEVERAL independent calls at once -- ``segments`` = [start, end) of each call's masks in
         ``packed`` (the two per-class 0.4 merges of an image) -- with ONE device-to-host wait for all of them: one reduction, one contour
         trace and one pair matrix over the (segment, class) runs, one native call with a "tile" per segment (every segment is
         filtered with its own local indices, N6 included: exactly what separate calls do).  Returns per segment
-        (masks, scores, classes, (area, bbox)) -- (None, [], [], None) for an empty result."""
+        (masks, scores, classes, (area, bbox, inter)) -- (None, [], [], None) for an empty result.  ``all_pairs``: the pair matrix
+        covers EVERY pair of a segment, not only the same-class ones the filter itself reads, and ``inter`` is the survivors'
+        symmetric intersection matrix (else None): the spatial constraints that follow the 0.7 pass of an image then need no
+        device work of their own (``DeviceMaskAlgebra.preload``)."""
         empty = (None, [], [], None)
         n = int(packed.shape[0])
         if n == 0:
@@ -561,6 +564,9 @@ class InferencePipeline:
             for a_, b_ in zip(starts, ends):
                 run_first[s0 + a_:s0 + b_] = s0 + a_
                 run_count[s0 + a_:s0 + b_] = b_ - a_
+            if all_pairs:
+                run_first[s0:s1] = s0
+                run_count[s0:s1] = s1 - s0
         if general:
             out = []
             for s0, s1 in segments:
@@ -572,7 +578,7 @@ class InferencePipeline:
                     out.append(empty)
                 else:
                     a_, b_ = self.ops.area_bbox(m)
-                    out.append((m, s_, c_, (a_.cpu().numpy().astype(np.int64), b_.cpu().numpy().astype(np.int64))))
+                    out.append((m, s_, c_, (a_.cpu().numpy().astype(np.int64), b_.cpu().numpy().astype(np.int64), None)))
             return out
         ops = self.ops
         packed = packed.contiguous()
@@ -619,7 +625,14 @@ class InferencePipeline:
             if k == 0:
                 out.append(empty)
             else:
-                out.append((kept_all[pos:pos + k], [scores[i] for i in gl], [classes[i] for i in gl], (area[gl], bbox[gl])))
+                inter = None
+                if all_pairs:
+                    s0 = int(run_first[gl[0]])
+                    lo, hi = np.minimum(gl[:, None], gl[None, :]), np.maximum(gl[:, None], gl[None, :])
+                    inter = I_c[lo, np.minimum(hi - s0, ld - 1)].astype(np.int64)      # row i, column j - first[i] holds |i & j| for j > i
+                    d_ = np.arange(k)
+                    inter[d_, d_] = area[gl]
+                out.append((kept_all[pos:pos + k], [scores[i] for i in gl], [classes[i] for i in gl], (area[gl], bbox[gl], inter)))
             pos += k
         return out
 
@@ -2170,9 +2183,13 @@ def run_inference(dataset_name, output_dir, visualize=True, threshold=0.65, draw
                         all_classes.extend(c)
             packed = torch.cat(parts, dim=0) if parts else None
             pipe.ops.set_frame_width(int(image_dev.shape[1]))
-            packed, scores, classes, tabs = pipe.deduplicate_masks_smart(packed, all_scores, all_classes, iou_threshold=0.7, with_tables=True)
+            constrained = bool(spatial_cfg and spatial_cfg.get("enabled", False))
+            packed, scores, classes, tabs = pipe.deduplicate_masks_smart(packed, all_scores, all_classes, iou_threshold=0.7, with_tables=True,
+                                                                        all_pairs=constrained)
             if packed is not None and packed.shape[0]:
                 alg = DeviceMaskAlgebra(pipe.ops, packed, area=tabs[0], bbox=tabs[1])       # (pixel counts / boxes: already on the host)
+                if tabs[2] is not None:
+                    alg.preload(tabs[2])        # ... and every pair's intersection: the constraints below launch and wait for nothing
                 keep = apply_spatial_constraints_indices(alg, scores, classes, spatial_cfg)
                 if len(keep) != int(packed.shape[0]):
                     packed = pipe.ops.gather_regions(packed, keep, tabs[1][keep])
