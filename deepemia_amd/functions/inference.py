@@ -2183,7 +2183,7 @@ def run_inference(dataset_name, output_dir, visualize=True, threshold=0.65, draw
                         all_classes.extend(c)
             packed = torch.cat(parts, dim=0) if parts else None
             pipe.ops.set_frame_width(int(image_dev.shape[1]))
-            constrained = bool(spatial_cfg and spatial_cfg.get("enabled", False))
+            constrained = bool(spatial_cfg and spatial_cfg.get("enabled", False)) and os.environ.get("DEEPEMIA_ALL_PAIRS", "1") == "1"   # (A/B switch)
             packed, scores, classes, tabs = pipe.deduplicate_masks_smart(packed, all_scores, all_classes, iou_threshold=0.7, with_tables=True,
                                                                         all_pairs=constrained)
             if packed is not None and packed.shape[0]:

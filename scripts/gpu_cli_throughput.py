@@ -52,7 +52,8 @@ def run_cli(root, cfgdir, split, workers, n, profile=False, rocprof=False):
     loop_s = max((a * b for a, b in loops), default=None)          # the slowest rank's image loop
     tm = re.search(r"Inference task finished in ([0-9.]+)s", log)
     rows = list(csv.reader(open(split / "measurements_results.csv"))) if (split / "measurements_results.csv").exists() else []
-    sha = hashlib.sha256(b"".join(open(split / f, "rb").read() for f in ("measurements_results.csv", "R50_flip_results.csv"))).hexdigest() if rows else None
+    # (rows sorted: the folder's listing order differs from one temporary directory to the next, the rows themselves must not)
+    sha = hashlib.sha256(b"".join(b"".join(sorted(open(split / f, "rb").readlines())) for f in ("measurements_results.csv", "R50_flip_results.csv"))).hexdigest() if rows else None
     return {"rc": r.returncode, "workers": workers, "images": n, "wall_s_incl_start_up": dt, "csv_rows": max(len(rows) - 1, 0),
             "image_loop_s": loop_s, "image_loop_ms_per_image": (1e3 * loop_s / n if loop_s else None),
             "tile_forwards_per_image": 1 + TILES_PER_IMAGE,
